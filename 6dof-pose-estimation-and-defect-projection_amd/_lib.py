@@ -1,0 +1,313 @@
+"""ctypes binding of libpedp_hip.so (C ABI: include/pedp.h).
+
+The library is the product: if it is missing, cannot be loaded, or no GPU answers,
+every entry point raises -- there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PEDP_LIB", os.path.join(_HERE, "libpedp_hip.so"))
+
+HOST, DEVICE = 0, 1
+POINT_TO_PLANE, POINT_TO_POINT = 0, 1
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_correspondence_distance", C.c_double),
+        ("estimator", C.c_int),
+        ("max_iteration", C.c_int),
+        ("relative_fitness", C.c_double),
+        ("relative_rmse", C.c_double),
+        ("allreduce", ALLREDUCE_FN),
+        ("allreduce_user", C.c_void_p),
+        ("n_source_global", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/pedp.h declares
+_P = C.POINTER
+PROTOTYPES = {
+    "pedp_version": (C.c_int, []),
+    "pedp_last_error": (C.c_char_p, []),
+    "pedp_device_count": (C.c_int, [_P(C.c_int)]),
+    "pedp_ctx_create": (C.c_int, [C.c_int, C.c_void_p, _P(C.c_void_p)]),
+    "pedp_ctx_destroy": (None, [C.c_void_p]),
+    "pedp_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "pedp_mesh_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
+    "pedp_mesh_destroy": (None, [C.c_void_p]),
+    "pedp_mesh_size": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64)]),
+    "pedp_raycast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
+    "pedp_cloud_destroy": (None, [C.c_void_p]),
+    "pedp_cloud_size": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int)]),
+    "pedp_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_void_p,
+                           _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_void_p, C.c_void_p]),
+    "pedp_icp_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "pedp_cluster_poses": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, _P(C.c_int)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class PedpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every prototype.  Raises if it is absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PedpError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                f"`python 6dof-pose-estimation-and-defect-projection_amd/build.py` "
+                "(this package has no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the header disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().pedp_last_error()
+        raise PedpError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().pedp_device_count(C.byref(n)), "pedp_device_count")
+    return n.value
+
+
+class Context:
+    """One GPU + one HIP stream.  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so torch.distributed collectives order
+    with the library's kernels."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        self.device = device
+        lib = load()
+        check(lib.pedp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)),
+              "pedp_ctx_create")
+
+    def synchronize(self):
+        check(load().pedp_ctx_synchronize(self._h), "pedp_ctx_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().pedp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (own stream)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx
+
+
+class Mesh:
+    """Device-resident triangle records of one posed mesh (RaycastingScene stand-in)."""
+
+    def __init__(self, ctx, vertices, triangles):
+        self.ctx = ctx
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        t = np.asarray(triangles)
+        if t.size and (t.min() < 0):
+            raise PedpError("negative vertex index")
+        t = np.ascontiguousarray(t, dtype=np.uint32).reshape(-1, 3)
+        self.V, self.F = len(v), len(t)
+        self._h = C.c_void_p()
+        check(load().pedp_mesh_create(ctx._h, _ptr(v), self.V, _ptr(t), self.F, C.byref(self._h)),
+              "pedp_mesh_create")
+
+    def cast_rays(self, rays6, want_uv=True):
+        """rays6: N x 6 float32 host array.  Returns dict like RaycastingScene.cast_rays:
+        t_hit (f32, inf on miss), primitive_ids (u32, 0xFFFFFFFF on miss), primitive_uvs."""
+        r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
+        n = len(r)
+        t = np.empty(n, np.float32)
+        ids = np.empty(n, np.uint32)
+        uv = np.empty((n, 2), np.float32) if want_uv else None
+        check(load().pedp_raycast(self.ctx._h, self._h, _ptr(r), n, HOST, _ptr(t), _ptr(ids), _ptr(uv)),
+              "pedp_raycast")
+        out = {"t_hit": t, "primitive_ids": ids}
+        if want_uv:
+            out["primitive_uvs"] = uv
+        return out
+
+    def cast_rays_device(self, rays_ptr, n, t_ptr, id_ptr, uv_ptr=None):
+        """Device-pointer variant (torch tensors' data_ptr()); asynchronous on the stream."""
+        check(load().pedp_raycast(self.ctx._h, self._h, C.c_void_p(rays_ptr), int(n), DEVICE, C.c_void_p(t_ptr),
+                                  C.c_void_p(id_ptr), C.c_void_p(uv_ptr) if uv_ptr else None), "pedp_raycast")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().pedp_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Cloud:
+    """Device-resident float64 point cloud (+ normals)."""
+
+    def __init__(self, ctx, points, normals=None):
+        self.ctx = ctx
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        nrm = None
+        if normals is not None and len(normals):
+            nrm = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+            if len(nrm) != len(p):
+                raise PedpError("normals and points differ in length")
+        self.N = len(p)
+        self.has_normals = nrm is not None
+        self._h = C.c_void_p()
+        check(load().pedp_cloud_create(ctx._h, _ptr(p), _ptr(nrm), self.N, C.byref(self._h)), "pedp_cloud_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().pedp_cloud_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def raycast_configure(ctx, tri_chunks=0, variant=0):
+    check(load().pedp_raycast_configure(ctx._h, int(tri_chunks), int(variant)), "pedp_raycast_configure")
+
+
+def raycast_last_sweep_ms(ctx):
+    ms = C.c_float(0)
+    check(load().pedp_raycast_last_sweep_ms(ctx._h, C.byref(ms)), "pedp_raycast_last_sweep_ms")
+    return ms.value
+
+
+def nn_last_sweep_ms(ctx):
+    ms = C.c_float(0)
+    check(load().pedp_nn_last_sweep_ms(ctx._h, C.byref(ms)), "pedp_nn_last_sweep_ms")
+    return ms.value
+
+
+def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,
+        relative_fitness=1e-6, relative_rmse=1e-6, want_corr=False, want_trace=False, allreduce=None,
+        n_source_global=0):
+    """Raw pedp_icp call on Cloud handles.  Returns dict(T, fitness, inlier_rmse, iters[, corr, trace])."""
+    prm = IcpParams()
+    prm.max_correspondence_distance = float(max_correspondence_distance)
+    prm.estimator = int(estimator)
+    prm.max_iteration = int(max_iteration)
+    prm.relative_fitness = float(relative_fitness)
+    prm.relative_rmse = float(relative_rmse)
+    cb = None
+    if allreduce is not None:
+        def _hook(user, dev_ptr, n, stream):
+            try:
+                allreduce(dev_ptr, n, stream)
+                return 0
+            except Exception:  # an exception must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLREDUCE_FN(_hook)
+        prm.allreduce = cb
+    else:
+        prm.allreduce = C.cast(None, ALLREDUCE_FN)
+    prm.allreduce_user = None
+    prm.n_source_global = int(n_source_global)
+    T0 = np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+    T = np.empty((4, 4), np.float64)
+    fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+    corr = np.empty(source.N, np.int32) if want_corr else None
+    trace = np.zeros((max_iteration + 1, 18), np.float64) if want_trace else None
+    check(load().pedp_icp(ctx._h, source._h, target._h, C.byref(prm), _ptr(T0), _ptr(T), C.byref(fit),
+                          C.byref(rmse), C.byref(it), _ptr(corr), _ptr(trace)), "pedp_icp")
+    out = {"T": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iters": it.value}
+    if want_corr:
+        out["corr"] = corr
+    if want_trace:
+        out["trace"] = trace[: it.value + 1]
+    return out
+
+
+def icp_batched(ctx, source, target, max_correspondence_distance, inits, estimator=POINT_TO_PLANE, max_iteration=30):
+    prm = IcpParams()
+    prm.max_correspondence_distance = float(max_correspondence_distance)
+    prm.estimator = int(estimator)
+    prm.max_iteration = int(max_iteration)
+    prm.relative_fitness = -1.0
+    prm.relative_rmse = -1.0
+    prm.allreduce = C.cast(None, ALLREDUCE_FN)
+    prm.allreduce_user = None
+    prm.n_source_global = 0
+    I = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 16)
+    B = len(I)
+    T = np.empty((B, 4, 4), np.float64)
+    fit = np.empty(B, np.float64)
+    rmse = np.empty(B, np.float64)
+    check(load().pedp_icp_batched(ctx._h, source._h, target._h, C.byref(prm), _ptr(I), B, _ptr(T), _ptr(fit),
+                                  _ptr(rmse)), "pedp_icp_batched")
+    return T, fit, rmse
+
+
+def nn(ctx, source, target, T=None):
+    """Exact nearest neighbour of every (transformed) source point: (idx int32, d2 float64)."""
+    M = np.ascontiguousarray(np.eye(4) if T is None else T, dtype=np.float64)
+    idx = np.empty(source.N, np.int32)
+    d2 = np.empty(source.N, np.float64)
+    check(load().pedp_nn(ctx._h, source._h, target._h, _ptr(M), _ptr(idx), _ptr(d2)), "pedp_nn")
+    return idx, d2
+
+
+def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
+    """mycpp.cluster_poses stand-in (estimater.py:118): returns the kept 4x4 float32 poses."""
+    p = np.ascontiguousarray(poses_in, dtype=np.float32).reshape(-1, 16)
+    s = np.ascontiguousarray(symmetry_tfs, dtype=np.float32).reshape(-1, 16)
+    keep = np.empty(max(len(p), 1), np.int32)
+    nk = C.c_int(0)
+    check(load().pedp_cluster_poses(float(angle_diff), float(dist_diff), _ptr(p), len(p), _ptr(s), len(s),
+                                    _ptr(keep), C.byref(nk)), "pedp_cluster_poses")
+    return keep[: nk.value].copy()

@@ -1,0 +1,164 @@
+// Context, error reporting and resource handles of libpedp_hip.so.
+#include "pedp_internal.h"
+#include <cmath>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void pedp_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int pedp_scratch::reserve(size_t bytes) {
+    if (bytes <= cap) return PEDP_OK;
+    release();
+    size_t want = bytes + bytes / 4 + 256;
+    PEDP_HIP_CHECK(hipMalloc(&ptr, want));
+    cap = want;
+    return PEDP_OK;
+}
+
+void pedp_scratch::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+extern "C" {
+
+int pedp_version(void) { return 100; }
+
+const char *pedp_last_error(void) { return g_err; }
+
+int pedp_device_count(int *count) {
+    PEDP_REQUIRE(count, "pedp_device_count: null output");
+    PEDP_HIP_CHECK(hipGetDeviceCount(count));
+    return PEDP_OK;
+}
+
+int pedp_ctx_create(int device, void *stream, pedp_ctx_t *out) {
+    PEDP_REQUIRE(out, "pedp_ctx_create: null output");
+    *out = nullptr;
+    int n = 0;
+    PEDP_HIP_CHECK(hipGetDeviceCount(&n));
+    PEDP_REQUIRE(device >= 0 && device < n, "pedp_ctx_create: device %d out of range (%d visible)", device, n);
+    PEDP_HIP_CHECK(hipSetDevice(device));
+    pedp_ctx_s *c = new (std::nothrow) pedp_ctx_s();
+    if (!c) { pedp_set_error("pedp_ctx_create: out of host memory"); return PEDP_ERR_ALLOC; }
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; pedp_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return PEDP_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->nn_ev0) != hipSuccess || hipEventCreate(&c->nn_ev1) != hipSuccess) {
+        pedp_set_error("pedp_ctx_create: hipEventCreate failed");
+        pedp_ctx_destroy(c);
+        return PEDP_ERR_HIP;
+    }
+    c->pinned_cap = 1 << 16;
+    if (hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault) != hipSuccess) {
+        pedp_set_error("pedp_ctx_create: hipHostMalloc failed");
+        pedp_ctx_destroy(c);
+        return PEDP_ERR_ALLOC;
+    }
+    *out = c;
+    return PEDP_OK;
+}
+
+void pedp_ctx_destroy(pedp_ctx_t c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->ray_keys.release();
+    c->ray_in.release();
+    c->ray_out.release();
+    c->icp_ws.release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
+    if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pedp_ctx_synchronize(pedp_ctx_t c) {
+    PEDP_REQUIRE(c, "pedp_ctx_synchronize: null context");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+// ---------------------------------------------------------------- clouds
+
+int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
+                      pedp_cloud_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_cloud_create: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE(N >= 0 && N < (int64_t)0x7FFFFFF0, "pedp_cloud_create: N=%lld out of range", (long long)N);
+    PEDP_REQUIRE(pts || N == 0, "pedp_cloud_create: null points");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
+    if (!cl) { pedp_set_error("pedp_cloud_create: out of host memory"); return PEDP_ERR_ALLOC; }
+    cl->ctx = c;
+    cl->N = N;
+    if (N > 0) {
+        double sum[3] = {0, 0, 0};
+        for (int64_t i = 0; i < N; ++i) { sum[0] += pts[3 * i]; sum[1] += pts[3 * i + 1]; sum[2] += pts[3 * i + 2]; }
+        for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
+        float Tn = 0.f, T2 = 0.f;
+        for (int64_t i = 0; i < N; ++i) {
+            float x = (float)(pts[3 * i] - cl->centroid[0]), y = (float)(pts[3 * i + 1] - cl->centroid[1]),
+                  z = (float)(pts[3 * i + 2] - cl->centroid[2]);
+            float n1 = fabsf(x) + fabsf(y) + fabsf(z), n2 = x * x + y * y + z * z;
+            if (n1 > Tn) Tn = n1;
+            if (n2 > T2) T2 = n2;
+        }
+        cl->Tn = Tn * 1.0001f;
+        cl->T2 = T2 * 1.0001f;
+    }
+    size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
+    hipError_t e = hipMalloc((void **)&cl->pts, bytes);
+    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && normals) {
+        cl->has_normals = true;
+        e = hipMalloc((void **)&cl->normals, bytes);
+        if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->normals, normals, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        pedp_set_error("pedp_cloud_create: %s", hipGetErrorString(e));
+        pedp_cloud_destroy(cl);
+        return PEDP_ERR_HIP;
+    }
+    *out = cl;
+    return PEDP_OK;
+}
+
+void pedp_cloud_destroy(pedp_cloud_t cl) {
+    if (!cl) return;
+    if (cl->ctx) (void)hipSetDevice(cl->ctx->device);
+    if (cl->pts) (void)hipFree(cl->pts);
+    if (cl->normals) (void)hipFree(cl->normals);
+    if (cl->tgt4) (void)hipFree(cl->tgt4);
+    delete cl;
+}
+
+int pedp_cloud_size(pedp_cloud_t cl, int64_t *N, int *has_normals) {
+    PEDP_REQUIRE(cl, "pedp_cloud_size: null cloud");
+    if (N) *N = cl->N;
+    if (has_normals) *has_normals = cl->has_normals ? 1 : 0;
+    return PEDP_OK;
+}
+
+}  // extern "C"

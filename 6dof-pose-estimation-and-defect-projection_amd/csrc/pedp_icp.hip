@@ -1,0 +1,751 @@
+// ICP (registration_icp) for gfx950 (MI355X).
+//
+// Replaces o3d.pipelines.registration.registration_icp as called by
+// src/pose_estimation.py:519-521 (refine_registration) and :654-660 (z search, one
+// iteration).  Semantics contract: oracle/icp.c (float64; exact nearest neighbour,
+// strict d^2 < r^2, point-to-plane 6x6 / point-to-point Umeyama update, Open3D's
+// convergence rule).
+//
+// Kernels per correspondence pass (all on the context's stream, no host round trip: a
+// device-side `done` flag turns the remaining passes into no-ops):
+//   icp_transform_pack   P <- U * P in float64 (the oracle's operation order), plus the
+//                        float32 MFMA operand of every scene point, (-2x', -2y', -2z', 1)
+//                        in coordinates centred on the target centroid.
+//   nn_sweep             the one dense contraction.  v_mfma_f32_16x16x4_f32 evaluates
+//                        g(i,j) = |t'_j|^2 - 2 s'_i . t'_j for 16 target x 16 scene
+//                        points per instruction (A = target tile (x,y,z,|t|^2), B = scene
+//                        block); a wave keeps 8 scene blocks (128 points) as B operands in
+//                        registers for the whole sweep and streams target tiles as
+//                        coalesced 256-B fragments.  Epilogue per MFMA: 6 VALU ops keeping
+//                        (best tile value, its tile, second-best tile value) per lane.
+//                        fp32 g is only a FILTER: with a proven error bound eps_i the true
+//                        nearest neighbour lies in the tiles whose value is within
+//                        2 eps_i of the minimum; those <= 16 points are re-scored in
+//                        float64 in the oracle's exact formula; if a second tile of one
+//                        lane group is inside the window the point goes to nn_fallback.
+//   nn_fallback          exact float64 brute force for the (rare) ambiguous points.
+//   icp_accumulate       float64 J^T J / J^T r (or Umeyama moments), fixed partition and
+//                        fixed reduction tree: run-to-run bit-stable.
+//   icp_reduce + icp_solve   29-double packet (optionally summed over ranks by the
+//                        caller's hook), pivoted LDLT 6x6 / Jacobi SVD 3x3, T <- U * T,
+//                        fitness / rmse / convergence.
+#include "pedp_internal.h"
+#include <cmath>
+#include <new>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PACKET = 29;  // doubles per partial-sum packet
+constexpr int NN_SB = 8;    // scene blocks of 16 points per wave
+constexpr int NN_WAVES = 4;
+constexpr int NN_PTS_PER_WG = NN_SB * 16 * NN_WAVES;  // 512
+constexpr int NN_TU = 4;    // target tiles in flight
+constexpr int ACC_BLOCKS = 256;
+constexpr int ACC_THREADS = 256;
+
+struct IcpState {
+    double T[16];
+    double upd[16];
+    double fitness, rmse, prev_fitness, prev_rmse;
+    double centroid[3];
+    int done;
+    int iters;
+    int fb_count;
+    int pad;
+};
+
+__device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double dsub(double a, double b) { return __dsub_rn(a, b); }
+
+// the oracle's dist2(): (dx*dx + dy*dy) + dz*dz, no FMA
+__device__ __forceinline__ double dist2(double ax, double ay, double az, double bx, double by, double bz) {
+    double dx = dsub(ax, bx), dy = dsub(ay, by), dz = dsub(az, bz);
+    return dadd(dadd(dmul(dx, dx), dmul(dy, dy)), dmul(dz, dz));
+}
+
+// ------------------------------------------------------------------ target preparation
+// float4 (x', y', z', |t'|^2) per target point, centred on c; pad rows can never win.
+__global__ void pack_target_kernel(const double *__restrict__ pts, int64_t N, int64_t N_pad, double cx,
+                                   double cy, double cz, float4 *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_pad) return;
+    if (i >= N) { out[i] = make_float4(0.f, 0.f, 0.f, 1e30f); return; }
+    float x = (float)(pts[3 * i] - cx), y = (float)(pts[3 * i + 1] - cy), z = (float)(pts[3 * i + 2] - cz);
+    double w = (double)x * x + (double)y * y + (double)z * z;
+    out[i] = make_float4(x, y, z, (float)w);
+}
+
+// ------------------------------------------------------------------ transform + pack
+// mode 0: P <- T * src (first pass; T = init), mode 1: P <- upd * P.
+__global__ void icp_transform_pack_kernel(const IcpState *__restrict__ st, int mode,
+                                          const double *__restrict__ src, double *__restrict__ P, int64_t N,
+                                          int64_t N_pad, float4 *__restrict__ B, float *__restrict__ eps,
+                                          float *__restrict__ S, float Tn, float T2, float r1) {
+    if (st->done) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_pad) return;
+    if (i >= N) {
+        B[i] = make_float4(0.f, 0.f, 0.f, 1.f);
+        eps[i] = 0.f;
+        S[i] = 3e38f;  // never an inlier candidate
+        return;
+    }
+    const double *M = mode == 0 ? st->T : st->upd;
+    const double *in = mode == 0 ? src : P;
+    double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+    double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+    double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+    P[3 * i] = nx; P[3 * i + 1] = ny; P[3 * i + 2] = nz;
+    float sx = (float)(nx - st->centroid[0]), sy = (float)(ny - st->centroid[1]), sz = (float)(nz - st->centroid[2]);
+    B[i] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
+    // Error bound of the fp32 surrogate relative to the float64 distance, for points whose
+    // nearest neighbour is closer than r1 (see DESIGN.md "NN filter bound"):
+    //   eps = 2^-23 * (5 * (2*|s'|_1*Tn + T2) + 2*min(r1, |s'|_1 + Tn)*(Tn + |s'|_1))
+    float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
+    float Mi = 2.0f * s1 * Tn + T2;
+    eps[i] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
+    S[i] = sx * sx + sy * sy + sz * sz;
+}
+
+// ------------------------------------------------------------------ NN sweep (MFMA)
+__device__ __forceinline__ void lexmin(double &d, int &j, double od, int oj) {
+    if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+}
+
+__global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
+    IcpState *__restrict__ st, const float *__restrict__ tgtf /* N_t_pad x 4 */, int n_tiles,
+    const double *__restrict__ tgt, int64_t Nt, const float *__restrict__ srcf /* N_s_pad x 4 */,
+    const double *__restrict__ P, int64_t Ns, const float *__restrict__ eps, const float *__restrict__ S,
+    float r2f, int32_t *__restrict__ idx_out, double *__restrict__ d2_out, int32_t *__restrict__ fb_list) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = ((int64_t)blockIdx.x * NN_WAVES + wave) * (NN_SB * 16);
+    const int frag = (lane & 15) * 4 + (lane >> 4);  // float offset inside a 16-point tile
+
+    float b[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) b[sb] = srcf[(base + sb * 16) * 4 + frag];
+
+    float b1[NN_SB], b2[NN_SB];
+    int t1[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = 0; }
+
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = 0; tile < n_tiles; tile += NN_TU) {  // n_tiles is a multiple of NN_TU
+        float a[NN_TU];
+#pragma unroll
+        for (int u = 0; u < NN_TU; ++u) a[u] = tgtf[(size_t)(tile + u) * 64 + frag];
+#pragma unroll
+        for (int u = 0; u < NN_TU; ++u) {
+#pragma unroll
+            for (int sb = 0; sb < NN_SB; ++sb) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[sb], zero, 0, 0, 0);
+                float v = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                t1[sb] = v < b1[sb] ? tile + u : t1[sb];
+                b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
+                b1[sb] = fminf(b1[sb], v);
+            }
+        }
+    }
+
+    // ---- exact selection.  Lane (q = lane >> 4, j = lane & 15) owns rows 4q..4q+3 of
+    // every tile for scene point j of each block.
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) {
+        const int64_t i = base + sb * 16 + j;
+        float m = b1[sb], m2 = b2[sb];
+        m = fminf(m, __shfl_xor(m, 16, 64));
+        m = fminf(m, __shfl_xor(m, 32, 64));
+        m2 = fminf(m2, __shfl_xor(m2, 16, 64));
+        m2 = fminf(m2, __shfl_xor(m2, 32, 64));
+        const float e = eps[i];
+        const float Si = S[i];
+        const bool maybe_inlier = (i < Ns) && (m + Si <= r2f + 4.0f * e + 4.8e-7f * Si);
+        const float win = m + 2.0f * e;
+        double bd = __longlong_as_double(0x7FF0000000000000ll);
+        int bj = 0x7FFFFFFF;
+        if (maybe_inlier && b1[sb] <= win) {
+            const double px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+            const int64_t row0 = (int64_t)t1[sb] * 16 + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t row = row0 + r;
+                if (row < Nt) {
+                    double d = dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]);
+                    lexmin(bd, bj, d, (int)row);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            double od = __shfl_xor(bd, off, 64);
+            int oj = __shfl_xor(bj, off, 64);
+            lexmin(bd, bj, od, oj);
+        }
+        if (q == 0 && i < Ns) {
+            if (!maybe_inlier) {
+                idx_out[i] = -1;
+                d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
+            } else {
+                idx_out[i] = bj;
+                d2_out[i] = bd;
+                if (m2 <= win) {  // a second tile of some lane group is inside the window
+                    int slot = atomicAdd(&st->fb_count, 1);
+                    fb_list[slot] = (int)i;
+                }
+            }
+        }
+    }
+}
+
+// One wave per ambiguous point: exact brute force in float64.
+__global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__restrict__ st,
+                                                          const int32_t *__restrict__ fb_list,
+                                                          const double *__restrict__ tgt, int64_t Nt,
+                                                          const double *__restrict__ P,
+                                                          int32_t *__restrict__ idx_out,
+                                                          double *__restrict__ d2_out) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int n = st->fb_count;
+    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+        const int i = fb_list[w];
+        const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
+        double bd = __longlong_as_double(0x7FF0000000000000ll);
+        int bj = 0x7FFFFFFF;
+        for (int64_t row = lane; row < Nt; row += 64) {
+            double d = dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]);
+            if (d < bd) { bd = d; bj = (int)row; }  // rows ascend per lane: ties keep the lower
+        }
+#pragma unroll
+        for (int off = 1; off <= 32; off <<= 1) {
+            double od = __shfl_xor(bd, off, 64);
+            int oj = __shfl_xor(bj, off, 64);
+            lexmin(bd, bj, od, oj);
+        }
+        if (lane == 0) { idx_out[i] = bj; d2_out[i] = bd; }
+    }
+}
+
+// ------------------------------------------------------------------ accumulate
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Packet layout.  point-to-plane: [0..20] upper triangle of J J^T (row-major), [21..26] J r,
+// [27] sum d^2, [28] count.  point-to-point: [0..2] sum (s-c), [3..5] sum (t-c),
+// [6..14] sum (t-c)(s-c)^T, [27], [28] as above.
+__global__ __launch_bounds__(ACC_THREADS) void icp_accumulate_kernel(
+    const IcpState *__restrict__ st, int estimator, const double *__restrict__ P, int64_t Ns,
+    const double *__restrict__ tgt, const double *__restrict__ nrm, int32_t *__restrict__ idx,
+    const double *__restrict__ d2, double r2, double *__restrict__ partials /* ACC_BLOCKS x PACKET */) {
+    if (st->done) return;
+    double acc[PACKET];
+#pragma unroll
+    for (int k = 0; k < PACKET; ++k) acc[k] = 0.0;
+    const double cx = st->centroid[0], cy = st->centroid[1], cz = st->centroid[2];
+    for (int64_t i = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x; i < Ns; i += (int64_t)ACC_BLOCKS * ACC_THREADS) {
+        int j = idx[i];
+        if (j < 0) continue;
+        double dd = d2[i];
+        if (!(dd < r2)) { idx[i] = -1; continue; }  // strict, as SearchHybrid's lower_bound
+        double sx = P[3 * i], sy = P[3 * i + 1], sz = P[3 * i + 2];
+        double tx = tgt[3 * (int64_t)j], ty = tgt[3 * (int64_t)j + 1], tz = tgt[3 * (int64_t)j + 2];
+        if (estimator == PEDP_POINT_TO_PLANE) {
+            double nx = nrm[3 * (int64_t)j], ny = nrm[3 * (int64_t)j + 1], nz = nrm[3 * (int64_t)j + 2];
+            double r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+            double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = a; c < 6; ++c) acc[k++] += J[a] * J[c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+        } else {
+            double s[3] = {sx - cx, sy - cy, sz - cz}, t[3] = {tx - cx, ty - cy, tz - cz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { acc[a] += s[a]; acc[3 + a] += t[a]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[6 + 3 * a + c] += t[a] * s[c];
+        }
+        acc[27] += dd;
+        acc[28] += 1.0;
+    }
+    __shared__ double sh[ACC_THREADS / 64][PACKET];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < PACKET; ++k) {
+        double v = wave_sum(acc[k]);
+        if (lane == 0) sh[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PACKET) {
+        double v = 0.0;
+        for (int w = 0; w < ACC_THREADS / 64; ++w) v += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * PACKET + threadIdx.x] = v;
+    }
+}
+
+__global__ void icp_reduce_kernel(const IcpState *__restrict__ st, const double *__restrict__ partials,
+                                  double *__restrict__ packet) {
+    if (st->done) return;
+    if (threadIdx.x < PACKET) {
+        double v = 0.0;
+        for (int b = 0; b < ACC_BLOCKS; ++b) v += partials[(size_t)b * PACKET + threadIdx.x];
+        packet[threadIdx.x] = v;
+    }
+}
+
+// ------------------------------------------------------------------ solve (one thread)
+__device__ void mat4_mul_dev(const double *A, const double *B, double *C) {
+    double R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
+            R[4 * i + j] = s;
+        }
+    for (int k = 0; k < 16; ++k) C[k] = R[k];
+}
+
+__device__ void ident4(double *T) {
+    for (int k = 0; k < 16; ++k) T[k] = 0.0;
+    T[0] = T[5] = T[10] = T[15] = 1.0;
+}
+
+// Eigen-style LDLT (left-looking; pivot = largest remaining original diagonal entry), as
+// in oracle/icp.c pedp_oracle_solve6_ldlt.
+__device__ bool solve6_ldlt(const double *Ain, const double *b, double *x) {
+    const int n = 6;
+    double A[6][6], tmp[6], y[6];
+    int tr[6];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) A[i][j] = Ain[n * i + j];
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double big = fabs(A[k][k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
+        tr[k] = p;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+            for (int i = 0; i < n; ++i) { double t = A[i][k]; A[i][k] = A[i][p]; A[i][p] = t; }
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) tmp[j] = A[j][j] * A[k][j];
+            double s = 0.0;
+            for (int j = 0; j < k; ++j) s += A[k][j] * tmp[j];
+            A[k][k] -= s;
+            for (int i = k + 1; i < n; ++i) {
+                double u = 0.0;
+                for (int j = 0; j < k; ++j) u += A[i][j] * tmp[j];
+                A[i][k] -= u;
+            }
+        }
+        double akk = A[k][k];
+        if (fabs(akk) > 0.0)
+            for (int i = k + 1; i < n; ++i) A[i][k] /= akk;
+    }
+    for (int i = 0; i < n; ++i) y[i] = b[i];
+    for (int k = 0; k < n; ++k)
+        if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+    for (int i = 0; i < n; ++i) {
+        if (fabs(A[i][i]) > 2.2250738585072014e-308) y[i] /= A[i][i];
+        else y[i] = 0.0;
+    }
+    for (int i = n - 1; i >= 0; --i)
+        for (int j = i + 1; j < n; ++j) y[i] -= A[j][i] * y[j];
+    for (int k = n - 1; k >= 0; --k)
+        if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+        x[i] = y[i];
+        if (!(y[i] == y[i]) || isinf(y[i])) ok = false;
+    }
+    return ok;
+}
+
+__device__ void vec6_to_T(const double *x, double *T) {
+    double ca = cos(x[0]), sa = sin(x[0]);
+    double cb = cos(x[1]), sb = sin(x[1]);
+    double cc = cos(x[2]), sc = sin(x[2]);
+    ident4(T);
+    T[0] = cc * cb;  T[1] = cc * sb * sa - sc * ca;  T[2] = cc * sb * ca + sc * sa;
+    T[4] = sc * cb;  T[5] = sc * sb * sa + cc * ca;  T[6] = sc * sb * ca - cc * sa;
+    T[8] = -sb;      T[9] = cb * sa;                 T[10] = cb * ca;
+    T[3] = x[3]; T[7] = x[4]; T[11] = x[5];
+}
+
+__device__ double det3_dev(const double *M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// 3x3 SVD by one-sided Jacobi (same routine as oracle/icp.c svd3)
+__device__ void svd3_dev(const double *Ain, double *U, double *w, double *V) {
+    double A[3][3], Vv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = Ain[3 * i + j];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha += A[i][p] * A[i][p];
+                    beta += A[i][q] * A[i][q];
+                    gamma += A[i][p] * A[i][q];
+                }
+                if (gamma == 0.0) continue;
+                off = fmax(off, fabs(gamma) / sqrt(fmax(alpha * beta, 2.2250738585072014e-308)));
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    double ap = A[i][p], aq = A[i][q];
+                    A[i][p] = c * ap - s * aq;
+                    A[i][q] = s * ap + c * aq;
+                    double vp = Vv[i][p], vq = Vv[i][q];
+                    Vv[i][p] = c * vp - s * vq;
+                    Vv[i][q] = s * vp + c * vq;
+                }
+            }
+        if (off < 1e-16) break;
+    }
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    for (int a = 0; a < 2; ++a)
+        for (int b2 = a + 1; b2 < 3; ++b2)
+            if (nrm[ord[b2]] > nrm[ord[a]]) { int t = ord[a]; ord[a] = ord[b2]; ord[b2] = t; }
+    double Um[3][3];
+    double tiny = nrm[ord[0]] * 1e-300 + 2.2250738585072014e-308;
+    for (int k = 0; k < 3; ++k) {
+        int j = ord[k];
+        w[k] = nrm[j];
+        for (int i = 0; i < 3; ++i) {
+            V[3 * i + k] = Vv[i][j];
+            Um[i][k] = (nrm[j] > tiny) ? A[i][j] / nrm[j] : 0.0;
+        }
+    }
+    double rel = 1e-13 * w[0];
+    if (w[0] <= tiny) {
+        for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) Um[i][k] = (i == k);
+    } else {
+        if (w[1] <= rel) {
+            double a[3] = {Um[0][0], Um[1][0], Um[2][0]};
+            int m = (fabs(a[0]) <= fabs(a[1]) && fabs(a[0]) <= fabs(a[2])) ? 0 : (fabs(a[1]) <= fabs(a[2]) ? 1 : 2);
+            double e[3] = {0, 0, 0};
+            e[m] = 1.0;
+            double dt = a[m];
+            double b2[3] = {e[0] - dt * a[0], e[1] - dt * a[1], e[2] - dt * a[2]};
+            double nb = sqrt(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+            for (int i = 0; i < 3; ++i) Um[i][1] = b2[i] / nb;
+        }
+        if (w[2] <= rel) {
+            Um[0][2] = Um[1][0] * Um[2][1] - Um[2][0] * Um[1][1];
+            Um[1][2] = Um[2][0] * Um[0][1] - Um[0][0] * Um[2][1];
+            Um[2][2] = Um[0][0] * Um[1][1] - Um[1][0] * Um[0][1];
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) U[3 * i + k] = Um[i][k];
+}
+
+// pass p (0 = initial correspondence pass).  Records fitness/rmse of the pass, decides
+// whether the loop ends, otherwise derives the next update from the packet.
+__global__ void icp_solve_kernel(IcpState *__restrict__ st, const double *__restrict__ packet, int pass,
+                                 int max_iter, int estimator, double n_source, double rel_fitness,
+                                 double rel_rmse, double *__restrict__ trace) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->done) return;
+    st->fb_count = 0;
+    const double K = packet[28];
+    double fit = 0.0, rmse = 0.0;
+    if (K > 0.0) { fit = K / n_source; rmse = sqrt(packet[27] / K); }
+    st->prev_fitness = st->fitness;
+    st->prev_rmse = st->rmse;
+    st->fitness = fit;
+    st->rmse = rmse;
+    if (trace) {
+        double *tr = trace + 18 * pass;
+        tr[0] = fit; tr[1] = rmse;
+        for (int k = 0; k < 16; ++k) tr[2 + k] = st->T[k];
+    }
+    st->iters = pass;
+    if (pass >= max_iter) { st->done = 1; return; }
+    if (pass > 0 && fabs(st->prev_fitness - fit) < rel_fitness && fabs(st->prev_rmse - rmse) < rel_rmse) {
+        st->done = 1;
+        return;
+    }
+    double upd[16];
+    ident4(upd);
+    if (K > 0.0) {
+        if (estimator == PEDP_POINT_TO_PLANE) {
+            double A[36], nb[6], x[6];
+            int k = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c = a; c < 6; ++c) { A[6 * a + c] = packet[k]; A[6 * c + a] = packet[k]; ++k; }
+            for (int a = 0; a < 6; ++a) nb[a] = -packet[21 + a];
+            if (solve6_ldlt(A, nb, x)) vec6_to_T(x, upd);
+        } else {
+            const double *c = st->centroid;
+            double ms[3], mt[3], sig[9];
+            for (int a = 0; a < 3; ++a) { ms[a] = packet[a] / K; mt[a] = packet[3 + a] / K; }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) sig[3 * a + b] = packet[6 + 3 * a + b] / K - mt[a] * ms[b];
+            double U[9], w[3], V[9];
+            svd3_dev(sig, U, w, V);
+            double sgn = (det3_dev(U) * det3_dev(V) < 0.0) ? -1.0 : 1.0;
+            double R[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    R[3 * a + b] = U[3 * a] * V[3 * b] + U[3 * a + 1] * V[3 * b + 1] + sgn * U[3 * a + 2] * V[3 * b + 2];
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) upd[4 * a + b] = R[3 * a + b];
+                double msa[3] = {ms[0] + c[0], ms[1] + c[1], ms[2] + c[2]};
+                upd[4 * a + 3] = (mt[a] + c[a]) - (R[3 * a] * msa[0] + R[3 * a + 1] * msa[1] + R[3 * a + 2] * msa[2]);
+            }
+        }
+    }
+    for (int k = 0; k < 16; ++k) st->upd[k] = upd[k];
+    mat4_mul_dev(upd, st->T, st->T);
+}
+
+// ------------------------------------------------------------------ host side
+
+struct TargetPrep {
+    double c[3];
+    float Tn, T2;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct IcpWorkspace {
+    IcpState *st;
+    double *P, *d2, *partials, *packet, *trace;
+    float4 *B;
+    const float4 *tgt4;
+    float *eps, *S;
+    int32_t *idx, *fb;
+    int64_t Ns_pad, Nt_pad;
+};
+
+int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorkspace &w) {
+    w.Ns_pad = (int64_t)align_up((size_t)(Ns > 0 ? Ns : 1), NN_PTS_PER_WG);
+    w.Nt_pad = (int64_t)align_up((size_t)(Nt > 0 ? Nt : 1), 16 * NN_TU);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_st = take(sizeof(IcpState));
+    size_t o_P = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
+    size_t o_d2 = take(sizeof(double) * (size_t)w.Ns_pad);
+    size_t o_part = take(sizeof(double) * ACC_BLOCKS * PACKET);
+    size_t o_pack = take(sizeof(double) * 32);
+    size_t o_trace = take(sizeof(double) * 18 * (size_t)(max_iter + 1));
+    size_t o_B = take(sizeof(float4) * (size_t)w.Ns_pad);
+    size_t o_eps = take(sizeof(float) * (size_t)w.Ns_pad);
+    size_t o_S = take(sizeof(float) * (size_t)w.Ns_pad);
+    size_t o_idx = take(sizeof(int32_t) * (size_t)w.Ns_pad);
+    size_t o_fb = take(sizeof(int32_t) * (size_t)w.Ns_pad);
+    int st = c->icp_ws.reserve(off);
+    if (st) return st;
+    char *b = (char *)c->icp_ws.ptr;
+    w.st = (IcpState *)(b + o_st);
+    w.P = (double *)(b + o_P);
+    w.d2 = (double *)(b + o_d2);
+    w.partials = (double *)(b + o_part);
+    w.packet = (double *)(b + o_pack);
+    w.trace = (double *)(b + o_trace);
+    w.B = (float4 *)(b + o_B);
+    w.eps = (float *)(b + o_eps);
+    w.S = (float *)(b + o_S);
+    w.idx = (int32_t *)(b + o_idx);
+    w.fb = (int32_t *)(b + o_fb);
+    return PEDP_OK;
+}
+
+// Enqueue one correspondence pass (transform, sweep, fallback).  mode as in
+// icp_transform_pack_kernel.
+int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int mode,
+                    const TargetPrep &tp, double r, bool timed) {
+    const int64_t Ns = src->N, Nt = tgt->N;
+    // r1: distance scale of the candidates the bound must hold for (anything farther is
+    // not an inlier anyway); huge radii fall back to the cloud scale.
+    float r1 = (float)(r * 1.01);
+    {
+        int64_t grid = (w.Ns_pad + 255) / 256;
+        hipLaunchKernelGGL(icp_transform_pack_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, mode,
+                           src->pts, w.P, Ns, w.Ns_pad, w.B, w.eps, w.S, tp.Tn, tp.T2, r1);
+    }
+    if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
+    {
+        int64_t grid = w.Ns_pad / NN_PTS_PER_WG;
+        float r2f = (float)(r * r) * 1.00001f;
+        hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,
+                           (const float *)w.tgt4, (int)(w.Nt_pad / 16), tgt->pts, Nt, (const float *)w.B, w.P, Ns,
+                           w.eps, w.S, r2f, w.idx, w.d2, w.fb);
+    }
+    if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
+    hipLaunchKernelGGL(nn_fallback_kernel, dim3(4 * c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, tgt->pts, Nt,
+                       w.P, w.idx, w.d2);
+    PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
+// Target-side operand of the sweep, built once per cloud and kept in the handle (the
+// reference re-runs ICP ~50x per frame against the same model, pose_estimation.py:577-613).
+int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
+    for (int k = 0; k < 3; ++k) tp.c[k] = tgt->centroid[k];
+    tp.Tn = tgt->Tn;
+    tp.T2 = tgt->T2;
+    if (tgt->tgt4) return PEDP_OK;
+    int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU);
+    PEDP_HIP_CHECK(hipMalloc(&tgt->tgt4, sizeof(float4) * (size_t)pad));
+    tgt->tgt4_pad = pad;
+    int64_t grid = (pad + 255) / 256;
+    hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts, tgt->N, pad,
+                       tp.c[0], tp.c[1], tp.c[2], (float4 *)tgt->tgt4);
+    PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
+             const double init[16], double T_out[16], double *fitness, double *inlier_rmse,
+             int32_t *n_iter_done, int32_t *corr, double *trace) {
+    PEDP_REQUIRE(c && source && target && prm && init && T_out, "pedp_icp: null argument");
+    PEDP_REQUIRE(source->ctx == c && target->ctx == c, "pedp_icp: cloud belongs to another context");
+    PEDP_REQUIRE(prm->estimator == PEDP_POINT_TO_PLANE || prm->estimator == PEDP_POINT_TO_POINT,
+                 "pedp_icp: unknown estimator %d", prm->estimator);
+    PEDP_REQUIRE(prm->max_iteration >= 0 && prm->max_iteration <= 100000, "pedp_icp: max_iteration out of range");
+    if (prm->estimator == PEDP_POINT_TO_PLANE && !target->has_normals) {
+        pedp_set_error("pedp_icp: TransformationEstimationPointToPlane requires target normals");
+        return PEDP_ERR_NO_NORMALS;
+    }
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t Ns = source->N, Nt = target->N;
+    const int max_iter = prm->max_iteration;
+    const double r = prm->max_correspondence_distance;
+    const double n_global = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
+
+    IcpWorkspace w;
+    int rc = carve_workspace(c, Ns, Nt, max_iter, w);
+    if (rc) return rc;
+
+    TargetPrep tp;
+    rc = ensure_target_pack(c, target, tp);
+    if (rc) return rc;
+    w.tgt4 = (const float4 *)target->tgt4;
+
+    IcpState h{};
+    for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
+    for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
+    // Open3D: max_correspondence_distance <= 0 or an empty cloud gives an empty result
+    const bool degenerate = (r <= 0.0 || Ns == 0 || Nt == 0);
+    IcpState *hp = (IcpState *)c->pinned;
+    *hp = h;
+    PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    const double r2 = r * r;
+    for (int pass = 0; pass <= max_iter; ++pass) {
+        if (!degenerate) {
+            rc = enqueue_nn_pass(c, w, source, target, pass == 0 ? 0 : 1, tp, r, false);
+            if (rc) return rc;
+            hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, c->stream, w.st,
+                               prm->estimator, w.P, Ns, target->pts, target->normals, w.idx, w.d2, r2, w.partials);
+            hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.partials, w.packet);
+        } else {
+            PEDP_HIP_CHECK(hipMemsetAsync(w.packet, 0, sizeof(double) * 32, c->stream));
+            if (pass == 0 && Ns > 0) PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, c->stream));
+        }
+        if (prm->allreduce) {
+            if (prm->allreduce(prm->allreduce_user, w.packet, PACKET, (void *)c->stream) != 0) {
+                pedp_set_error("pedp_icp: all-reduce hook failed in pass %d", pass);
+                (void)hipStreamSynchronize(c->stream);
+                return PEDP_ERR_COLLECTIVE;
+            }
+        }
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.packet, pass, max_iter,
+                           prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
+                           prm->relative_rmse, trace ? w.trace : nullptr);
+        PEDP_HIP_CHECK(hipGetLastError());
+    }
+    PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    if (corr && Ns > 0) PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)Ns, hipMemcpyDeviceToHost, c->stream));
+    if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
+    if (fitness) *fitness = hp->fitness;
+    if (inlier_rmse) *inlier_rmse = hp->rmse;
+    if (n_iter_done) *n_iter_done = hp->iters;
+    return PEDP_OK;
+}
+
+int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
+                     const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse) {
+    PEDP_REQUIRE(c && source && target && prm && inits && T_out, "pedp_icp_batched: null argument");
+    PEDP_REQUIRE(B >= 0, "pedp_icp_batched: negative batch");
+    pedp_icp_params p = *prm;
+    p.relative_fitness = -1.0;  // no early exit across the batch
+    p.relative_rmse = -1.0;
+    for (int b = 0; b < B; ++b) {
+        int rc = pedp_icp(c, source, target, &p, inits + 16 * b, T_out + 16 * b, fitness ? fitness + b : nullptr,
+                          inlier_rmse ? inlier_rmse + b : nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return PEDP_OK;
+}
+
+int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double T[16], int32_t *idx, double *d2) {
+    PEDP_REQUIRE(c && source && target && T && idx && d2, "pedp_nn: null argument");
+    PEDP_REQUIRE(source->ctx == c && target->ctx == c, "pedp_nn: cloud belongs to another context");
+    PEDP_REQUIRE(target->N > 0, "pedp_nn: empty target");
+    if (source->N == 0) return PEDP_OK;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    IcpWorkspace w;
+    int rc = carve_workspace(c, source->N, target->N, 0, w);
+    if (rc) return rc;
+    TargetPrep tp;
+    rc = ensure_target_pack(c, target, tp);
+    if (rc) return rc;
+    w.tgt4 = (const float4 *)target->tgt4;
+    IcpState *hp = (IcpState *)c->pinned;
+    IcpState h{};
+    for (int k = 0; k < 16; ++k) { h.T[k] = T[k]; h.upd[k] = T[k]; }
+    for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
+    *hp = h;
+    PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    // every point is a candidate: radius = "infinite" (cloud scale bound)
+    rc = enqueue_nn_pass(c, w, source, target, 0, tp, 1e18, true);
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipMemcpyAsync(idx, w.idx, sizeof(int32_t) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipMemcpyAsync(d2, w.d2, sizeof(double) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_nn_last_sweep_ms(pedp_ctx_t c, float *ms) {
+    PEDP_REQUIRE(c && ms, "pedp_nn_last_sweep_ms: null argument");
+    PEDP_REQUIRE(c->nn_timed, "pedp_nn_last_sweep_ms: no timed sweep has run on this context");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    PEDP_HIP_CHECK(hipEventSynchronize(c->nn_ev1));
+    PEDP_HIP_CHECK(hipEventElapsedTime(ms, c->nn_ev0, c->nn_ev1));
+    return PEDP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Internal declarations shared by the translation units of libpedp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/pedp.h"
+
+void pedp_set_error(const char *fmt, ...);
+
+#define PEDP_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            pedp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return PEDP_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define PEDP_REQUIRE(cond, ...)             \
+    do {                                    \
+        if (!(cond)) {                      \
+            pedp_set_error(__VA_ARGS__);    \
+            return PEDP_ERR_BAD_ARG;        \
+        }                                   \
+    } while (0)
+
+// A growable device scratch buffer owned by the context (no hipMalloc on the hot path
+// once sizes have settled).
+struct pedp_scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+struct pedp_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    // ray casting
+    pedp_scratch ray_keys;   // N x u64 packed (t_bits << 32 | prim_id)
+    pedp_scratch ray_in;     // staging for host-memory calls
+    pedp_scratch ray_out;
+    int ray_tri_chunks = 0;  // 0 = auto
+    int ray_variant = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // sweep timing
+    bool ray_timed = false;
+    bool nn_timed = false;
+    hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;
+    // ICP
+    pedp_scratch icp_ws;
+    void *pinned = nullptr;  // small pinned host block for result read-back
+    size_t pinned_cap = 0;
+};
+
+// Triangle record: 12 floats (48 B, 16-B aligned so a wave fetches it with scalar
+// dwordx4/x8 loads): v0.xyz, e1.xyz, e2.xyz, 3 pad.
+#define PEDP_TRI_STRIDE 12
+
+struct pedp_mesh_s {
+    pedp_ctx_t ctx = nullptr;
+    int64_t V = 0, F = 0;
+    float *tri = nullptr;  // F_padded x PEDP_TRI_STRIDE floats on the device
+    int64_t F_padded = 0;  // multiple of 8; pad records can never be hit (all zero => det == 0)
+};
+
+struct pedp_cloud_s {
+    pedp_ctx_t ctx = nullptr;
+    int64_t N = 0;
+    bool has_normals = false;
+    double *pts = nullptr;      // N x 3 f64 (device)
+    double *normals = nullptr;  // N x 3 f64 (device) or null
+    // Set at creation (host pass over the points): centroid and the two magnitudes of the
+    // centred cloud that the NN filter's error bound needs when this cloud is the target.
+    double centroid[3] = {0, 0, 0};
+    float Tn = 0.f;  // max |t'|_1
+    float T2 = 0.f;  // max |t'|_2^2
+    // Built on first use as an ICP target: float4 (x', y', z', |t'|^2), padded.
+    void *tgt4 = nullptr;
+    int64_t tgt4_pad = 0;
+};

@@ -1,0 +1,144 @@
+/*
+ * pedp.h -- C ABI of libpedp_hip.so: the MI355X (gfx950) implementation of the
+ * reference's geometric hot path, behind plain pointers and sizes.
+ *
+ * The reference binds no FFI on this path today: both stages are Python calls into
+ * the Open3D wheel.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repository); INTEGRATION.md shows the ctypes
+ * stub a maintainer adds on the reference side.  The library occupies the
+ * reference's native-extension slot (import-with-fallback convention of
+ * Utils.py:41-57, where mycpp and bundlesdf.mycuda are loaded) and additionally
+ * exports cluster_poses so estimater.py:118 keeps working without mycpp.
+ *
+ * Conventions
+ *   - every function returns PEDP_OK (0) or a negative pedp_status; the message of
+ *     the last failure on the calling thread is pedp_last_error().
+ *   - `mem` arguments: PEDP_HOST = the array pointers are host memory (the call
+ *     copies, runs, copies back and returns after completion); PEDP_DEVICE = they
+ *     are device memory on the context's GPU (the call only enqueues work on the
+ *     context's stream; use pedp_ctx_synchronize or the stream to wait).
+ *   - the callee never frees or retains caller arrays; handles own device copies.
+ *   - one context = one device + one HIP stream; a context is not thread-safe,
+ *     different contexts are independent.
+ */
+#ifndef PEDP_H
+#define PEDP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PEDP_OK = 0,
+    PEDP_ERR_BAD_ARG = -1,
+    PEDP_ERR_NO_NORMALS = -2, /* point-to-plane needs target normals (Open3D raises) */
+    PEDP_ERR_HIP = -3,
+    PEDP_ERR_ALLOC = -4,
+    PEDP_ERR_COLLECTIVE = -5 /* the caller's all-reduce hook failed */
+} pedp_status;
+
+enum { PEDP_HOST = 0, PEDP_DEVICE = 1 };
+enum { PEDP_POINT_TO_PLANE = 0, PEDP_POINT_TO_POINT = 1 };
+
+typedef struct pedp_ctx_s *pedp_ctx_t;
+typedef struct pedp_mesh_s *pedp_mesh_t;
+typedef struct pedp_cloud_s *pedp_cloud_t;
+
+int pedp_version(void);
+const char *pedp_last_error(void);
+int pedp_device_count(int *count);
+
+/* stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the context create its own. */
+int pedp_ctx_create(int device, void *stream, pedp_ctx_t *out);
+void pedp_ctx_destroy(pedp_ctx_t ctx);
+int pedp_ctx_synchronize(pedp_ctx_t ctx);
+
+/* ---------------------------------------------------------------- ray projection
+ * Replaces src/defect_projection.py:245-256:
+ *     t_mesh = o3d.t.geometry.TriangleMesh.from_legacy(mesh)        -> pedp_mesh_create
+ *     scene = o3d.t.geometry.RaycastingScene(); scene.add_triangles(t_mesh)
+ *     intersections = scene.cast_rays(o3d_rays)                     -> pedp_raycast
+ * verts: V x 3 float32 (from_legacy's cast), tris: F x 3 uint32, both host memory.
+ */
+int pedp_mesh_create(pedp_ctx_t ctx, const float *verts, int64_t V, const uint32_t *tris,
+                     int64_t F, pedp_mesh_t *out);
+void pedp_mesh_destroy(pedp_mesh_t mesh);
+int pedp_mesh_size(pedp_mesh_t mesh, int64_t *V, int64_t *F);
+
+/* cast_rays: rays6 = N x [ox oy oz dx dy dz] float32 (directions are used as given,
+ * not re-normalised; tnear = 0, tfar = +inf, no culling).  Outputs, all length N:
+ * t_hit (+inf on miss), prim_id (0xFFFFFFFF on miss), uv (N x 2, nullable; 0 on miss).
+ * Closest hit; ties: smaller t, then smaller triangle index. */
+int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N, int mem,
+                 float *t_hit, uint32_t *prim_id, float *uv);
+
+/* Tuning knobs of the sweep (0 = keep default): triangle chunks per ray block
+ * (multiple of 8: chunk c is served by XCD c % 8) and sweep variant
+ * (0 auto, 1 ray-per-lane, 2 triangle-per-lane with wave-wide min). */
+int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
+
+/* Milliseconds the last pedp_raycast spent in its sweep kernel (HIP events on the
+ * context's stream); synchronises the stream. */
+int pedp_raycast_last_sweep_ms(pedp_ctx_t ctx, float *ms);
+
+/* ---------------------------------------------------------------- ICP
+ * Replaces src/pose_estimation.py:519-521 and :654-660:
+ *     o3d.pipelines.registration.registration_icp(source, target, max_corr_dist, init,
+ *         TransformationEstimationPointToPlane()[, ICPConvergenceCriteria(max_iteration=1)])
+ * Clouds: N x 3 float64 host arrays (Open3D's Vector3dVector); normals nullable.
+ */
+int pedp_cloud_create(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N,
+                      pedp_cloud_t *out);
+void pedp_cloud_destroy(pedp_cloud_t cloud);
+int pedp_cloud_size(pedp_cloud_t cloud, int64_t *N, int *has_normals);
+
+/* Optional hook called once per correspondence pass with a DEVICE pointer to the
+ * n-double partial-sum packet of this rank; it must enqueue an in-place sum over all
+ * ranks on `stream` (RCCL all-reduce through torch.distributed) and return 0. */
+typedef int (*pedp_allreduce_fn)(void *user, double *dev_packet, int n, void *stream);
+
+typedef struct {
+    double max_correspondence_distance;
+    int estimator;           /* PEDP_POINT_TO_PLANE (reference default) / PEDP_POINT_TO_POINT */
+    int max_iteration;       /* Open3D default 30 */
+    double relative_fitness; /* Open3D default 1e-6; negative disables the early exit */
+    double relative_rmse;    /* Open3D default 1e-6 */
+    pedp_allreduce_fn allreduce; /* NULL on one GPU */
+    void *allreduce_user;
+    int64_t n_source_global; /* fitness denominator when the scene is sharded; 0 = local N */
+} pedp_icp_params;
+
+/* init / T_out: row-major 4x4 float64, source -> target (scene -> model), host memory.
+ * corr (nullable, host, N_source): target index per source point or -1.
+ * trace (nullable, host): (max_iteration + 1) x 18 doubles [fitness, rmse, T] per pass. */
+int pedp_icp(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
+             const pedp_icp_params *params, const double init[16], double T_out[16],
+             double *fitness, double *inlier_rmse, int32_t *n_iter_done, int32_t *corr,
+             double *trace);
+
+/* Batched refine (FoundationPose hypothesis sizing, estimater.py:104-122): B start
+ * poses share one source and one target; no early exit across the batch. */
+int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
+                     const pedp_icp_params *params, const double *inits /* B x 16 */, int B,
+                     double *T_out /* B x 16 */, double *fitness /* B */,
+                     double *inlier_rmse /* B */);
+
+/* One exact nearest-neighbour pass (the correspondence step alone): for every source
+ * point transformed by T, the index of the closest target point and the squared
+ * distance, float64-exact (ties: lowest index).  idx/d2: host arrays, length N. */
+int pedp_nn(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const double T[16],
+            int32_t *idx, double *d2);
+int pedp_nn_last_sweep_ms(pedp_ctx_t ctx, float *ms);
+
+/* ---------------------------------------------------------------- cluster_poses
+ * Replaces mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68; caller
+ * estimater.py:118).  Host only.  poses: n x 16 float32 row-major, syms: s x 16.
+ * keep_idx: caller array of n ints, receives the indices of the kept poses. */
+int pedp_cluster_poses(float angle_diff_deg, float dist_diff, const float *poses, int n,
+                       const float *syms, int s, int32_t *keep_idx, int *n_keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

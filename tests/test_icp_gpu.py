@@ -1,0 +1,158 @@
+"""GPU parity of the ICP path against the float64 oracle, through the C ABI
+(pedp_nn / pedp_icp).  Tolerance (BASELINE.md s6 / north_star): refined 4x4 pose within
+1e-5 abs; here the observed agreement is ~1e-10 and correspondence sets are identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5
+
+
+def _frame_scene(oracle, config):
+    from pedp_hip import synth
+
+    f = synth.Frame(config)
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    return f, f.scene(depth)
+
+
+@pytest.mark.parametrize("config", ["tiny", "parity"])
+def test_nn_exact(ctx, oracle, config):
+    from pedp_hip import _lib
+
+    f, scene = _frame_scene(oracle, config)
+    src = _lib.Cloud(ctx, scene)
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    T = f.icp_init()
+    idx, d2 = _lib.nn(ctx, src, tgt, T)
+    ridx, rd2 = oracle.nn(oracle.transform(T, scene), f.model_points, kdtree=True)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2.view(np.uint64), rd2.view(np.uint64))  # same formula, same bits
+
+
+def test_nn_adversarial_ties(ctx, oracle):
+    """Many target points at (near-)equal distance: the fp32 filter cannot decide and the
+    float64 re-score / fallback must: lattice targets, queries on cell centres and faces."""
+    from pedp_hip import _lib
+
+    g = np.arange(-6, 7, dtype=np.float64) * 4.0
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + 100.0
+    rng = np.random.default_rng(3)
+    q = tgt[rng.integers(0, len(tgt), 1500)] + np.array([2.0, 2.0, 2.0])       # 8-way exact ties
+    q2 = tgt[rng.integers(0, len(tgt), 1500)] + np.array([2.0, 0.0, 0.0])      # 2-way exact ties
+    q3 = tgt[rng.integers(0, len(tgt), 1500)] + rng.normal(0, 1e-7, (1500, 3)) + [2.0, 2.0, 0]
+    src = np.vstack([q, q2, q3])
+    idx, d2 = _lib.nn(ctx, _lib.Cloud(ctx, src), _lib.Cloud(ctx, tgt))
+    ridx, rd2 = oracle.nn(src, tgt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+@pytest.mark.parametrize("config", ["tiny", "parity"])
+def test_icp_trace_matches_oracle(ctx, oracle, config, estimator):
+    from pedp_hip import _lib
+
+    f, scene = _frame_scene(oracle, config)
+    src = _lib.Cloud(ctx, scene)
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    res = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), estimator=estimator, max_iteration=20,
+                   relative_fitness=-1, relative_rmse=-1, want_corr=True, want_trace=True)
+    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), estimator=estimator, max_iter=20,
+                     rel_fitness=-1, rel_rmse=-1)
+    assert res["iters"] == ref["iters"] == 20
+    assert np.array_equal(res["corr"], ref["corr"])
+    assert res["fitness"] == ref["fitness"]
+    assert abs(res["inlier_rmse"] - ref["inlier_rmse"]) < 1e-9
+    assert np.abs(res["T"] - ref["T"]).max() < POSE_TOL
+    assert np.abs(res["trace"][:, :2] - ref["trace"][:, :2]).max() < 1e-9      # per-pass fitness / rmse
+    assert np.abs(res["trace"][:, 2:] - ref["trace"][:, 2:]).max() < POSE_TOL  # per-pass T
+
+
+def test_icp_default_criteria_early_exit(ctx, oracle):
+    """Open3D defaults (30 iterations, 1e-6 / 1e-6): same stopping pass as the oracle.  A
+    noise-free partial view converges and trips the relative criteria before 30."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    hit = np.isfinite(depth)
+    scene = synth.scene_from_depth(depth[hit], f.dirs[hit], noise_sigma=0.0)
+    res = _lib.icp(ctx, _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals), 10.0, f.icp_init(),
+                   want_corr=True)
+    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init())
+    assert res["iters"] == ref["iters"]
+    assert ref["iters"] < 30
+    assert np.abs(res["T"] - ref["T"]).max() < POSE_TOL
+    assert res["fitness"] == ref["fitness"] and np.array_equal(res["corr"], ref["corr"])
+
+
+def test_icp_known_answer_noise_free(ctx):
+    """Scene = rigidly moved model subset, exact correspondences exist: the recovered
+    transform is the inverse motion."""
+    from pedp_hip import _lib, synth
+
+    verts, tris, normals = synth.bumpy_torus(50, 40)
+    model = verts.astype(np.float64)
+    M = np.eye(4)
+    M[:3, :3] = synth.axis_angle([0.3, -1.0, 0.5], np.deg2rad(1.5))
+    M[:3, 3] = [0.4, -0.3, 0.5]
+    scene = (model[::3] @ M[:3, :3].T) + M[:3, 3]
+    for est in (0, 1):
+        res = _lib.icp(ctx, _lib.Cloud(ctx, scene), _lib.Cloud(ctx, model, normals), 5.0, np.eye(4),
+                       estimator=est, max_iteration=60, relative_fitness=1e-12, relative_rmse=1e-12)
+        assert res["fitness"] == 1.0
+        assert np.abs(res["T"] - np.linalg.inv(M)).max() < 1e-8
+        assert res["inlier_rmse"] < 1e-8
+
+
+def test_icp_error_and_degenerate_cases(ctx, oracle):
+    from pedp_hip import _lib, synth
+
+    verts, tris, normals = synth.bumpy_torus(16, 12)
+    model = verts.astype(np.float64)
+    scene = model[:50] + 0.1
+    src = _lib.Cloud(ctx, scene)
+    with pytest.raises(_lib.PedpError, match="normals"):
+        _lib.icp(ctx, src, _lib.Cloud(ctx, model), 5.0, np.eye(4), estimator=0)
+    tgt = _lib.Cloud(ctx, model, normals)
+    # nothing within reach: fitness 0, rmse 0, identity update, stops after one iteration
+    far = np.eye(4)
+    far[:3, 3] = 1e4
+    res = _lib.icp(ctx, src, tgt, 1.0, far, want_corr=True)
+    ref = oracle.icp(scene, model, normals, 1.0, far)
+    assert res["fitness"] == ref["fitness"] == 0.0 and res["inlier_rmse"] == 0.0
+    assert res["iters"] == ref["iters"] == 1 and np.array_equal(res["T"], far)
+    assert (res["corr"] == -1).all()
+    # max_iteration = 0 returns the initial pass
+    res0 = _lib.icp(ctx, src, tgt, 5.0, np.eye(4), max_iteration=0)
+    ref0 = oracle.icp(scene, model, normals, 5.0, np.eye(4), max_iter=0)
+    assert res0["iters"] == 0 and res0["fitness"] == ref0["fitness"] and np.array_equal(res0["T"], np.eye(4))
+    # empty source
+    res_e = _lib.icp(ctx, _lib.Cloud(ctx, np.zeros((0, 3))), tgt, 5.0, np.eye(4))
+    assert res_e["fitness"] == 0.0
+
+
+def test_icp_batched_matches_single(ctx, oracle):
+    from pedp_hip import _lib, synth
+
+    f, scene = _frame_scene(oracle, "tiny")
+    src = _lib.Cloud(ctx, scene)
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(6)])
+    T, fit, rmse = _lib.icp_batched(ctx, src, tgt, 10.0, inits, max_iteration=5)
+    for b in range(len(inits)):
+        ref = oracle.icp(scene, f.model_points, f.normals, 10.0, inits[b], max_iter=5, rel_fitness=-1, rel_rmse=-1)
+        assert np.abs(T[b] - ref["T"]).max() < POSE_TOL and fit[b] == ref["fitness"]
+
+
+def test_cluster_poses_matches_oracle(oracle):
+    from pedp_hip import _lib, synth
+
+    rng = np.random.default_rng(0)
+    poses = np.tile(np.eye(4, dtype=np.float32), (60, 1, 1))
+    for k in range(60):
+        poses[k, :3, :3] = synth.axis_angle(rng.normal(size=3), rng.uniform(0, np.pi)).astype(np.float32)
+    syms = np.stack([np.eye(4), np.diag([-1.0, -1.0, 1.0, 1.0])]).astype(np.float32)
+    assert np.array_equal(_lib.cluster_poses(30, 99999, poses, syms), oracle.cluster_poses(30, 99999, poses, syms))

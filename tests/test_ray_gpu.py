@@ -1,0 +1,131 @@
+"""GPU parity of the ray sweep against the oracle: t_hit / primitive_ids / uv bit-exact
+(BASELINE.md s6).  Everything goes through the C ABI (pedp_raycast)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(res, ref):
+    assert np.array_equal(res["primitive_ids"], ref["primitive_ids"])
+    assert np.array_equal(res["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
+    assert np.array_equal(res["primitive_uvs"].view(np.uint32), ref["primitive_uvs"].view(np.uint32))
+
+
+@pytest.mark.parametrize("config", ["tiny", "parity"])
+@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 32), (2, 0), (2, 16)])
+def test_frame_bit_exact(ctx, oracle, config, variant, chunks):
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame(config)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    assert np.isfinite(ref["t_hit"]).sum() > 50
+    _lib.raycast_configure(ctx, chunks, variant)
+    try:
+        mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+        _same(mesh.cast_rays(f.rays6), ref)
+    finally:
+        _lib.raycast_configure(ctx, 0, 0)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
+def test_ragged_ray_counts(ctx, oracle, n):
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    rng = np.random.default_rng(n)
+    sel = rng.choice(f.n_rays, size=n, replace=False) if n else np.zeros(0, int)
+    rays = f.rays6[sel]
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    res = mesh.cast_rays(rays)
+    ref = oracle.raycast(f.verts_posed, f.tris, rays)
+    _same(res, ref)
+
+
+def test_general_origins_and_unnormalised_directions(ctx, oracle):
+    """cast_rays takes arbitrary [o|d] rows: per-ray origins, directions used as given."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    rng = np.random.default_rng(5)
+    n = 3000
+    o = rng.normal(0, 150, size=(n, 3))
+    tgt = f.verts_posed[rng.integers(0, len(f.verts_posed), n)] + rng.normal(0, 5, size=(n, 3))
+    d = (tgt - o) * rng.uniform(0.01, 3.0, size=(n, 1))
+    rays = np.hstack([o, d]).astype(np.float32)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    for variant in (1, 2):
+        _lib.raycast_configure(ctx, 0, variant)
+        try:
+            _same(mesh.cast_rays(rays), oracle.raycast(f.verts_posed, f.tris, rays))
+        finally:
+            _lib.raycast_configure(ctx, 0, 0)
+
+
+def test_known_answers_single_triangle_and_cube(ctx):
+    from pedp_hip import _lib
+
+    v = np.array([[0, 0, 5], [1, 0, 5], [0, 1, 5]], np.float32)
+    t = np.array([[0, 1, 2]], np.uint32)
+    mesh = _lib.Mesh(ctx, v, t)
+    rays = np.array([
+        [0.25, 0.25, 0, 0, 0, 1],    # interior: t = 5, u = v = 0.25
+        [0.25, 0.25, 0, 0, 0, -1],   # behind the origin: miss
+        [0.0, 0.0, 0, 0, 0, 1],      # vertex v0: inclusive
+        [0.5, 0.5, 0, 0, 0, 1],      # on the hypotenuse: inclusive
+        [0.6, 0.6, 0, 0, 0, 1],      # outside
+        [0.25, 0.25, 10, 0, 0, -1],  # back face: no culling, t = 5
+        [0.25, 0.25, 0, 0, 0, 2],    # unnormalised direction: t = 2.5
+        [0.25, 0.25, 0, 1, 0, 0],    # parallel: det == 0 -> miss
+    ], np.float32)
+    r = mesh.cast_rays(rays)
+    assert r["t_hit"].tolist() == [5.0, np.inf, 5.0, 5.0, np.inf, 5.0, 2.5, np.inf]
+    assert r["primitive_ids"].tolist() == [0, 0xFFFFFFFF, 0, 0, 0xFFFFFFFF, 0, 0, 0xFFFFFFFF]
+    assert r["primitive_uvs"][0].tolist() == [0.25, 0.25]
+    # unit cube [0,1]^3, 12 triangles; a ray along +z through (0.3, 0.6) enters at z=0
+    cv = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    ct = np.array([[a, b, c] for a, b, c, d in quads] + [[a, c, d] for a, b, c, d in quads], np.uint32)
+    cube = _lib.Mesh(ctx, cv, ct)
+    rr = cube.cast_rays(np.array([[0.3, 0.6, -2, 0, 0, 1], [0.3, 0.6, 0.5, 0, 0, 1], [3, 3, -2, 0, 0, 1]], np.float32))
+    assert rr["t_hit"].tolist() == [2.0, 0.5, np.inf]
+
+
+def test_tie_takes_lowest_triangle_index(ctx, oracle):
+    """Two coincident triangles: equal t -> the smaller index wins, whatever the chunking."""
+    from pedp_hip import _lib
+
+    base = np.array([[0, 0, 5], [1, 0, 5], [0, 1, 5]], np.float32)
+    far = base + np.float32([0, 0, 3])
+    v = np.vstack([far, base, base])
+    pad = 70  # push the duplicates into different unroll groups / lanes
+    filler = np.tile(np.arange(3, dtype=np.uint32), (pad, 1))          # far triangle, many times
+    t = np.vstack([filler, [[3, 4, 5]], filler, [[6, 7, 8]]]).astype(np.uint32)
+    rays = np.tile(np.array([[0.2, 0.3, 0, 0, 0, 1]], np.float32), (130, 1))
+    mesh = _lib.Mesh(ctx, v, t)
+    for variant in (1, 2):
+        _lib.raycast_configure(ctx, 8, variant)
+        try:
+            r = mesh.cast_rays(rays)
+        finally:
+            _lib.raycast_configure(ctx, 0, 0)
+        assert (r["primitive_ids"] == pad).all() and (r["t_hit"] == 5.0).all()
+        ref = oracle.raycast(v, t, rays)
+        assert np.array_equal(r["primitive_ids"], ref["primitive_ids"])
+
+
+def test_bad_arguments_raise(ctx):
+    from pedp_hip import _lib
+
+    with pytest.raises(_lib.PedpError):
+        _lib.Mesh(ctx, np.zeros((3, 3), np.float32), np.array([[0, 1, 3]], np.uint32))  # index >= V
+    with pytest.raises(_lib.PedpError):
+        _lib.raycast_configure(ctx, 12, 1)  # chunks must be a multiple of 8
+
+
+def test_empty_mesh_all_miss(ctx):
+    from pedp_hip import _lib
+
+    mesh = _lib.Mesh(ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    r = mesh.cast_rays(np.array([[0, 0, 0, 0, 0, 1]] * 5, np.float32))
+    assert np.isinf(r["t_hit"]).all() and (r["primitive_ids"] == 0xFFFFFFFF).all()
