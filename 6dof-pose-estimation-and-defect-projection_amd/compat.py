@@ -1,0 +1,48 @@
+"""Drop-in surface: `from pedp_hip.compat import *` where run.py says `from src import *`
+(run.py:3, src/__init__.py:1-4), plus the `mycpp` slot (Utils.py:45-48, estimater.py:118).
+
+Only the hot-path names are provided; viewer, sensor and learned-model code
+stay the reference's own.
+"""
+import numpy as np
+
+from . import _lib
+from .geometry import (LineSet, PinholeCameraIntrinsic, PointCloud, RegistrationResult,  # noqa: F401
+                       TriangleMesh)
+from .icp_refine import (improve_result, predict_z_axis_adjustment, preprocess_source,  # noqa: F401
+                         preprocess_target, refine_pose_with_icp, refine_registration, transform_object)
+from .ray_projection import (compute_rays, create_intersection_pcd, heatmap_to_points,  # noqa: F401
+                             intersect_rays_with_mesh, load_extrinsics, project_debug_rays, ray_tracing)
+from .registration import (ICPConvergenceCriteria, TransformationEstimationPointToPlane,  # noqa: F401
+                           TransformationEstimationPointToPoint, get_rotation_matrix_from_xyz,
+                           registration_icp)
+
+
+def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
+    """mycpp.cluster_poses(angle_diff_deg, dist_diff, poses[N,4,4], symmetry_tfs[S,4,4]) ->
+    list of kept 4x4 float32 poses (mycpp/src/app/pybind_api.cpp:24-68).  Prints the two
+    lines the C++ prints (:26, :66)."""
+    poses = np.ascontiguousarray(poses_in, dtype=np.float32).reshape(-1, 4, 4)
+    print(f"num original candidates = {len(poses)}")
+    keep = _lib.cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs)
+    print(f"num of pose after clustering: {len(keep)}")
+    return [poses[k].copy() for k in keep]
+
+
+class _MyCpp:
+    """`mycpp = pedp_hip.compat.mycpp` gives estimater.py its `mycpp.cluster_poses`."""
+    cluster_poses = staticmethod(cluster_poses)
+
+
+mycpp = _MyCpp()
+
+__all__ = [
+    "refine_registration", "improve_result", "predict_z_axis_adjustment", "refine_pose_with_icp",
+    "preprocess_source", "preprocess_target", "transform_object",
+    "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
+    "project_debug_rays", "load_extrinsics", "ray_tracing",
+    "registration_icp", "TransformationEstimationPointToPlane", "TransformationEstimationPointToPoint",
+    "ICPConvergenceCriteria", "get_rotation_matrix_from_xyz",
+    "PointCloud", "TriangleMesh", "LineSet", "PinholeCameraIntrinsic", "RegistrationResult",
+    "cluster_poses", "mycpp",
+]

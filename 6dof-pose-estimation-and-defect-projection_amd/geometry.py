@@ -1,0 +1,159 @@
+"""Plain holders with the attribute surface the reference uses on Open3D objects along the
+hot path.  Open3D is not importable on the GPU box, so the
+drop-in functions work on these -- and on real Open3D objects too, because every access
+goes through `np.asarray(obj.points)`-style duck typing.
+
+    o3d.geometry.PointCloud        .points .normals .colors .has_normals() .has_colors()
+                                   .transform(T) .paint_uniform_color(rgb)
+                                   (src/pose_estimation.py:162-169, :406-409, :769-770)
+    o3d.geometry.TriangleMesh      .vertices .triangles .transform(T)
+                                   (src/defect_projection.py:240-245, :549-550)
+    o3d.camera.PinholeCameraIntrinsic   .intrinsic_matrix (src/defect_projection.py:209-212)
+    o3d.pipelines.registration.RegistrationResult   .transformation .fitness .inlier_rmse
+                                   .correspondence_set (src/pose_estimation.py:566-569, :617-620)
+"""
+import copy
+
+import numpy as np
+
+
+def _arr(x, cols=3, dtype=np.float64):
+    a = np.asarray(x, dtype=dtype)
+    return a.reshape(-1, cols) if a.size else np.zeros((0, cols), dtype)
+
+
+class PointCloud:
+    def __init__(self, points=None, normals=None, colors=None):
+        self.points = _arr([] if points is None else points)
+        self.normals = _arr([] if normals is None else normals)
+        self.colors = _arr([] if colors is None else colors)
+
+    def has_normals(self):
+        return len(self.normals) == len(self.points) and len(self.points) > 0
+
+    def has_colors(self):
+        return len(self.colors) == len(self.points) and len(self.points) > 0
+
+    def has_points(self):
+        return len(self.points) > 0
+
+    def transform(self, T):
+        """In place, float64, like Open3D: points by the full 4x4, normals by the rotation."""
+        T = np.asarray(T, dtype=np.float64)
+        self.points = np.asarray(self.points, np.float64) @ T[:3, :3].T + T[:3, 3]
+        if len(self.normals):
+            self.normals = np.asarray(self.normals, np.float64) @ T[:3, :3].T
+        return self
+
+    def paint_uniform_color(self, rgb):
+        self.colors = np.tile(np.asarray(rgb, np.float64), (len(self.points), 1))
+        return self
+
+    def __len__(self):
+        return len(self.points)
+
+    def __deepcopy__(self, memo):
+        return PointCloud(np.array(self.points), np.array(self.normals), np.array(self.colors))
+
+
+class TriangleMesh:
+    def __init__(self, vertices=None, triangles=None):
+        self.vertices = _arr([] if vertices is None else vertices)
+        self.triangles = _arr([] if triangles is None else triangles, 3, np.int32)
+        self.vertex_normals = np.zeros((0, 3))
+        self.triangle_normals = np.zeros((0, 3))
+
+    def transform(self, T):
+        T = np.asarray(T, dtype=np.float64)
+        self.vertices = np.asarray(self.vertices, np.float64) @ T[:3, :3].T + T[:3, 3]
+        if len(self.vertex_normals):
+            self.vertex_normals = self.vertex_normals @ T[:3, :3].T
+        if len(self.triangle_normals):
+            self.triangle_normals = self.triangle_normals @ T[:3, :3].T
+        return self
+
+    def has_triangle_normals(self):
+        return len(self.triangle_normals) == len(self.triangles) and len(self.triangles) > 0
+
+    def has_vertex_normals(self):
+        return len(self.vertex_normals) == len(self.vertices) and len(self.vertices) > 0
+
+    def compute_triangle_normals(self):
+        v, t = np.asarray(self.vertices, np.float64), np.asarray(self.triangles)
+        n = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]])
+        ln = np.linalg.norm(n, axis=1, keepdims=True)
+        self.triangle_normals = n / np.where(ln > 0, ln, 1.0)
+        return self
+
+    def compute_vertex_normals(self):
+        v, t = np.asarray(self.vertices, np.float64), np.asarray(self.triangles)
+        fn = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]])
+        acc = np.zeros_like(v)
+        for k in range(3):
+            np.add.at(acc, t[:, k], fn)
+        ln = np.linalg.norm(acc, axis=1, keepdims=True)
+        self.vertex_normals = acc / np.where(ln > 0, ln, 1.0)
+        return self
+
+    def __deepcopy__(self, memo):
+        m = TriangleMesh(np.array(self.vertices), np.array(self.triangles))
+        m.vertex_normals = np.array(self.vertex_normals)
+        m.triangle_normals = np.array(self.triangle_normals)
+        return m
+
+
+class LineSet:
+    """Debug rays returned by ray_tracing when nothing was hit (defect_projection.py:296-317)."""
+
+    def __init__(self):
+        self.points = np.zeros((0, 3))
+        self.lines = np.zeros((0, 2), np.int32)
+        self.colors = np.zeros((0, 3))
+
+    def paint_uniform_color(self, rgb):
+        self.colors = np.tile(np.asarray(rgb, np.float64), (len(self.lines), 1))
+        return self
+
+    def transform(self, T):
+        T = np.asarray(T, dtype=np.float64)
+        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        return self
+
+
+class PinholeCameraIntrinsic:
+    def __init__(self, width=0, height=0, fx=1.0, fy=1.0, cx=0.0, cy=0.0, intrinsic_matrix=None):
+        self.width, self.height = int(width), int(height)
+        if intrinsic_matrix is not None:
+            self.intrinsic_matrix = np.array(intrinsic_matrix, dtype=np.float64)
+        else:
+            self.intrinsic_matrix = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float64)
+
+
+class RegistrationResult:
+    def __init__(self, transformation=None):
+        self.transformation = np.eye(4) if transformation is None else np.array(transformation, dtype=np.float64)
+        self.fitness = 0.0
+        self.inlier_rmse = 0.0
+        self.correspondence_set = np.zeros((0, 2), np.int32)
+
+    def __repr__(self):
+        return (f"RegistrationResult with fitness={self.fitness:e}, inlier_rmse={self.inlier_rmse:e}, "
+                f"and correspondence_set size of {len(self.correspondence_set)}")
+
+
+def points_of(obj):
+    """float64 N x 3 view of a PointCloud-like object (ours, Open3D's, or a bare array)."""
+    if hasattr(obj, "points"):
+        return _arr(obj.points)
+    return _arr(obj)
+
+
+def normals_of(obj):
+    if hasattr(obj, "has_normals"):
+        return _arr(obj.normals) if obj.has_normals() else None
+    n = getattr(obj, "normals", None)
+    return _arr(n) if n is not None and len(n) else None
+
+
+def clone(obj):
+    return copy.deepcopy(obj)

@@ -1,0 +1,182 @@
+"""Host mirror of the reference's ICP refinement functions (src/pose_estimation.py), same
+names, positional signatures, return values and input mutations, with every
+registration_icp call running on the GPU through libpedp_hip.so.
+
+    refine_registration          pose_estimation.py:505-522
+    improve_result               :547-622   (randomised restarts, global numpy RNG)
+    predict_z_axis_adjustment    :624-683   (adaptive camera-z line search)
+    refine_pose_with_icp         :749-822   (orchestrator called by run.py:99)
+    transform_object             :406-409
+    preprocess_target            :141-183   (random subsample to max_pcd; keeps normals)
+    preprocess_source            :186-268   (OUT OF SCOPE this round, SURVEY s8 f2: the scene
+                                             cloud is passed through unchanged)
+
+Units are millimetres, transformations are 4x4 float64; `*.transformation` of a result maps
+scene -> model, exactly like the reference's RegistrationResult.
+"""
+import copy
+import logging
+
+import numpy as np
+
+from . import registration as reg
+from .geometry import PointCloud, RegistrationResult, clone, normals_of, points_of
+
+
+def transform_object(pcd, transformation):
+    """Deep copy moved by `transformation` (pose_estimation.py:406-409)."""
+    moved = clone(pcd)
+    moved.transform(transformation)
+    return moved
+
+
+def refine_registration(source, target, transformation, param):
+    """One full point-to-plane ICP with Open3D's default criteria (pose_estimation.py:505-522)."""
+    return reg.registration_icp(source, target, param["refine_registration"]["distance_threshold"],
+                                transformation, reg.TransformationEstimationPointToPlane())
+
+
+def preprocess_target(pcd, param):
+    """Subsample the model cloud to `max_pcd` points with the global numpy RNG
+    (np.random.choice(..., replace=False), pose_estimation.py:159-169).  The reference then
+    re-estimates normals and computes FPFH features (:174-179, Open3D KD-tree code, SURVEY s8
+    f2 'next'); here the model's own normals are carried over and the feature slot is None."""
+    cap = param["preprocess_target"]["max_pcd"]
+    pts, nrm = points_of(pcd), normals_of(pcd)
+    if len(pts) > cap:
+        keep = np.random.choice(len(pts), cap, replace=False)
+        out = PointCloud(pts[keep], None if nrm is None else nrm[keep])
+        if hasattr(pcd, "has_colors") and pcd.has_colors():
+            out.colors = np.asarray(pcd.colors)[keep]
+    else:
+        logging.info(f":: Point cloud already has less than or exactly {cap} points.")
+        out = pcd
+    if normals_of(out) is None:
+        raise RuntimeError("preprocess_target: the model cloud carries no normals; normal estimation "
+                           "(pose_estimation.py:301-306) belongs to the not-yet-built preprocessing row")
+    return out, None
+
+
+def preprocess_source(pcd, background, param, i=0):
+    """Scene preprocessing (voxel grid, plane removal, clustering, outlier filter;
+    pose_estimation.py:186-268) is the 'next' row f2 of SURVEY s8 and is not built: the cloud
+    is returned as is.  Only the reference's parameter mutation for tracking frames is kept
+    (`down_sample = 5` when i > 0, :202-203)."""
+    if i > 0:
+        param.setdefault("preprocess_source", {})["down_sample"] = 5
+    return pcd, pcd, None
+
+
+def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, max_adjustment=50,
+                              initial_step=10):
+    """Adaptive 1-D search for the camera-z offset that maximises ICP fitness
+    (pose_estimation.py:624-683).  Each probe is a single-iteration point-to-plane ICP started
+    from inv(T) with T[2,3] lowered by the probe offset.  Walk in the current direction while
+    the probe improves (fitness, then lower rmse); otherwise turn round and halve the step;
+    clamp to +-max_adjustment (step / 1.25, turn); stop below 0.1 mm or above 0.95 fitness."""
+    radius = param["refine_registration"]["distance_threshold"]
+    d_src, d_tgt = reg.upload(source), reg.upload(target)  # one upload for all probes
+    one_iteration = reg.ICPConvergenceCriteria(max_iteration=1)
+    plane = reg.TransformationEstimationPointToPlane()
+    best_adjustment, best_fitness, best_rmse = 0, 0, float("inf")
+    offset, step, heading = 0, initial_step, 1
+    while abs(step) >= 0.1:
+        probe = np.copy(initial_fp_transformation)
+        probe[2, 3] -= offset
+        res = reg.registration_icp(d_src, d_tgt, radius, np.linalg.inv(probe), plane, one_iteration)
+        better = res.fitness > best_fitness or (res.fitness == best_fitness and res.inlier_rmse < best_rmse)
+        if better:
+            best_adjustment, best_fitness, best_rmse = offset, res.fitness, res.inlier_rmse
+        else:
+            heading = -heading
+            step = step / 2
+        offset += step * heading
+        if abs(offset) > max_adjustment:
+            offset = max_adjustment * np.sign(offset)
+            step = step / 1.25
+            heading = -heading
+        if best_fitness > 0.95:
+            break
+    logging.info(f":: Best z-axis adjustment: {best_adjustment:.2f}mm, Fitness: {best_fitness:.4f}, "
+                 f"RMSE: {best_rmse:.4f}")
+    return best_adjustment, best_fitness, best_rmse
+
+
+def improve_result(source_processed, original_target_processed, current_result, parameter):
+    """Up to 50 randomised ICP restarts around the best scene->model transformation so far
+    (pose_estimation.py:547-622).
+
+    Reference behaviours kept because they change the returned numbers:
+      * `current_result` may be a bare 4x4 (tracking frames, run.py:168): treated as
+        fitness 0.8 / rmse 3.0 (:564-569);
+      * the search starts from inv(current_result.transformation) (:572);
+      * RNG order per restart: 1 x uniform(0.8, 1.2), 3 x uniform(-0.01, 0.01), 1 x
+        uniform(-x, x, 3) from the global numpy RNG;
+      * the distance threshold is scaled IN PLACE on a shallow copy, so it random-walks
+        across restarts (:580-582);
+      * a result with zero fitness or rmse widens the translation noise by 0.25 (:609);
+      * exceptions in a restart are logged and skipped (:610-611).
+    """
+    settings = copy.deepcopy(parameter)
+    if not hasattr(current_result, "fitness") or current_result.fitness is None:
+        seed = RegistrationResult(current_result)
+        seed.fitness, seed.inlier_rmse = 0.8, 3.0
+        current_result = seed
+    best_fitness, best_rmse = current_result.fitness, current_result.inlier_rmse
+    best_T = np.linalg.inv(current_result.transformation)
+    want_fitness = settings["run_icp"]["fitness_threshold"]
+    want_rmse = settings["run_icp"]["rmse_threshold"]
+    d_src, d_tgt = reg.upload(source_processed), reg.upload(original_target_processed)
+    spread, rounds = 0.1, 0
+    logging.info(":: Additional refinements")
+    while rounds < 50 and (best_fitness < want_fitness or best_rmse > want_rmse):
+        trial = settings.copy()  # shallow on purpose: the nested dict is shared
+        trial["refine_registration"]["distance_threshold"] *= np.random.uniform(0.8, 1.2)
+        wobble = np.eye(4)
+        wobble[:3, :3] = reg.get_rotation_matrix_from_xyz([np.random.uniform(-0.01, 0.01) for _ in range(3)])
+        wobble[:3, 3] = np.random.uniform(-spread, spread, 3)
+        try:
+            res = refine_registration(d_src, d_tgt, wobble @ best_T, trial)
+            if res.fitness > 0 and res.inlier_rmse > 0:
+                if res.fitness > best_fitness or (res.fitness == best_fitness and res.inlier_rmse < best_rmse):
+                    best_fitness, best_rmse, best_T = res.fitness, res.inlier_rmse, res.transformation
+                    logging.info(f":: Improved result: Fitness = {best_fitness:.4f}, RMSE = {best_rmse:.4f}")
+            else:
+                logging.info(f":: Iteration {rounds + 1} produced an invalid result. Skipping.")
+                spread += 0.25
+        except Exception as exc:  # same contract as the reference: a failed restart is skipped
+            logging.info(f":: Error in refinement iteration {rounds + 1}: {exc}. Skipping this iteration.")
+        rounds += 1
+    logging.info(f":: Total iterations: {rounds}")
+    out = RegistrationResult(best_T)
+    out.fitness, out.inlier_rmse = best_fitness, best_rmse
+    return out
+
+
+def refine_pose_with_icp(source, target, background, initial_fp_transformation, parameters):
+    """FoundationPose estimate -> z search -> randomised ICP refinement (pose_estimation.py:
+    749-822; caller run.py:99).  Mutations kept: both clouds are painted (:769-770) and the
+    caller's `initial_fp_transformation[2, 3]` receives the z adjustment in place (:789),
+    which run.py:104 relies on.  Returns (model moved into the scene, result, z adjustment,
+    preprocessed target)."""
+    param = copy.deepcopy(parameters)
+    if hasattr(source, "paint_uniform_color"):
+        source.paint_uniform_color([1, 0, 0])
+    if hasattr(target, "paint_uniform_color"):
+        target.paint_uniform_color([0, 0, 1])
+    target_processed, _ = preprocess_target(target, param)
+    source_processed, _, _ = preprocess_source(source, background, param)
+
+    z_adjustment, fitness, rmse = predict_z_axis_adjustment(source_processed, target_processed,
+                                                            initial_fp_transformation, param)
+    initial_fp_transformation[2, 3] += z_adjustment
+    logging.info(f":: Predicted Z-axis adjustment: {z_adjustment:.2f}mm")
+
+    start = RegistrationResult(initial_fp_transformation)
+    start.fitness, start.inlier_rmse = fitness, rmse
+    best = improve_result(source_processed, target_processed, start, param)
+    model_in_scene = np.linalg.inv(best.transformation)
+    logging.info(f"-- Final Results\n:: Refine registration results: Inlier_rmse: {best.inlier_rmse:.4f}, "
+                 f"Fitness: {best.fitness:.4f}\n:: Final Transformation Matrix:\n{model_in_scene}")
+    target_transformed = transform_object(target, model_in_scene)
+    return target_transformed, best, z_adjustment, target_processed

@@ -1,0 +1,162 @@
+"""Host mirror of the reference's 2D -> 3D defect projection (src/defect_projection.py): same
+names, positional signatures and return values; the ray / mesh intersection runs on the GPU
+through libpedp_hip.so instead of Open3D's RaycastingScene (Embree).
+
+    heatmap_to_points          defect_projection.py:165-179
+    compute_rays               :196-223
+    intersect_rays_with_mesh   :225-266
+    create_intersection_pcd    :268-294
+    project_debug_rays         :296-317
+    load_extrinsics            :65-94
+    ray_tracing                :527-563   (caller run.py:113, :187)
+"""
+import json
+import logging
+
+import numpy as np
+
+from . import _lib
+from .geometry import LineSet, PointCloud, clone
+
+
+def heatmap_to_points(heatmap, threshold=0.5):
+    """Pixels above `threshold` as (x, y, intensity) tuples in row-major order (y outer):
+    this order is the ray order of everything downstream."""
+    rows, cols = np.nonzero(heatmap > threshold)
+    return list(zip(cols, rows, heatmap[rows, cols]))
+
+
+def compute_rays(points, intrinsic):
+    """Unit viewing directions (float64) of the given pixels through a pinhole camera:
+    normalise((x - cx) / fx, (y - cy) / fy, 1).  The reference loops in Python per pixel
+    (defect_projection.py:216-222); this is the same arithmetic on whole arrays."""
+    K = np.asarray(intrinsic.intrinsic_matrix, dtype=np.float64)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    if len(points) == 0:
+        return np.array([]), np.array([])
+    px = np.array([p[0] for p in points], dtype=np.float64)
+    py = np.array([p[1] for p in points], dtype=np.float64)
+    intensities = np.array([p[2] for p in points])
+    d = np.stack([(px - cx) / fx, (py - cy) / fy, np.ones_like(px)], axis=1)
+    d /= np.sqrt(np.einsum("ij,ij->i", d, d))[:, None]
+    return d, intensities
+
+
+def _device_mesh(mesh, ctx):
+    """from_legacy: float32 vertices, uint32 triangles (defect_projection.py:245)."""
+    if isinstance(mesh, _lib.Mesh):
+        return mesh
+    return _lib.Mesh(ctx, np.asarray(mesh.vertices, dtype=np.float64).astype(np.float32),
+                     np.asarray(mesh.triangles))
+
+
+def cast_rays(mesh, rays6, ctx=None):
+    """RaycastingScene.cast_rays stand-in: dict with t_hit, primitive_ids, primitive_uvs."""
+    ctx = ctx or (mesh.ctx if isinstance(mesh, _lib.Mesh) else _lib.default_context())
+    return _device_mesh(mesh, ctx).cast_rays(rays6)
+
+
+def intersect_rays_with_mesh(mesh, rays, origin, intensities, ctx=None, details=None):
+    """Closest hit of every ray with the mesh; returns (hit points M x 3 float64, intensities
+    of the rays that hit), ray order preserved.  As in the reference the [origin | direction]
+    rows are cast to float32 for the intersection (:251) while the hit points are formed in
+    float64 from the float64 directions and the float32 distance (:261-263).
+    `details`, if a dict, receives t_hit / primitive_ids / primitive_uvs / valid mask (the
+    reference discards them; north_star asks for the triangle indices)."""
+    rays = np.asarray(rays, dtype=np.float64).reshape(-1, 3)
+    n = len(rays)
+    origins = np.tile(np.asarray(origin), (n, 1))
+    rays6 = np.hstack((origins, rays)).astype(np.float32)
+    hit = cast_rays(mesh, rays6, ctx)
+    t = hit["t_hit"]
+    valid = t != np.inf
+    points = origins[valid] + rays[valid] * t[valid, np.newaxis]
+    if details is not None:
+        details.update(hit)
+        details["valid"] = valid
+    return points, np.asarray(intensities)[valid]
+
+
+# matplotlib's 'jet' segment data (x, y) per channel, restated so the GPU box needs no
+# matplotlib: the reference maps normalised intensities through cm.get_cmap('jet') (:290).
+_JET = {
+    "r": [(0.0, 0.0), (0.35, 0.0), (0.66, 1.0), (0.89, 1.0), (1.0, 0.5)],
+    "g": [(0.0, 0.0), (0.125, 0.0), (0.375, 1.0), (0.64, 1.0), (0.91, 0.0), (1.0, 0.0)],
+    "b": [(0.0, 0.5), (0.11, 1.0), (0.34, 1.0), (0.65, 0.0), (1.0, 0.0)],
+}
+_JET_LUT = None
+
+
+def _jet_lut():
+    global _JET_LUT
+    if _JET_LUT is None:
+        grid = np.linspace(0.0, 1.0, 256)
+        _JET_LUT = np.stack([np.interp(grid, *zip(*_JET[c])) for c in "rgb"], axis=1)
+    return _JET_LUT
+
+
+def jet(values):
+    """RGB of matplotlib's 256-entry 'jet' lookup: index floor(v * 256) clipped to 0..255;
+    NaN maps to black (matplotlib's 'bad' colour is transparent black)."""
+    v = np.asarray(values, dtype=np.float64)
+    idx = np.where(np.isnan(v), 0, np.clip(np.nan_to_num(v) * 256.0, -1, 256)).astype(np.int64)
+    idx = np.clip(idx, 0, 255)
+    rgb = _jet_lut()[idx]
+    rgb[np.isnan(v)] = 0.0
+    return rgb
+
+
+def create_intersection_pcd(intersections, intensities):
+    """Hit points coloured by min-max normalised intensity through 'jet'
+    (defect_projection.py:268-294).  Equal intensities divide by zero in the reference too
+    (NaN -> black)."""
+    pcd = PointCloud(intersections)
+    intensities = np.asarray(intensities, dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        scaled = (intensities - np.min(intensities)) / (np.max(intensities) - np.min(intensities))
+    pcd.colors = jet(scaled)
+    return pcd
+
+
+def project_debug_rays(rays, origin):
+    """Red 1000-unit line segments along the rays, returned when nothing was hit (:296-317)."""
+    logging.info("No intersections found.")
+    rays = np.asarray(rays, dtype=np.float64).reshape(-1, 3)
+    ls = LineSet()
+    ls.points = np.vstack((np.tile(origin, (len(rays), 1)), origin + rays * 1000))
+    ls.lines = np.array([[i, i + len(rays)] for i in range(len(rays))], dtype=np.int32).reshape(-1, 2)
+    ls.paint_uniform_color([1, 0, 0])
+    return ls
+
+
+def load_extrinsics(file_path):
+    """color_to_depth / depth_to_color 4x4 from {file_path}/configs/camera_extrinsics.json
+    (defect_projection.py:65-94)."""
+    with open(f"{file_path}/configs/camera_extrinsics.json", "r") as fh:
+        data = json.load(fh)
+
+    def _mat(entry):
+        T = np.eye(4)
+        T[:3, :3] = np.array(entry["rotation_matrix"])
+        T[:3, 3] = np.array(entry["translation_vector"][0])
+        return T
+
+    return _mat(data["color_to_depth"]), _mat(data["depth_to_color"])
+
+
+def ray_tracing(data_dir, target_mesh, heatmap, color_intrinsics, heatmap_threshold=0.5):
+    """Project the heat map's hot pixels onto the posed mesh (defect_projection.py:527-563):
+    rays start at the colour camera's origin, the mesh (given in the depth-camera frame) is
+    copied and moved into the colour-camera frame with inv(color_to_depth), and the closest
+    hits come back as a jet-coloured cloud -- or red debug rays if nothing was hit.
+    Returns (cloud or LineSet, moved mesh copy)."""
+    origin = np.array([0, 0, 0])
+    color_to_depth, _ = load_extrinsics(data_dir)
+    mesh_in_color = clone(target_mesh)
+    mesh_in_color.transform(np.linalg.inv(color_to_depth))
+    pixels = heatmap_to_points(heatmap, heatmap_threshold)
+    rays, intensities = compute_rays(pixels, color_intrinsics)
+    hits, hit_intensities = intersect_rays_with_mesh(mesh_in_color, rays, origin, intensities)
+    if len(hits) > 0:
+        return create_intersection_pcd(hits, hit_intensities), mesh_in_color
+    return project_debug_rays(rays, origin), mesh_in_color

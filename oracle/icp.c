@@ -266,18 +266,24 @@ void pedp_oracle_nn(const double *src, int64_t Ns, const double *tgt, int64_t Nt
     }
 }
 
-/* KD-tree: median split on the widest axis, leaves of <= 16 points. */
+/* KD-tree in the manner of nanoflann (the tree Open3D's KDTreeFlann wraps): median split on
+ * the widest axis, leaves of <= 16 points, and a search that carries the per-axis squared
+ * distance from the query to the current cell (incremental box distance), seeded with the
+ * distance to the root bounding box -- so far-away queries prune almost everything after the
+ * first leaf.  Like KDTreeFlann::SearchHybrid(.., max_nn = 1) it is a plain 1-NN search; the
+ * radius is applied afterwards by the caller. */
 typedef struct {
     int32_t first, count; /* leaf: slots in perm; internal: count == 0 */
     int32_t left, right;
     int32_t axis;
-    double split;
+    double divlow, divhigh; /* max of left / min of right along axis */
 } kd_node;
 typedef struct {
     kd_node *nodes;
     int32_t n_nodes;
     int32_t *perm;
     const double *pts;
+    double lo[3], hi[3];
 } kd_t;
 
 static int kd_axis;
@@ -291,7 +297,7 @@ static int kd_cmp(const void *a, const void *b) {
 static int32_t kd_build_rec(kd_t *t, int32_t first, int32_t count) {
     int32_t me = t->n_nodes++;
     kd_node *nd = &t->nodes[me];
-    nd->first = first; nd->count = 0; nd->left = nd->right = -1; nd->axis = 0; nd->split = 0;
+    nd->first = first; nd->count = 0; nd->left = nd->right = -1; nd->axis = 0; nd->divlow = nd->divhigh = 0;
     if (count <= 16) { nd->count = count; return me; }
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int32_t i = first; i < first + count; ++i)
@@ -307,15 +313,20 @@ static int32_t kd_build_rec(kd_t *t, int32_t first, int32_t count) {
     kd_pts = t->pts;
     qsort(t->perm + first, (size_t)count, sizeof(int32_t), kd_cmp);
     int32_t nl = count / 2;
-    double split = t->pts[3 * (int64_t)t->perm[first + nl] + ax];
+    double divlow = t->pts[3 * (int64_t)t->perm[first + nl - 1] + ax];
+    double divhigh = t->pts[3 * (int64_t)t->perm[first + nl] + ax];
     int32_t l = kd_build_rec(t, first, nl);
     int32_t r = kd_build_rec(t, first + nl, count - nl);
     nd = &t->nodes[me]; /* nodes array is preallocated: pointer stays valid */
-    nd->axis = ax; nd->split = split; nd->left = l; nd->right = r;
+    nd->axis = ax; nd->divlow = divlow; nd->divhigh = divhigh; nd->left = l; nd->right = r;
     return me;
 }
 
-static void kd_search(const kd_t *t, int32_t ni, const double *q, double *best, int32_t *bi) {
+/* mind = lower bound of the squared distance from q to any point of this cell, dists[] its
+ * per-axis parts.  A cell is skipped only if its bound, shrunk by a relative 1e-12 against
+ * rounding, still exceeds the best distance: ties are never pruned. */
+static void kd_search(const kd_t *t, int32_t ni, const double *q, double mind, double dists[3],
+                      double *best, int32_t *bi) {
     const kd_node *nd = &t->nodes[ni];
     if (nd->count > 0) {
         for (int32_t i = nd->first; i < nd->first + nd->count; ++i) {
@@ -325,12 +336,20 @@ static void kd_search(const kd_t *t, int32_t ni, const double *q, double *best, 
         }
         return;
     }
-    double diff = q[nd->axis] - nd->split;
-    int32_t near = diff < 0 ? nd->left : nd->right, far = diff < 0 ? nd->right : nd->left;
-    kd_search(t, near, q, best, bi);
-    /* left holds coords <= split, right holds coords >= split: fl(diff^2) never exceeds
-     * the computed distance of a far-side point, so this prune is exact; ties kept. */
-    if (!(diff * diff > *best)) kd_search(t, far, q, best, bi);
+    double val = q[nd->axis];
+    double d1 = val - nd->divlow, d2 = val - nd->divhigh;
+    int32_t near, far;
+    double cut;
+    if (d1 + d2 < 0) { near = nd->left; far = nd->right; cut = d2 * d2; }
+    else { near = nd->right; far = nd->left; cut = d1 * d1; }
+    kd_search(t, near, q, mind, dists, best, bi);
+    double keep = dists[nd->axis];
+    double mfar = mind + cut - keep;
+    if (!(mfar * (1.0 - 1e-12) > *best)) {
+        dists[nd->axis] = cut;
+        kd_search(t, far, q, mfar, dists, best, bi);
+        dists[nd->axis] = keep;
+    }
 }
 
 void pedp_oracle_nn_kdtree(const double *src, int64_t Ns, const double *tgt, int64_t Nt,
@@ -349,13 +368,27 @@ void pedp_oracle_nn_kdtree(const double *src, int64_t Ns, const double *tgt, int
     t.perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)Nt);
     t.n_nodes = 0;
     t.pts = tgt;
-    for (int64_t i = 0; i < Nt; ++i) t.perm[i] = (int32_t)i;
+    for (int k = 0; k < 3; ++k) { t.lo[k] = INFINITY; t.hi[k] = -INFINITY; }
+    for (int64_t i = 0; i < Nt; ++i) {
+        t.perm[i] = (int32_t)i;
+        for (int k = 0; k < 3; ++k) {
+            if (tgt[3 * i + k] < t.lo[k]) t.lo[k] = tgt[3 * i + k];
+            if (tgt[3 * i + k] > t.hi[k]) t.hi[k] = tgt[3 * i + k];
+        }
+    }
     kd_build_rec(&t, 0, (int32_t)Nt);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < Ns; ++i) {
+        const double *q = src + 3 * i;
+        double dists[3], mind = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            double e = q[k] < t.lo[k] ? t.lo[k] - q[k] : (q[k] > t.hi[k] ? q[k] - t.hi[k] : 0.0);
+            dists[k] = e * e;
+            mind += dists[k];
+        }
         double best = INFINITY;
         int32_t bi = 0x7FFFFFFF;
-        kd_search(&t, 0, src + 3 * i, &best, &bi);
+        kd_search(&t, 0, q, mind, dists, &best, &bi);
         idx[i] = bi;
         d2[i] = best;
     }
