@@ -1,0 +1,133 @@
+"""GPU tests of the drop-in surface (pedp_hip.compat): the reference's function names run on
+the HIP library and reproduce the oracle's restatement of the same control flow."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _frame():
+    from pedp_hip import synth
+
+    return synth.Frame("parity")
+
+
+def test_intersect_rays_with_mesh_points_and_details(oracle):
+    from pedp_hip.compat import TriangleMesh, intersect_rays_with_mesh
+
+    f = _frame()
+    mesh = TriangleMesh(f.verts_posed.astype(np.float64), f.tris)
+    intens = np.linspace(0.0, 1.0, f.n_rays)
+    details = {}
+    pts, it = intersect_rays_with_mesh(mesh, f.dirs, np.array([0, 0, 0]), intens, details=details)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    valid = np.isfinite(ref["t_hit"])
+    assert np.array_equal(details["primitive_ids"], ref["primitive_ids"])          # bit-exact triangle ids
+    assert np.array_equal(details["valid"], valid) and np.array_equal(it, intens[valid])
+    expect = f.dirs[valid] * ref["t_hit"][valid, None].astype(np.float64)          # float64 from float32 t, :261-263
+    assert np.abs(pts - expect).max() <= 1e-5 and pts.dtype == np.float64
+
+
+def test_ray_tracing_end_to_end(oracle, tmp_path):
+    from pedp_hip.compat import PinholeCameraIntrinsic, PointCloud, LineSet, TriangleMesh, ray_tracing
+
+    f = _frame()
+    c2d = np.eye(4)
+    c2d[:3, :3] = [[0.9998, -0.02, 0.0], [0.02, 0.9998, 0.0], [0, 0, 1]]
+    c2d[:3, 3] = [-32.0, 1.5, 3.0]
+    (tmp_path / "configs").mkdir()
+    (tmp_path / "configs" / "camera_extrinsics.json").write_text(json.dumps({
+        "color_to_depth": {"rotation_matrix": c2d[:3, :3].tolist(), "translation_vector": [c2d[:3, 3].tolist()]},
+        "depth_to_color": {"rotation_matrix": c2d[:3, :3].T.tolist(), "translation_vector": [(-c2d[:3, :3].T @ c2d[:3, 3]).tolist()]}}))
+    K = PinholeCameraIntrinsic(f.width, f.height, f.f, f.f, f.cx, f.cy)
+    # mesh handed over in the depth-camera frame, as run.py:109 does
+    mesh_depth = TriangleMesh(f.verts_posed.astype(np.float64) @ c2d[:3, :3].T + c2d[:3, 3], f.tris)
+    yy, xx = np.mgrid[0:f.height, 0:f.width]
+    heat = np.exp(-(((xx - 80) / 30.0) ** 2 + ((yy - 70) / 25.0) ** 2))
+    pcd, moved = ray_tracing(str(tmp_path), mesh_depth, heat, K, heatmap_threshold=0.75)
+    assert isinstance(pcd, PointCloud) and moved is not mesh_depth
+    # the same thing by hand through the oracle
+    vcol = (np.asarray(mesh_depth.vertices) @ np.linalg.inv(c2d)[:3, :3].T + np.linalg.inv(c2d)[:3, 3]).astype(np.float32)
+    mask = heat > 0.75
+    dirs = f.dirs.reshape(f.height, f.width, 3)[mask]
+    rays6 = np.hstack([np.zeros_like(dirs), dirs]).astype(np.float32)
+    ref = oracle.raycast(vcol, f.tris, rays6)
+    ok = np.isfinite(ref["t_hit"])
+    assert ok.sum() > 100 and len(pcd.points) == ok.sum()
+    assert np.abs(pcd.points - dirs[ok] * ref["t_hit"][ok, None].astype(np.float64)).max() <= 1e-5
+    assert pcd.colors.shape == (ok.sum(), 3) and pcd.colors.min() >= 0 and pcd.colors.max() <= 1
+    # nothing hot enough to hit the object -> red debug rays
+    heat2 = np.zeros_like(heat)
+    heat2[0, 0] = 1.0
+    dbg, _ = ray_tracing(str(tmp_path), mesh_depth, heat2, K, heatmap_threshold=0.75)
+    assert isinstance(dbg, LineSet) and len(dbg.lines) == 1
+
+
+def test_registration_icp_open3d_style_call(oracle):
+    from pedp_hip.compat import (ICPConvergenceCriteria, PointCloud, TransformationEstimationPointToPlane,
+                                 registration_icp)
+
+    g = np.load(os.path.join(GOLD, "g3g4_icp_traces.npz"))
+    src, tgt = PointCloud(g["scene_noisy"]), PointCloud(g["model"], normals=g["normals"])
+    res = registration_icp(src, tgt, 10.0, g["init"], TransformationEstimationPointToPlane(),
+                           ICPConvergenceCriteria(max_iteration=1), want_correspondences=True)
+    ref = oracle.icp(g["scene_noisy"], g["model"], g["normals"], 10.0, g["init"], max_iter=1)
+    assert res.fitness == ref["fitness"] and np.abs(res.transformation - ref["T"]).max() < 1e-5
+    keep = ref["corr"] >= 0
+    assert np.array_equal(res.correspondence_set[:, 0], np.nonzero(keep)[0])
+    assert np.array_equal(res.correspondence_set[:, 1], ref["corr"][keep])
+    with pytest.raises(RuntimeError, match="normals"):
+        registration_icp(src, PointCloud(g["model"]), 10.0, g["init"], TransformationEstimationPointToPlane())
+
+
+def test_improve_result_and_z_search_match_oracle_flow(oracle):
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, improve_result, predict_z_axis_adjustment
+
+    g = np.load(os.path.join(GOLD, "g3g4_icp_traces.npz"))
+    src, tgt = PointCloud(g["scene_clean"]), PointCloud(g["model"], normals=g["normals"])
+    param = {"refine_registration": {"distance_threshold": 8.0}, "run_icp": {"fitness_threshold": 0.999, "rmse_threshold": 0.05}}
+    np.random.seed(0)
+    res = improve_result(src, tgt, synth.start_pose(), param)
+    gold = np.load(os.path.join(GOLD, "g6_improve_result.npz"))
+    assert res.fitness == float(gold["best_fitness"])
+    assert np.abs(res.transformation - gold["best_T"]).max() < 1e-5 and abs(res.inlier_rmse - float(gold["best_rmse"])) < 1e-9
+    assert np.random.uniform() == float(gold["rng_after"])        # same number of restarts, same RNG draws
+    shifted = synth.start_pose()
+    shifted[2, 3] += 12.0
+    got = predict_z_axis_adjustment(src, tgt, shifted, param)
+    ref = oracle.predict_z_axis_adjustment(g["scene_clean"], g["model"], g["normals"], shifted, param)
+    assert got[0] == ref[0] and got[1] == ref[1] and abs(got[2] - ref[2]) < 1e-9
+
+
+def test_refine_pose_with_icp_full_flow(oracle):
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, refine_pose_with_icp
+
+    f = _frame()
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    hit = np.isfinite(depth)
+    scene = synth.scene_from_depth(depth[hit], f.dirs[hit], noise_sigma=0.2)
+    src, tgt = PointCloud(scene), PointCloud(f.model_points, normals=f.normals)
+    params = {"preprocess_target": {"max_pcd": 100000}, "refine_registration": {"distance_threshold": 6.0},
+              "run_icp": {"fitness_threshold": 0.98, "rmse_threshold": 1.0}}
+    init = synth.start_pose()
+    init[2, 3] += 4.0
+    init_ref = init.copy()
+    np.random.seed(7)
+    moved, best, z, _ = refine_pose_with_icp(src, tgt, None, init, params)
+    # oracle flow, same seed
+    np.random.seed(7)
+    z_ref, fit, rmse = oracle.predict_z_axis_adjustment(scene, f.model_points, f.normals, init_ref, params)
+    init_ref[2, 3] += z_ref
+    start = oracle.Result(init_ref, fit, rmse)
+    best_ref = oracle.improve_result(scene, f.model_points, f.normals, start, params)
+    assert z == z_ref and best.fitness == best_ref.fitness
+    assert np.abs(best.transformation - best_ref.transformation).max() < 1e-5
+    assert np.array_equal(init, init_ref)                       # caller's matrix mutated the same way
+    err = np.abs(np.linalg.inv(best.transformation) - f.T_gt).max()
+    assert err < 0.5                                            # and it actually refines towards the truth (mm)
