@@ -82,6 +82,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_keys.release();
     c->ray_in.release();
     c->ray_out.release();
+    c->ray_aux.release();
     c->icp_ws.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

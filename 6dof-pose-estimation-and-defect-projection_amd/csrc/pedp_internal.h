@@ -44,6 +44,7 @@ struct pedp_ctx_s {
     pedp_scratch ray_keys;   // N x u64 packed (t_bits << 32 | prim_id)
     pedp_scratch ray_in;     // staging for host-memory calls
     pedp_scratch ray_out;
+    pedp_scratch ray_aux;    // shared-origin flag + per-call shared-origin pair records
     int ray_tri_chunks = 0;  // 0 = auto
     int ray_variant = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // sweep timing
@@ -64,6 +65,7 @@ struct pedp_mesh_s {
     pedp_ctx_t ctx = nullptr;
     int64_t V = 0, F = 0;
     float *tri = nullptr;  // F_padded x PEDP_TRI_STRIDE floats on the device
+    float *tri2 = nullptr; // F_padded/2 pair-interleaved general-origin records (18 floats each)
     int64_t F_padded = 0;  // multiple of 8; pad records can never be hit (all zero => det == 0)
 };
 

@@ -2,29 +2,46 @@
 //
 // Replaces RaycastingScene.add_triangles + cast_rays as called by
 // src/defect_projection.py:245-256 (one camera ray per heat-map pixel against every
-// triangle of the posed mesh).  Arithmetic contract: oracle/ray.c (Moeller-Trumbore,
-// division-deferred, every operation one fp32 rounding in a fixed order) -- results are
-// bit-identical to it: t_hit, primitive ids and (u, v).
+// triangle of the posed mesh).  Arithmetic contract: oracle/ray.c -- Moeller-Trumbore in
+// scalar-triple-product form, division deferred to accepted hits, every operation one fp32
+// rounding in a fixed order.  Results are bit-identical to it: t_hit, primitive ids, (u, v).
 //
-// Mapping (ray-per-lane variant): one ray per lane, its origin/direction in VGPRs for
-// the whole sweep.  The triangle index is wave-uniform, so a triangle record is fetched
-// with scalar loads (s_load_dwordx8 + x4 of a 48-B record) and feeds the VALU as SGPR
-// operands: the scalar cache is the broadcast, no LDS traffic and no VGPRs are spent on
-// triangle data.  The grid is (ray blocks) x (triangle chunks); chunk c is always served
-// by workgroups with blockIdx % 8 == c % 8, i.e. by one XCD, so each XCD's L2 only ever
-// holds its own 1/8 of the triangle buffer.  Partial results meet in one packed
-// 64-bit atomicMin per ray and chunk: key = (bits(t) << 32) | triangle id, which orders
-// by t (t >= 0, so IEEE bits are monotone) and then by triangle index -- exactly the
-// oracle's tie rule, independent of execution order.
+//   per triangle:  e1 = v1 - v0, e2 = v2 - v0, m = e2 x e1
+//   per test:      det = d . m ; s = o - v0 ; un = d . (e2 x s) ; vn = d . (s x e1) ; tn = -(s . m)
 //
-// Variant 2 (triangle-per-lane) is for few rays against a big mesh: lanes own
-// consecutive triangles (coalesced 16-B loads of the record buffer), the ray is
-// wave-uniform, and the packed key is min-reduced across the 64 lanes with DPP/shuffles.
+// Variant 1, ray per lane (default).  One ray per lane, origin/direction in VGPRs for the
+// whole sweep.  The triangle index is wave-uniform, so records are fetched with SCALAR loads
+// and feed the VALU as SGPR operands (the scalar cache is the broadcast: no LDS traffic, no
+// VGPRs for triangle data).  Two triangles ride in the two halves of every packed fp32
+// instruction (v_pk_mul_f32 / v_pk_fma_f32 deliver 1.54x the flops per issue slot of the
+// scalar forms on this chip, tools/microbench_valu.hip): records are stored
+// pair-interleaved so one aligned SGPR pair = (A.x, B.x) = one packed operand.
+//   * general origins: 12 x 2 floats per pair (v0, e1, e2, m), 24 arithmetic ops per test;
+//   * all rays share one origin (always true for the reference, defect_projection.py:545):
+//     the origin-dependent terms e2 x s, s x e1, s . m are evaluated once per triangle by
+//     pair_shared_kernel with the very same operations, leaving 3 dot products per test
+//     (10 x 2 floats per pair).  A device-side flag selects the path, no host round trip.
+// The hot loop only decides "inside the triangle?" with a branch-free score
+//     min3(un*det, vn*det, |det| - |un+vn|) >= 0
+// which is a superset of the oracle's accept set (products keep the sign, underflow gives
+// +-0 which passes); the division, tn, and the 64-bit min sit on a rarely taken wave-level
+// branch that applies the oracle's exact predicate.
+// Grid = (ray blocks) x (triangle chunks); chunk c is always served by workgroups with
+// blockIdx % 8 == c % 8, i.e. one XCD, so each XCD's L2 only holds its part of the records.
+// Partial results meet in one packed 64-bit atomicMin per ray and chunk:
+// key = (bits(t) << 32) | triangle id orders by t (t >= 0: IEEE bits are monotone), then by
+// triangle index -- the oracle's tie rule, independent of execution order.
+//
+// Variant 2, triangle per lane: few rays against a big mesh.  Lanes own consecutive
+// triangles (coalesced 16-B loads of the AoS records), 4 wave-uniform rays per wave, and the
+// packed key is min-reduced across the 64 lanes: the wavefront-wide min-t reduction.
 #include "pedp_internal.h"
+#include <new>
 
 namespace {
 
 constexpr unsigned long long KEY_MISS = 0xFFFFFFFFFFFFFFFFull;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float mulr(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fmar(float a, float b, float c) { return __fmaf_rn(a, b, c); }
@@ -43,46 +60,33 @@ struct MT {
     float det, un, vn, tn;
 };
 
-// The oracle's operation order (oracle/ray.c header comment), verbatim.
-__device__ __forceinline__ MT mt_eval(const Ray &r, float v0x, float v0y, float v0z, float e1x,
-                                      float e1y, float e1z, float e2x, float e2y, float e2z) {
+// The oracle's operation order (oracle/ray.c header comment), verbatim.  rec = 12 floats.
+__device__ __forceinline__ MT mt_eval(const Ray &r, const float *rec) {
+    const float v0x = rec[0], v0y = rec[1], v0z = rec[2], e1x = rec[3], e1y = rec[4], e1z = rec[5];
+    const float e2x = rec[6], e2y = rec[7], e2z = rec[8], mx = rec[9], my = rec[10], mz = rec[11];
     MT m;
-    float px = fmar(r.dy, e2z, -mulr(r.dz, e2y));
-    float py = fmar(r.dz, e2x, -mulr(r.dx, e2z));
-    float pz = fmar(r.dx, e2y, -mulr(r.dy, e2x));
-    m.det = dot3(e1x, e1y, e1z, px, py, pz);
-    float sx = subr(r.ox, v0x), sy = subr(r.oy, v0y), sz = subr(r.oz, v0z);
-    m.un = dot3(sx, sy, sz, px, py, pz);
-    float qx = fmar(sy, e1z, -mulr(sz, e1y));
-    float qy = fmar(sz, e1x, -mulr(sx, e1z));
-    float qz = fmar(sx, e1y, -mulr(sy, e1x));
-    m.vn = dot3(r.dx, r.dy, r.dz, qx, qy, qz);
-    m.tn = dot3(e2x, e2y, e2z, qx, qy, qz);
+    m.det = dot3(r.dx, r.dy, r.dz, mx, my, mz);
+    const float sx = subr(r.ox, v0x), sy = subr(r.oy, v0y), sz = subr(r.oz, v0z);
+    const float ax = fmar(e2y, sz, -mulr(e2z, sy));  // a = e2 x s
+    const float ay = fmar(e2z, sx, -mulr(e2x, sz));
+    const float az = fmar(e2x, sy, -mulr(e2y, sx));
+    m.un = dot3(r.dx, r.dy, r.dz, ax, ay, az);
+    const float bx = fmar(sy, e1z, -mulr(sz, e1y));  // b = s x e1
+    const float by = fmar(sz, e1x, -mulr(sx, e1z));
+    const float bz = fmar(sx, e1y, -mulr(sy, e1x));
+    m.vn = dot3(r.dx, r.dy, r.dz, bx, by, bz);
+    m.tn = -dot3(sx, sy, sz, mx, my, mz);
     return m;
 }
 
-// Exact acceptance predicate of the oracle (det != 0 is checked next to it).
-__device__ __forceinline__ bool mt_pass(const MT &m) {
+// Exact acceptance predicate of the oracle.
+__device__ __forceinline__ bool mt_accept(const MT &m) {
     unsigned sg = __float_as_uint(m.det) & 0x80000000u;
     float U = __uint_as_float(__float_as_uint(m.un) ^ sg);
     float V = __uint_as_float(__float_as_uint(m.vn) ^ sg);
     float T = __uint_as_float(__float_as_uint(m.tn) ^ sg);
     float W = addr(U, V);
-    return (U >= 0.0f) & (V >= 0.0f) & (T >= 0.0f) & (W <= fabsf(m.det));
-}
-
-// Branch-free score for the hot loop: score >= 0 <=> mt_pass for all non-NaN operands.
-// With s = sign(det): U,V,T >= 0 <=> min3(un,vn,tn) >= 0 (s > 0) or max3(un,vn,tn) <= 0
-// (s < 0); U + V == (un + vn)^s exactly, so once U,V >= 0 holds, U + V <= |det| <=>
-// fl(|det| - |un + vn|) >= 0 (a difference has the sign of the exact difference).  With
-// a NaN operand the score may pass where mt_pass does not, never the other way round:
-// the accept path re-applies mt_pass, so the score only has to be a superset.
-__device__ __forceinline__ float mt_score(const MT &m) {
-    float lo = fminf(fminf(m.un, m.vn), m.tn);
-    float hi = fmaxf(fmaxf(m.un, m.vn), m.tn);
-    float sd = (__float_as_int(m.det) < 0) ? -hi : lo;
-    float R = subr(fabsf(m.det), fabsf(addr(m.un, m.vn)));
-    return fminf(sd, R);
+    return (m.det != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (T >= 0.0f) & (W <= fabsf(m.det));
 }
 
 __device__ __forceinline__ unsigned long long mt_key(const MT &m, unsigned id) {
@@ -107,68 +111,153 @@ __global__ void tri_setup_kernel(const float *__restrict__ verts, const uint32_t
     const float *a = verts + 3 * (int64_t)tris[3 * f + 0];
     const float *b = verts + 3 * (int64_t)tris[3 * f + 1];
     const float *c = verts + 3 * (int64_t)tris[3 * f + 2];
+    float e1[3], e2[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        e1[k] = subr(b[k], a[k]);
+        e2[k] = subr(c[k], a[k]);
         r[k] = a[k];
-        r[3 + k] = subr(b[k], a[k]);
-        r[6 + k] = subr(c[k], a[k]);
+        r[3 + k] = e1[k];
+        r[6 + k] = e2[k];
     }
-    r[9] = r[10] = r[11] = 0.0f;
+    r[9] = fmar(e2[1], e1[2], -mulr(e2[2], e1[1]));  // m = e2 x e1
+    r[10] = fmar(e2[2], e1[0], -mulr(e2[0], e1[2]));
+    r[11] = fmar(e2[0], e1[1], -mulr(e2[1], e1[0]));
 }
 
-// ------------------------------------------------------------------ sweep, ray per lane
-constexpr int RPL_BLOCK = 256;
-constexpr int RPL_UNROLL = 4;
+// ------------------------------------------------------------------ pair-interleaved records
+constexpr int PAIR_GEN = 24;  // floats per pair record, general origin: v0 e1 e2 m
+constexpr int PAIR_SH = 20;   // floats per pair record, shared origin:  m a b tn
 
+__global__ void pair_general_kernel(const float *__restrict__ aos, int64_t F_padded, float *__restrict__ out) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F_padded) return;
+    const float *r = aos + f * PEDP_TRI_STRIDE;
+    float *o = out + (f >> 1) * PAIR_GEN + (f & 1);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[2 * k] = r[k];
+}
+
+// origin-dependent terms for o = origin of ray 0, in the oracle's own operations
+__global__ void pair_shared_kernel(const float *__restrict__ aos, int64_t F_padded, const float *__restrict__ rays6,
+                                   const int *__restrict__ shared_flag, float *__restrict__ out) {
+    if (*shared_flag == 0) return;
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F_padded) return;
+    const float *r = aos + f * PEDP_TRI_STRIDE;
+    const float e1x = r[3], e1y = r[4], e1z = r[5], e2x = r[6], e2y = r[7], e2z = r[8];
+    const float mx = r[9], my = r[10], mz = r[11];
+    const float sx = subr(rays6[0], r[0]), sy = subr(rays6[1], r[1]), sz = subr(rays6[2], r[2]);
+    const float ax = fmar(e2y, sz, -mulr(e2z, sy));
+    const float ay = fmar(e2z, sx, -mulr(e2x, sz));
+    const float az = fmar(e2x, sy, -mulr(e2y, sx));
+    const float bx = fmar(sy, e1z, -mulr(sz, e1y));
+    const float by = fmar(sz, e1x, -mulr(sx, e1z));
+    const float bz = fmar(sx, e1y, -mulr(sy, e1x));
+    const float tn = -dot3(sx, sy, sz, mx, my, mz);
+    const float v[10] = {mx, my, mz, ax, ay, az, bx, by, bz, tn};
+    float *o = out + (f >> 1) * PAIR_SH + (f & 1);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) o[2 * k] = v[k];
+}
+
+// all ray origins bit-identical to ray 0's?  flag preset to non-zero, cleared on a mismatch
+__global__ void origin_check_kernel(const float *__restrict__ rays6, int64_t N, int *__restrict__ flag) {
+    const unsigned ox = __float_as_uint(rays6[0]), oy = __float_as_uint(rays6[1]), oz = __float_as_uint(rays6[2]);
+    bool same = true;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        same = same && (__float_as_uint(rays6[6 * i]) == ox) && (__float_as_uint(rays6[6 * i + 1]) == oy) &&
+               (__float_as_uint(rays6[6 * i + 2]) == oz);
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
+// ------------------------------------------------------------------ sweep, ray per lane (packed)
+__device__ __forceinline__ f2 splat(float a) { return (f2){a, a}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 dot3p(f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz) {
+    return fma2(az, bz, fma2(ay, by, ax * bx));
+}
+
+struct MT2 {  // det, un, vn of the two triangles of a pair
+    f2 det, un, vn;
+};
+
+__device__ __forceinline__ MT2 eval_pair_general(const Ray &r, const f2 *t) {
+    const f2 v0x = t[0], v0y = t[1], v0z = t[2], e1x = t[3], e1y = t[4], e1z = t[5];
+    const f2 e2x = t[6], e2y = t[7], e2z = t[8], mx = t[9], my = t[10], mz = t[11];
+    const f2 dx = splat(r.dx), dy = splat(r.dy), dz = splat(r.dz);
+    MT2 m;
+    m.det = dot3p(dx, dy, dz, mx, my, mz);
+    const f2 sx = splat(r.ox) - v0x, sy = splat(r.oy) - v0y, sz = splat(r.oz) - v0z;
+    const f2 ax = fma2(e2y, sz, -(e2z * sy));
+    const f2 ay = fma2(e2z, sx, -(e2x * sz));
+    const f2 az = fma2(e2x, sy, -(e2y * sx));
+    m.un = dot3p(dx, dy, dz, ax, ay, az);
+    const f2 bx = fma2(sy, e1z, -(sz * e1y));
+    const f2 by = fma2(sz, e1x, -(sx * e1z));
+    const f2 bz = fma2(sx, e1y, -(sy * e1x));
+    m.vn = dot3p(dx, dy, dz, bx, by, bz);
+    return m;
+}
+
+__device__ __forceinline__ MT2 eval_pair_shared(const Ray &r, const f2 *t) {
+    const f2 dx = splat(r.dx), dy = splat(r.dy), dz = splat(r.dz);
+    MT2 m;
+    m.det = dot3p(dx, dy, dz, t[0], t[1], t[2]);
+    m.un = dot3p(dx, dy, dz, t[3], t[4], t[5]);
+    m.vn = dot3p(dx, dy, dz, t[6], t[7], t[8]);
+    return m;
+}
+
+// "inside the triangle" score of both halves; >= 0 is a superset of the oracle's accept set
+__device__ __forceinline__ f2 inside_score(const MT2 &m) {
+    const f2 a = m.un * m.det, b = m.vn * m.det, w = m.un + m.vn;
+    f2 s;
+    s.x = fminf(fminf(a.x, b.x), subr(fabsf(m.det.x), fabsf(w.x)));
+    s.y = fminf(fminf(a.y, b.y), subr(fabsf(m.det.y), fabsf(w.y)));
+    return s;
+}
+
+constexpr int RPL_BLOCK = 256;
+constexpr int RPL_PAIRS = 2;  // pair records per loop iteration (4 triangles)
+
+// The two instantiations are launched back to back; the device flag lets exactly one work.
+template <bool SHARED>
 __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
-    const float4 *__restrict__ tri, int groups_total, int groups_per_chunk, int n_chunks,
-    const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys) {
+    const f2 *__restrict__ rec, const float *__restrict__ aos, int groups_total, int groups_per_chunk, int n_chunks,
+    const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys,
+    const int *__restrict__ shared_flag) {
+    if ((*shared_flag != 0) != SHARED) return;
+    constexpr int PF = (SHARED ? PAIR_SH : PAIR_GEN) / 2;  // f2 per pair record
     const int b = blockIdx.x;
-    const int chunk = b % n_chunks;  // n_chunks % 8 == 0, so chunk % 8 == b % 8: one XCD per chunk
+    const int chunk = b % n_chunks;  // n_chunks % 8 == 0: chunk % 8 == b % 8, one XCD per chunk
     const int64_t rb = b / n_chunks;
     const int64_t ray = rb * RPL_BLOCK + threadIdx.x;
     const int64_t rl = ray < N ? ray : N - 1;  // tail lanes re-run the last ray, never store
     Ray r;
     r.ox = rays6[6 * rl + 0]; r.oy = rays6[6 * rl + 1]; r.oz = rays6[6 * rl + 2];
     r.dx = rays6[6 * rl + 3]; r.dy = rays6[6 * rl + 4]; r.dz = rays6[6 * rl + 5];
-
     int g0 = chunk * groups_per_chunk;
     int g1 = g0 + groups_per_chunk;
     if (g1 > groups_total) g1 = groups_total;
     unsigned long long best = KEY_MISS;
-    if (g0 < g1) {
-        // Software pipeline: the records of group g+1 are requested (scalar loads into
-        // SGPRs) before group g is evaluated, so the scalar-cache latency hides behind
-        // ~4 x 35 VALU instructions.  The accept path (division, 64-bit min) is rare:
-        // one wave-level branch per group.
-        float4 cur[RPL_UNROLL * 3], nxt[RPL_UNROLL * 3];
-        {
-            const float4 *t = tri + (size_t)g0 * (RPL_UNROLL * 3);
+    for (int g = g0; g < g1; ++g) {
+        const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
+        f2 sc[RPL_PAIRS];
 #pragma unroll
-            for (int k = 0; k < RPL_UNROLL * 3; ++k) nxt[k] = t[k];
-        }
-        for (int g = g0; g < g1; ++g) {
+        for (int p = 0; p < RPL_PAIRS; ++p)
+            sc[p] = inside_score(SHARED ? eval_pair_shared(r, t + p * PF) : eval_pair_general(r, t + p * PF));
+        static_assert(RPL_PAIRS == 2, "score reduction below is written for 2 pairs");
+        const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
+        if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {  // wave-uniform, rarely taken
+            const int f0 = g * (2 * RPL_PAIRS);
 #pragma unroll
-            for (int k = 0; k < RPL_UNROLL * 3; ++k) cur[k] = nxt[k];
-            {
-                int gn = g + 1 < g1 ? g + 1 : g;
-                const float4 *t = tri + (size_t)gn * (RPL_UNROLL * 3);
-#pragma unroll
-                for (int k = 0; k < RPL_UNROLL * 3; ++k) nxt[k] = t[k];
-            }
-            MT m[RPL_UNROLL];
-#pragma unroll
-            for (int k = 0; k < RPL_UNROLL; ++k) {
-                float4 a = cur[3 * k + 0], bq = cur[3 * k + 1], c = cur[3 * k + 2];
-                m[k] = mt_eval(r, a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x);
-            }
-            static_assert(RPL_UNROLL == 4, "accept test below is written for 4 records");
-            const float sc = fmaxf(fmaxf(mt_score(m[0]), mt_score(m[1])), fmaxf(mt_score(m[2]), mt_score(m[3])));
-            if (__builtin_amdgcn_ballot_w64(sc >= 0.0f) != 0) {  // wave-uniform, rarely taken
-#pragma unroll
-                for (int k = 0; k < RPL_UNROLL; ++k) {
-                    if (mt_pass(m[k]) && m[k].det != 0.0f) {
-                        unsigned long long key = mt_key(m[k], (unsigned)(g * RPL_UNROLL + k));
+            for (int k = 0; k < 2 * RPL_PAIRS; ++k) {
+                const float s = (k & 1) ? sc[k >> 1].y : sc[k >> 1].x;
+                if (s >= 0.0f) {
+                    MT m = mt_eval(r, aos + (size_t)(f0 + k) * PEDP_TRI_STRIDE);  // exact, from the AoS record
+                    if (mt_accept(m)) {
+                        unsigned long long key = mt_key(m, (unsigned)(f0 + k));
                         best = key < best ? key : best;
                     }
                 }
@@ -179,8 +268,6 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
 }
 
 // ------------------------------------------------------------------ sweep, triangle per lane
-// One workgroup = 4 waves; each wave takes TPL_RAYS wave-uniform rays and strides over a
-// triangle chunk with lanes on consecutive triangles.
 constexpr int TPL_BLOCK = 256;
 constexpr int TPL_RAYS = 4;
 
@@ -199,7 +286,7 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
     const float4 *__restrict__ tri, int64_t F_padded, int tris_per_chunk, int n_chunks,
     const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys) {
     const int b = blockIdx.x;
-    const int chunk = b % n_chunks;  // n_chunks % 8 == 0, so chunk % 8 == b % 8: one XCD per chunk
+    const int chunk = b % n_chunks;
     const int64_t rb = b / n_chunks;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray0 = (rb * (TPL_BLOCK / 64) + wave) * TPL_RAYS;
@@ -207,8 +294,7 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
     Ray r[TPL_RAYS];
 #pragma unroll
     for (int k = 0; k < TPL_RAYS; ++k) {
-        int64_t rl = ray0 + k < N ? ray0 + k : N - 1;
-        // wave-uniform address: the compiler keeps these in SGPRs
+        int64_t rl = ray0 + k < N ? ray0 + k : N - 1;  // wave-uniform address: stays in SGPRs
         r[k].ox = rays6[6 * rl + 0]; r[k].oy = rays6[6 * rl + 1]; r[k].oz = rays6[6 * rl + 2];
         r[k].dx = rays6[6 * rl + 3]; r[k].dy = rays6[6 * rl + 4]; r[k].dz = rays6[6 * rl + 5];
     }
@@ -219,11 +305,12 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
     int64_t f1 = f0 + tris_per_chunk;
     if (f1 > F_padded) f1 = F_padded;
     for (int64_t f = f0 + lane; f < f1; f += 64) {
-        float4 a = tri[3 * f + 0], bq = tri[3 * f + 1], c = tri[3 * f + 2];
+        const float4 a = tri[3 * f + 0], bq = tri[3 * f + 1], c = tri[3 * f + 2];
+        const float rec[12] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int k = 0; k < TPL_RAYS; ++k) {
-            MT m = mt_eval(r[k], a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x);
-            if (mt_pass(m) && m.det != 0.0f) {
+            MT m = mt_eval(r[k], rec);
+            if (mt_accept(m)) {
                 unsigned long long key = mt_key(m, (unsigned)f);
                 best[k] = key < best[k] ? key : best[k];
             }
@@ -237,7 +324,7 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
 }
 
 // ------------------------------------------------------------------ finalize
-__global__ void ray_finalize_kernel(const float4 *__restrict__ tri, const float *__restrict__ rays6,
+__global__ void ray_finalize_kernel(const float *__restrict__ aos, const float *__restrict__ rays6,
                                     int64_t N, const unsigned long long *__restrict__ keys,
                                     float *__restrict__ t_hit, uint32_t *__restrict__ prim_id,
                                     float *__restrict__ uv) {
@@ -257,8 +344,7 @@ __global__ void ray_finalize_kernel(const float4 *__restrict__ tri, const float 
         Ray r;
         r.ox = rays6[6 * i + 0]; r.oy = rays6[6 * i + 1]; r.oz = rays6[6 * i + 2];
         r.dx = rays6[6 * i + 3]; r.dy = rays6[6 * i + 4]; r.dz = rays6[6 * i + 5];
-        float4 a = tri[3 * (size_t)id + 0], bq = tri[3 * (size_t)id + 1], c = tri[3 * (size_t)id + 2];
-        MT m = mt_eval(r, a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x);
+        MT m = mt_eval(r, aos + (size_t)id * PEDP_TRI_STRIDE);
         unsigned sg = __float_as_uint(m.det) & 0x80000000u;
         float U = __uint_as_float(__float_as_uint(m.un) ^ sg);
         float V = __uint_as_float(__float_as_uint(m.vn) ^ sg);
@@ -292,6 +378,7 @@ int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t
     float *d_verts = nullptr;
     uint32_t *d_tris = nullptr;
     hipError_t e = hipMalloc((void **)&m->tri, sizeof(float) * PEDP_TRI_STRIDE * (size_t)m->F_padded);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->tri2, sizeof(float) * PAIR_GEN * (size_t)(m->F_padded / 2));
     if (e == hipSuccess) e = hipMalloc((void **)&d_verts, sizeof(float) * 3 * (size_t)(V ? V : 1));
     if (e == hipSuccess) e = hipMalloc((void **)&d_tris, sizeof(uint32_t) * 3 * (size_t)(F ? F : 1));
     if (e == hipSuccess && V) e = hipMemcpyAsync(d_verts, verts, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream);
@@ -300,6 +387,7 @@ int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t
         int grid = (int)((m->F_padded + 255) / 256);
         hipLaunchKernelGGL(tri_setup_kernel, dim3(grid), dim3(256), 0, c->stream, d_verts, d_tris, F,
                            m->F_padded, m->tri);
+        hipLaunchKernelGGL(pair_general_kernel, dim3(grid), dim3(256), 0, c->stream, m->tri, m->F_padded, m->tri2);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -318,6 +406,7 @@ void pedp_mesh_destroy(pedp_mesh_t m) {
     if (!m) return;
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->tri) (void)hipFree(m->tri);
+    if (m->tri2) (void)hipFree(m->tri2);
     delete m;
 }
 
@@ -368,11 +457,17 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
 
     int variant = c->ray_variant;
     if (variant == 0) variant = (N < 16384) ? 2 : 1;
-    const float4 *tri = (const float4 *)mesh->tri;
-    PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     if (variant == 1) {
+        st = c->ray_aux.reserve(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2) + 256);
+        if (st) return st;
+        int *flag = (int *)c->ray_aux.ptr;
+        float *tri3 = (float *)((char *)c->ray_aux.ptr + 256);
+        PEDP_HIP_CHECK(hipMemsetAsync(flag, 0xFF, sizeof(int), c->stream));
+        hipLaunchKernelGGL(origin_check_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag);
+        hipLaunchKernelGGL(pair_shared_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream,
+                           mesh->tri, mesh->F_padded, d_rays, flag, tri3);
         int64_t ray_blocks = (N + RPL_BLOCK - 1) / RPL_BLOCK;
-        int groups_total = (int)(mesh->F_padded / RPL_UNROLL);
+        int groups_total = (int)(mesh->F_padded / (2 * RPL_PAIRS));
         int n_chunks = c->ray_tri_chunks;
         if (n_chunks == 0) {
             // enough workgroups for >= 4 rounds over the chip, triangle chunks not below 2k
@@ -382,8 +477,11 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         int gpc = (groups_total + n_chunks - 1) / n_chunks;
         int64_t grid = ray_blocks * n_chunks;
         PEDP_REQUIRE(grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
-        hipLaunchKernelGGL(ray_sweep_rpl_kernel, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream, tri,
-                           groups_total, gpc, n_chunks, d_rays, N, keys);
+        PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(ray_sweep_rpl_kernel<true>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
+                           (const f2 *)tri3, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
+        hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
+                           (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
     } else {
         int64_t rays_per_block = (TPL_BLOCK / 64) * TPL_RAYS;
         int64_t ray_blocks = (N + rays_per_block - 1) / rays_per_block;
@@ -396,15 +494,16 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         tpc = ((tpc + 63) / 64) * 64;
         int64_t grid = ray_blocks * n_chunks;
         PEDP_REQUIRE(grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
-        hipLaunchKernelGGL(ray_sweep_tpl_kernel, dim3((unsigned)grid), dim3(TPL_BLOCK), 0, c->stream, tri,
-                           mesh->F_padded, tpc, n_chunks, d_rays, N, keys);
+        PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(ray_sweep_tpl_kernel, dim3((unsigned)grid), dim3(TPL_BLOCK), 0, c->stream,
+                           (const float4 *)mesh->tri, mesh->F_padded, tpc, n_chunks, d_rays, N, keys);
     }
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     c->ray_timed = true;
     {
         int64_t grid = (N + 255) / 256;
-        hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tri, d_rays, N,
+        hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
                            keys, d_t, d_id, d_uv);
         PEDP_HIP_CHECK(hipGetLastError());
     }

@@ -25,15 +25,16 @@ extern "C" {
 
 /* ---- ray casting (float32; defect_projection.py:245-264) ---- */
 
-/* Per-triangle record (v0, e1 = v1 - v0, e2 = v2 - v0), 9 floats, computed in fp32
- * exactly like TriangleMesh.from_legacy + add_triangles would hand fp32 vertices to
- * the ray caster (defect_projection.py:245, :253-254). */
+/* Per-triangle record (v0, e1 = v1 - v0, e2 = v2 - v0, m = e2 x e1), PEDP_ORACLE_TRI = 12
+ * floats, computed in fp32 from the fp32 vertices TriangleMesh.from_legacy + add_triangles
+ * would hand to the ray caster (defect_projection.py:245, :253-254). */
+#define PEDP_ORACLE_TRI 12
 void pedp_oracle_tri_setup(const float *verts, int64_t V, const uint32_t *tris,
                            int64_t F, float *tri9);
 
 /* One Moeller-Trumbore test in the oracle's fixed operation order.  Returns 1 on
  * hit and writes t,u,v; 0 on miss. */
-int pedp_oracle_mt_test(const float o[3], const float d[3], const float tri9[9],
+int pedp_oracle_mt_test(const float o[3], const float d[3], const float *tri12,
                         float *t, float *u, float *v);
 
 /* Closest hit of every ray against every triangle (brute force).  rays6 is N x

@@ -52,7 +52,7 @@ def _p(a):
 def tri_setup(verts, tris):
     v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
     t = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
-    out = np.empty((len(t), 9), np.float32)
+    out = np.empty((len(t), 12), np.float32)   # v0, e1, e2, m = e2 x e1
     lib().pedp_oracle_tri_setup(_p(v), C.c_int64(len(v)), _p(t), C.c_int64(len(t)), _p(out))
     return out
 

@@ -12,16 +12,23 @@
  * hit), every operation a single fp32 rounding in the order written below.
  * Compile with -ffp-contract=off: fmaf() appears exactly where an FMA is meant.
  *
- *   p  = d x e2          p.x = fma(d.y, e2.z, -(d.z*e2.y)) ... (cyclic)
- *   det = e1 . p         dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
- *   s  = o - v0
- *   un = s . p
- *   q  = s x e1
- *   vn = d . q
- *   tn = e2 . q
+ *   per triangle (once):  e1 = v1 - v0,  e2 = v2 - v0,  m = e2 x e1
+ *       cross(a,b).x = fma(a.y, b.z, -(a.z*b.y)) ... (cyclic)
+ *   per ray/triangle test, scalar-triple-product form of Moeller-Trumbore
+ *       dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ *   det = d . m                      ( = e1 . (d x e2) )
+ *   s   = o - v0
+ *   un  = d . (e2 x s)               ( = s . (d x e2) )
+ *   vn  = d . (s x e1)
+ *   tn  = -(s . m)                   ( = e2 . (s x e1) )
  *   sg = signbit(det);  ad = |det|;  U = un^sg; V = vn^sg; T = tn^sg
  *   hit  <=>  det != 0  &&  U >= 0  &&  V >= 0  &&  (U+V) <= ad  &&  T >= 0
  *   t = |T / ad|,  u = U / ad,  v = V / ad          (IEEE division)
+ * This form is chosen because everything that depends on the ray ORIGIN (s, e2 x s, s x e1,
+ * s . m) is independent of the ray direction: for the reference's rays, which all start at
+ * one camera centre (defect_projection.py:545, :248), a GPU kernel may evaluate those terms
+ * once per triangle with the very same operations and be left with three dot products per
+ * test -- bit-identical to this per-test evaluation.
  * tnear = 0 inclusive, tfar = +inf, no back-face culling, inclusive edges.
  * Closest hit; ties: smaller t, then smaller triangle index.
  */
@@ -53,28 +60,29 @@ void pedp_oracle_tri_setup(const float *verts, int64_t V, const uint32_t *tris, 
         const float *a = verts + 3 * (int64_t)tris[3 * f + 0];
         const float *b = verts + 3 * (int64_t)tris[3 * f + 1];
         const float *c = verts + 3 * (int64_t)tris[3 * f + 2];
-        float *r = tri9 + 9 * f;
+        float *r = tri9 + PEDP_ORACLE_TRI * f;
         for (int k = 0; k < 3; ++k) {
             r[k] = a[k];
             r[3 + k] = b[k] - a[k];
             r[6 + k] = c[k] - a[k];
         }
+        cross3(r + 6, r + 3, r + 9); /* m = e2 x e1 */
     }
 }
 
-int pedp_oracle_mt_test(const float o[3], const float d[3], const float tri9[9], float *t,
+int pedp_oracle_mt_test(const float o[3], const float d[3], const float *tri, float *t,
                         float *u, float *v) {
-    const float *v0 = tri9, *e1 = tri9 + 3, *e2 = tri9 + 6;
-    float p[3], s[3], q[3];
-    cross3(d, e2, p);
-    float det = dot3(e1, p);
+    const float *v0 = tri, *e1 = tri + 3, *e2 = tri + 6, *m = tri + 9;
+    float s[3], a[3], b[3];
+    float det = dot3(d, m);
     s[0] = o[0] - v0[0];
     s[1] = o[1] - v0[1];
     s[2] = o[2] - v0[2];
-    float un = dot3(s, p);
-    cross3(s, e1, q);
-    float vn = dot3(d, q);
-    float tn = dot3(e2, q);
+    cross3(e2, s, a);
+    float un = dot3(d, a);
+    cross3(s, e1, b);
+    float vn = dot3(d, b);
+    float tn = -dot3(s, m);
     uint32_t sg = f2u(det) & 0x80000000u;
     float ad = u2f(f2u(det) & 0x7FFFFFFFu);
     float U = u2f(f2u(un) ^ sg), Vv = u2f(f2u(vn) ^ sg), T = u2f(f2u(tn) ^ sg);
@@ -96,7 +104,7 @@ static inline void cast_one_brute(const float *tri9, int64_t F, const float *ray
     uint32_t bi = 0xFFFFFFFFu;
     for (int64_t f = 0; f < F; ++f) {
         float t, u, v;
-        if (pedp_oracle_mt_test(ray, ray + 3, tri9 + 9 * f, &t, &u, &v)) {
+        if (pedp_oracle_mt_test(ray, ray + 3, tri9 + PEDP_ORACLE_TRI * f, &t, &u, &v)) {
             if (t < bt || (t == bt && (uint32_t)f < bi)) {
                 bt = t; bi = (uint32_t)f; bu = u; bv = v;
             }
@@ -199,7 +207,7 @@ static int bvh_build(bvh_t *b, const float *tri9, int64_t F) {
     if (!b->nodes || !b->prim || !b->cent || !b->blo || !b->bhi) return -1;
     for (int64_t f = 0; f < F; ++f) {
         b->prim[f] = (int32_t)f;
-        tri_bounds(tri9 + 9 * f, b->blo + 3 * f, b->bhi + 3 * f);
+        tri_bounds(tri9 + PEDP_ORACLE_TRI * f, b->blo + 3 * f, b->bhi + 3 * f);
         for (int k = 0; k < 3; ++k) b->cent[3 * f + k] = 0.5f * (b->blo[3 * f + k] + b->bhi[3 * f + k]);
     }
     b->n_nodes = 1;
@@ -246,7 +254,7 @@ static void cast_one_bvh(const bvh_t *b, const float *tri9, const float *ray, fl
             for (int32_t i = nd->left; i < nd->left + nd->count; ++i) {
                 uint32_t f = (uint32_t)b->prim[i];
                 float t, u, v;
-                if (pedp_oracle_mt_test(ray, ray + 3, tri9 + 9 * (int64_t)f, &t, &u, &v)) {
+                if (pedp_oracle_mt_test(ray, ray + 3, tri9 + PEDP_ORACLE_TRI * (int64_t)f, &t, &u, &v)) {
                     if (t < bt || (t == bt && f < bi)) { bt = t; bi = f; bu = u; bv = v; }
                 }
             }

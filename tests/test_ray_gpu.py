@@ -13,7 +13,7 @@ def _same(res, ref):
 
 
 @pytest.mark.parametrize("config", ["tiny", "parity"])
-@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 32), (2, 0), (2, 16)])
+@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 64), (2, 0), (2, 16)])
 def test_frame_bit_exact(ctx, oracle, config, variant, chunks):
     from pedp_hip import _lib, synth
 
@@ -112,6 +112,27 @@ def test_tie_takes_lowest_triangle_index(ctx, oracle):
         assert (r["primitive_ids"] == pad).all() and (r["t_hit"] == 5.0).all()
         ref = oracle.raycast(v, t, rays)
         assert np.array_equal(r["primitive_ids"], ref["primitive_ids"])
+
+
+def test_shared_and_mixed_origins_same_bits(ctx, oracle):
+    """The shared-origin fast path (origin-dependent terms hoisted per triangle) and the
+    general path give identical bits; one differing origin anywhere switches paths."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    rays = f.rays6.copy()
+    rays[:, :3] = np.float32([3.25, -1.5, 0.75])          # shared, non-zero origin
+    mixed = rays.copy()
+    mixed[-1, 0] = np.nextafter(mixed[-1, 0], np.float32(10))   # one ulp off in the last ray
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    _lib.raycast_configure(ctx, 0, 1)
+    try:
+        a, b = mesh.cast_rays(rays), mesh.cast_rays(mixed)
+    finally:
+        _lib.raycast_configure(ctx, 0, 0)
+    _same(a, oracle.raycast(f.verts_posed, f.tris, rays))
+    _same(b, oracle.raycast(f.verts_posed, f.tris, mixed))
+    assert np.array_equal(a["primitive_ids"][:-1], b["primitive_ids"][:-1])
 
 
 def test_bad_arguments_raise(ctx):
