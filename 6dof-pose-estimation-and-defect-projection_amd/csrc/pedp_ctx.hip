@@ -117,8 +117,13 @@ int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, in
         double sum[3] = {0, 0, 0};
         for (int64_t i = 0; i < N; ++i) { sum[0] += pts[3 * i]; sum[1] += pts[3 * i + 1]; sum[2] += pts[3 * i + 2]; }
         for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
+        for (int k = 0; k < 3; ++k) { cl->lo[k] = pts[k]; cl->hi[k] = pts[k]; }
         float Tn = 0.f, T2 = 0.f;
         for (int64_t i = 0; i < N; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                if (pts[3 * i + k] < cl->lo[k]) cl->lo[k] = pts[3 * i + k];
+                if (pts[3 * i + k] > cl->hi[k]) cl->hi[k] = pts[3 * i + k];
+            }
             float x = (float)(pts[3 * i] - cl->centroid[0]), y = (float)(pts[3 * i + 1] - cl->centroid[1]),
                   z = (float)(pts[3 * i + 2] - cl->centroid[2]);
             float n1 = fabsf(x) + fabsf(y) + fabsf(z), n2 = x * x + y * y + z * z;

@@ -8,16 +8,23 @@
 //
 // Kernels per correspondence pass (all on the context's stream, no host round trip: a
 // device-side `done` flag turns the remaining passes into no-ops):
-//   icp_transform_pack   P <- U * P in float64 (the oracle's operation order), plus the
-//                        float32 MFMA operand of every scene point, (-2x', -2y', -2z', 1)
-//                        in coordinates centred on the target centroid.
+//   icp_transform_pack   P <- U * P in float64 (the oracle's operation order).  Points farther
+//                        than r from the target's bounding box cannot be inliers and are
+//                        dropped here; the others are compacted (wave-aggregated atomic) into
+//                        the float32 MFMA operand array, (-2x', -2y', -2z', 1) in coordinates
+//                        centred on the target centroid.
 //   nn_sweep             the one dense contraction.  v_mfma_f32_16x16x4_f32 evaluates
 //                        g(i,j) = |t'_j|^2 - 2 s'_i . t'_j for 16 target x 16 scene
 //                        points per instruction (A = target tile (x,y,z,|t|^2), B = scene
 //                        block); a wave keeps 8 scene blocks (128 points) as B operands in
-//                        registers for the whole sweep and streams target tiles as
-//                        coalesced 256-B fragments.  Epilogue per MFMA: 6 VALU ops keeping
-//                        (best tile value, its tile, second-best tile value) per lane.
+//                        registers and streams a chunk of target tiles as coalesced 256-B
+//                        fragments; the grid is (scene blocks) x (target chunks), sized on
+//                        the device from the candidate count so small problems still fill
+//                        the chip.  The loop is software-pipelined: the MFMA of tile k+1 is
+//                        issued before the 6-op VALU epilogue of tile k (best tile value,
+//                        its tile, second-best tile value per lane), so one wave alone keeps
+//                        the matrix pipe busy.
+//   nn_select            exact selection from the per-(point, lane group, chunk) triples.
 //                        fp32 g is only a FILTER: with a proven error bound eps_i the true
 //                        nearest neighbour lies in the tiles whose value is within
 //                        2 eps_i of the minimum; those <= 16 points are re-scored in
@@ -41,7 +48,9 @@ constexpr int PACKET = 29;  // doubles per partial-sum packet
 constexpr int NN_SB = 8;    // scene blocks of 16 points per wave
 constexpr int NN_WAVES = 4;
 constexpr int NN_PTS_PER_WG = NN_SB * 16 * NN_WAVES;  // 512
-constexpr int NN_TU = 4;    // target tiles in flight
+constexpr int NN_TU = 4;    // target tiles fetched ahead
+constexpr int NN_MAX_CHUNKS = 32;   // target chunks per scene block (device-chosen, <= this)
+constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
 constexpr int ACC_BLOCKS = 256;
 constexpr int ACC_THREADS = 256;
 
@@ -53,7 +62,7 @@ struct IcpState {
     int done;
     int iters;
     int fb_count;
-    int pad;
+    int n_cand;   // scene points that can still be inliers this pass (compacted)
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -80,35 +89,52 @@ __global__ void pack_target_kernel(const double *__restrict__ pts, int64_t N, in
 
 // ------------------------------------------------------------------ transform + pack
 // mode 0: P <- T * src (first pass; T = init), mode 1: P <- upd * P.
-__global__ void icp_transform_pack_kernel(const IcpState *__restrict__ st, int mode,
-                                          const double *__restrict__ src, double *__restrict__ P, int64_t N,
-                                          int64_t N_pad, float4 *__restrict__ B, float *__restrict__ eps,
-                                          float *__restrict__ S, float Tn, float T2, float r1) {
+// box: target AABB (lo xyz, hi xyz); a point whose distance to it is > r has no neighbour
+// within r (d_nn >= d_box) and is written off as "no correspondence" right here.
+__global__ __launch_bounds__(256) void icp_transform_pack_kernel(
+    IcpState *__restrict__ st, int mode, const double *__restrict__ src, double *__restrict__ P, int64_t N,
+    float4 *__restrict__ B, float *__restrict__ eps, float *__restrict__ S, int32_t *__restrict__ list,
+    int32_t *__restrict__ idx_out, double *__restrict__ d2_out, float Tn, float T2, float r1, double r2cut,
+    double lox, double loy, double loz, double hix, double hiy, double hiz) {
     if (st->done) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N_pad) return;
-    if (i >= N) {
-        B[i] = make_float4(0.f, 0.f, 0.f, 1.f);
-        eps[i] = 0.f;
-        S[i] = 3e38f;  // never an inlier candidate
-        return;
+    bool cand = false;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (i < N) {
+        const double *M = mode == 0 ? st->T : st->upd;
+        const double *in = mode == 0 ? src : P;
+        double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+        double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+        double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+        P[3 * i] = nx; P[3 * i + 1] = ny; P[3 * i + 2] = nz;
+        double ex = fmax(fmax(lox - nx, nx - hix), 0.0), ey = fmax(fmax(loy - ny, ny - hiy), 0.0),
+               ez = fmax(fmax(loz - nz, nz - hiz), 0.0);
+        cand = (ex * ex + ey * ey + ez * ez) <= r2cut;  // r2cut = r^2 (1 + 1e-12): rounding-safe
+        sx = (float)(nx - st->centroid[0]); sy = (float)(ny - st->centroid[1]); sz = (float)(nz - st->centroid[2]);
+        if (!cand) {
+            idx_out[i] = -1;
+            d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
+        }
     }
-    const double *M = mode == 0 ? st->T : st->upd;
-    const double *in = mode == 0 ? src : P;
-    double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-    double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
-    double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
-    double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
-    P[3 * i] = nx; P[3 * i + 1] = ny; P[3 * i + 2] = nz;
-    float sx = (float)(nx - st->centroid[0]), sy = (float)(ny - st->centroid[1]), sz = (float)(nz - st->centroid[2]);
-    B[i] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
+    // wave-aggregated append to the candidate list
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(mask)) base = atomicAdd(&st->n_cand, __builtin_popcountll(mask));
+    base = __shfl(base, __builtin_ctzll(mask), 64);
+    if (!cand) return;
+    const int slot = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    B[slot] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
     // Error bound of the fp32 surrogate relative to the float64 distance, for points whose
     // nearest neighbour is closer than r1 (see DESIGN.md "NN filter bound"):
     //   eps = 2^-23 * (5 * (2*|s'|_1*Tn + T2) + 2*min(r1, |s'|_1 + Tn)*(Tn + |s'|_1))
     float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
     float Mi = 2.0f * s1 * Tn + T2;
-    eps[i] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
-    S[i] = sx * sx + sy * sy + sz * sz;
+    eps[slot] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
+    S[slot] = sx * sx + sy * sy + sz * sz;
+    list[slot] = (int)i;
 }
 
 // ------------------------------------------------------------------ NN sweep (MFMA)
@@ -116,92 +142,148 @@ __device__ __forceinline__ void lexmin(double &d, int &j, double od, int oj) {
     if (od < d || (od == d && oj < j)) { d = od; j = oj; }
 }
 
+// Work split, decided on the device from the candidate count: n_sb scene blocks of 128
+// points x n_ch target chunks, one wave each.  Chunks are multiples of NN_TU tiles.
+struct NnSplit {
+    int n_sb, n_ch, tiles_per_chunk;
+    int64_t stride;  // points per (chunk, lane group) plane of the triple arrays
+};
+__device__ __forceinline__ NnSplit nn_split(int count, int n_tiles, int total_waves, int64_t cap) {
+    NnSplit sp;
+    sp.n_sb = (count + NN_SB * 16 - 1) / (NN_SB * 16);
+    int ch = total_waves / (sp.n_sb > 0 ? sp.n_sb : 1);
+    int by_tiles = n_tiles / (4 * NN_TU);                                   // >= 16 tiles per chunk
+    int by_cap = (int)(cap / ((int64_t)(sp.n_sb > 0 ? sp.n_sb : 1) * NN_SB * 16));  // triple storage
+    ch = ch < by_tiles ? ch : by_tiles;
+    ch = ch < by_cap ? ch : by_cap;
+    ch = ch < NN_MAX_CHUNKS ? ch : NN_MAX_CHUNKS;
+    ch = ch < 1 ? 1 : ch;
+    int tpc = (n_tiles + ch - 1) / ch;
+    tpc = (tpc + NN_TU - 1) / NN_TU * NN_TU;
+    sp.n_ch = (n_tiles + tpc - 1) / tpc;
+    sp.tiles_per_chunk = tpc;
+    sp.stride = (int64_t)sp.n_sb * NN_SB * 16;  // n_ch * stride <= cap by construction
+    return sp;
+}
+
+// Triples of wave (sb, ch): tr_b1 / tr_t1 / tr_b2 [(ch * 4 + q) * stride + point]
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
-    IcpState *__restrict__ st, const float *__restrict__ tgtf /* N_t_pad x 4 */, int n_tiles,
-    const double *__restrict__ tgt, int64_t Nt, const float *__restrict__ srcf /* N_s_pad x 4 */,
-    const double *__restrict__ P, int64_t Ns, const float *__restrict__ eps, const float *__restrict__ S,
-    float r2f, int32_t *__restrict__ idx_out, double *__restrict__ d2_out, int32_t *__restrict__ fb_list) {
+    const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64 */, int n_tiles,
+    const float *__restrict__ srcf /* compacted, N_s_pad x 4 */, float *__restrict__ tr_b1,
+    int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2, int64_t cap, int total_waves) {
     if (st->done) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = ((int64_t)blockIdx.x * NN_WAVES + wave) * (NN_SB * 16);
+    const int count = st->n_cand;
+    const NnSplit sp = nn_split(count, n_tiles, total_waves, cap);
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * NN_WAVES + (threadIdx.x >> 6);
+    // chunk-major: the 4 waves of a workgroup sweep the same target chunk (shared L1 lines)
+    const int ch = w / (sp.n_sb > 0 ? sp.n_sb : 1), sb_id = w - ch * sp.n_sb;
+    if (sp.n_sb == 0 || ch >= sp.n_ch) return;  // wave-uniform
+    const int64_t base = (int64_t)sb_id * (NN_SB * 16);
     const int frag = (lane & 15) * 4 + (lane >> 4);  // float offset inside a 16-point tile
+    const int t0 = ch * sp.tiles_per_chunk;
+    int t1e = t0 + sp.tiles_per_chunk;
+    if (t1e > n_tiles) t1e = n_tiles;  // n_tiles and the chunk size are multiples of NN_TU
 
     float b[NN_SB];
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) b[sb] = srcf[(base + sb * 16) * 4 + frag];
-
     float b1[NN_SB], b2[NN_SB];
     int t1[NN_SB];
 #pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = 0; }
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = t0; }
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int tile = 0; tile < n_tiles; tile += NN_TU) {  // n_tiles is a multiple of NN_TU
-        float a[NN_TU];
+    const float *ap = tgtf + (size_t)t0 * 64 + frag;
+    float a[NN_TU];
 #pragma unroll
-        for (int u = 0; u < NN_TU; ++u) a[u] = tgtf[(size_t)(tile + u) * 64 + frag];
+    for (int u = 0; u < NN_TU; ++u) a[u] = ap[u * 64];
+    f32x4 acc[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
+    for (int tile = t0; tile < t1e; tile += NN_TU) {
+        ap += NN_TU * 64;
+        float an[NN_TU];
+#pragma unroll
+        for (int u = 0; u < NN_TU; ++u) an[u] = ap[u * 64];  // next batch (pad tiles exist behind the end)
 #pragma unroll
         for (int u = 0; u < NN_TU; ++u) {
+            const float a_next = (u + 1 < NN_TU) ? a[u + 1] : an[0];
 #pragma unroll
             for (int sb = 0; sb < NN_SB; ++sb) {
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[sb], zero, 0, 0, 0);
-                float v = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                // software pipeline: the matrix pipe works on tile+u+1 while the VALU folds tile+u
+                f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
+                const f32x4 cur = acc[sb];
+                float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
                 t1[sb] = v < b1[sb] ? tile + u : t1[sb];
                 b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
                 b1[sb] = fminf(b1[sb], v);
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // then its 6 VALU ops
             }
         }
+#pragma unroll
+        for (int u = 0; u < NN_TU; ++u) a[u] = an[u];
     }
-
-    // ---- exact selection.  Lane (q = lane >> 4, j = lane & 15) owns rows 4q..4q+3 of
-    // every tile for scene point j of each block.
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) {
-        const int64_t i = base + sb * 16 + j;
-        float m = b1[sb], m2 = b2[sb];
-        m = fminf(m, __shfl_xor(m, 16, 64));
-        m = fminf(m, __shfl_xor(m, 32, 64));
-        m2 = fminf(m2, __shfl_xor(m2, 16, 64));
-        m2 = fminf(m2, __shfl_xor(m2, 32, 64));
-        const float e = eps[i];
-        const float Si = S[i];
-        const bool maybe_inlier = (i < Ns) && (m + Si <= r2f + 4.0f * e + 4.8e-7f * Si);
-        const float win = m + 2.0f * e;
-        double bd = __longlong_as_double(0x7FF0000000000000ll);
-        int bj = 0x7FFFFFFF;
-        if (maybe_inlier && b1[sb] <= win) {
-            const double px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
-            const int64_t row0 = (int64_t)t1[sb] * 16 + 4 * q;
+        const int64_t k = base + sb * 16 + j;
+        if (k < count) {
+            const size_t o = (size_t)(ch * 4 + q) * sp.stride + k;
+            tr_b1[o] = b1[sb];
+            tr_t1[o] = t1[sb];
+            tr_b2[o] = b2[sb];
+        }
+    }
+}
+
+// Exact selection, one thread per candidate point: window = min b1 + 2 eps; re-score the 4
+// rows of every (chunk, lane group) whose best tile is inside the window in float64 (the
+// oracle's formula, lexicographic (d^2, index) min); a second tile inside the window sends
+// the point to nn_fallback.
+__global__ __launch_bounds__(256) void nn_select_kernel(
+    IcpState *__restrict__ st, int n_tiles, int total_waves, int64_t cap, const float *__restrict__ tr_b1,
+    const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt, int64_t Nt,
+    const double *__restrict__ P, const float *__restrict__ eps, const float *__restrict__ S,
+    const int32_t *__restrict__ list, float r2f, int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
+    int32_t *__restrict__ fb_list) {
+    if (st->done) return;
+    const int count = st->n_cand;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const NnSplit sp = nn_split(count, n_tiles, total_waves, cap);
+    const int groups = sp.n_ch * 4;
+    float m = __uint_as_float(0x7F800000u), m2 = m;
+    for (int g = 0; g < groups; ++g) {
+        m = fminf(m, tr_b1[(size_t)g * sp.stride + k]);
+        m2 = fminf(m2, tr_b2[(size_t)g * sp.stride + k]);
+    }
+    const int i = list[k];
+    const float e = eps[k], Si = S[k];
+    if (!(m + Si <= r2f + 4.0f * e + 4.8e-7f * Si)) {  // certainly farther than r
+        idx_out[i] = -1;
+        d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
+        return;
+    }
+    const float win = m + 2.0f * e;
+    const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
+    double bd = __longlong_as_double(0x7FF0000000000000ll);
+    int bj = 0x7FFFFFFF;
+    for (int g = 0; g < groups; ++g) {
+        if (tr_b1[(size_t)g * sp.stride + k] <= win) {
+            const int64_t row0 = (int64_t)tr_t1[(size_t)g * sp.stride + k] * 16 + 4 * (g & 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int64_t row = row0 + r;
-                if (row < Nt) {
-                    double d = dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]);
-                    lexmin(bd, bj, d, (int)row);
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            double od = __shfl_xor(bd, off, 64);
-            int oj = __shfl_xor(bj, off, 64);
-            lexmin(bd, bj, od, oj);
-        }
-        if (q == 0 && i < Ns) {
-            if (!maybe_inlier) {
-                idx_out[i] = -1;
-                d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
-            } else {
-                idx_out[i] = bj;
-                d2_out[i] = bd;
-                if (m2 <= win) {  // a second tile of some lane group is inside the window
-                    int slot = atomicAdd(&st->fb_count, 1);
-                    fb_list[slot] = (int)i;
-                }
+                const int64_t row = row0 + r;
+                if (row < Nt) lexmin(bd, bj, dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]), (int)row);
             }
         }
     }
+    idx_out[i] = bj;
+    d2_out[i] = bd;
+    if (m2 <= win) fb_list[atomicAdd(&st->fb_count, 1)] = i;  // ambiguous: exact brute force decides
 }
 
 // One wave per ambiguous point: exact brute force in float64.
@@ -473,6 +555,7 @@ __global__ void icp_solve_kernel(IcpState *__restrict__ st, const double *__rest
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->done) return;
     st->fb_count = 0;
+    st->n_cand = 0;
     const double K = packet[28];
     double fit = 0.0, rmse = 0.0;
     if (K > 0.0) { fit = K / n_source; rmse = sqrt(packet[27] / K); }
@@ -530,6 +613,7 @@ __global__ void icp_solve_kernel(IcpState *__restrict__ st, const double *__rest
 struct TargetPrep {
     double c[3];
     float Tn, T2;
+    double lo[3], hi[3];
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -540,8 +624,11 @@ struct IcpWorkspace {
     float4 *B;
     const float4 *tgt4;
     float *eps, *S;
-    int32_t *idx, *fb;
-    int64_t Ns_pad, Nt_pad;
+    int32_t *idx, *fb, *list;
+    float *tr_b1, *tr_b2;
+    int32_t *tr_t1;
+    int64_t Ns_pad, Nt_pad, cap;
+    int total_waves;
 };
 
 int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorkspace &w) {
@@ -560,6 +647,13 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     size_t o_S = take(sizeof(float) * (size_t)w.Ns_pad);
     size_t o_idx = take(sizeof(int32_t) * (size_t)w.Ns_pad);
     size_t o_fb = take(sizeof(int32_t) * (size_t)w.Ns_pad);
+    size_t o_list = take(sizeof(int32_t) * (size_t)w.Ns_pad);
+    // per-(point, lane group, chunk) triples: room for 4 groups x (points x chunks <= cap)
+    w.total_waves = 16 * c->num_cus;  // 4 waves per SIMD when the split uses all of them
+    w.cap = w.Ns_pad > (int64_t)w.total_waves * NN_SB * 16 ? w.Ns_pad : (int64_t)w.total_waves * NN_SB * 16;
+    size_t o_b1 = take(sizeof(float) * 4 * (size_t)w.cap);
+    size_t o_t1 = take(sizeof(int32_t) * 4 * (size_t)w.cap);
+    size_t o_b2 = take(sizeof(float) * 4 * (size_t)w.cap);
     int st = c->icp_ws.reserve(off);
     if (st) return st;
     char *b = (char *)c->icp_ws.ptr;
@@ -574,6 +668,10 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     w.S = (float *)(b + o_S);
     w.idx = (int32_t *)(b + o_idx);
     w.fb = (int32_t *)(b + o_fb);
+    w.list = (int32_t *)(b + o_list);
+    w.tr_b1 = (float *)(b + o_b1);
+    w.tr_t1 = (int32_t *)(b + o_t1);
+    w.tr_b2 = (float *)(b + o_b2);
     return PEDP_OK;
 }
 
@@ -583,22 +681,31 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
                     const TargetPrep &tp, double r, bool timed) {
     const int64_t Ns = src->N, Nt = tgt->N;
     // r1: distance scale of the candidates the bound must hold for (anything farther is
-    // not an inlier anyway); huge radii fall back to the cloud scale.
-    float r1 = (float)(r * 1.01);
+    // not an inlier anyway); huge radii fall back to the cloud scale inside the kernel.
+    const float r1 = (float)(r * 1.01);
+    const double r2cut = r * r * (1.0 + 1e-12);
+    const int n_tiles = (int)(w.Nt_pad / 16);
     {
-        int64_t grid = (w.Ns_pad + 255) / 256;
+        int64_t grid = (Ns + 255) / 256;
         hipLaunchKernelGGL(icp_transform_pack_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, mode,
-                           src->pts, w.P, Ns, w.Ns_pad, w.B, w.eps, w.S, tp.Tn, tp.T2, r1);
+                           src->pts, w.P, Ns, w.B, w.eps, w.S, w.list, w.idx, w.d2, tp.Tn, tp.T2, r1, r2cut,
+                           tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
     }
     if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
-    {
-        int64_t grid = w.Ns_pad / NN_PTS_PER_WG;
-        float r2f = (float)(r * r) * 1.00001f;
-        hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,
-                           (const float *)w.tgt4, (int)(w.Nt_pad / 16), tgt->pts, Nt, (const float *)w.B, w.P, Ns,
-                           w.eps, w.S, r2f, w.idx, w.d2, w.fb);
-    }
+    // triple storage per group is `cap` points-times-chunks; the device-side split keeps
+    // (scene blocks x chunks) within it.
+    hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)((w.total_waves + NN_WAVES - 1) / NN_WAVES +
+                                                         (unsigned)(w.Ns_pad / NN_PTS_PER_WG))),
+                       dim3(NN_WAVES * 64), 0, c->stream, w.st, (const float *)w.tgt4, n_tiles, (const float *)w.B,
+                       w.tr_b1, w.tr_t1, w.tr_b2, w.cap, w.total_waves);
     if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
+    {
+        const float r2f = (float)(r * r) * 1.00001f;
+        int64_t grid = (Ns + 255) / 256;
+        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, n_tiles,
+                           w.total_waves, w.cap, w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, Nt, w.P, w.eps, w.S, w.list, r2f,
+                           w.idx, w.d2, w.fb);
+    }
     hipLaunchKernelGGL(nn_fallback_kernel, dim3(4 * c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, tgt->pts, Nt,
                        w.P, w.idx, w.d2);
     PEDP_HIP_CHECK(hipGetLastError());
@@ -611,8 +718,10 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     for (int k = 0; k < 3; ++k) tp.c[k] = tgt->centroid[k];
     tp.Tn = tgt->Tn;
     tp.T2 = tgt->T2;
+    for (int k = 0; k < 3; ++k) { tp.lo[k] = tgt->lo[k]; tp.hi[k] = tgt->hi[k]; }
     if (tgt->tgt4) return PEDP_OK;
-    int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU);
+    // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
+    int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
     PEDP_HIP_CHECK(hipMalloc(&tgt->tgt4, sizeof(float4) * (size_t)pad));
     tgt->tgt4_pad = pad;
     int64_t grid = (pad + 255) / 256;

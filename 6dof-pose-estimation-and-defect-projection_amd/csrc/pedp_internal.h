@@ -80,6 +80,7 @@ struct pedp_cloud_s {
     double centroid[3] = {0, 0, 0};
     float Tn = 0.f;  // max |t'|_1
     float T2 = 0.f;  // max |t'|_2^2
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // axis-aligned bounding box of the points
     // Built on first use as an ICP target: float4 (x', y', z', |t'|^2), padded.
     void *tgt4 = nullptr;
     int64_t tgt4_pad = 0;
