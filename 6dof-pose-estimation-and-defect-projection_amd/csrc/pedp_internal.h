@@ -65,7 +65,9 @@ struct pedp_mesh_s {
     pedp_ctx_t ctx = nullptr;
     int64_t V = 0, F = 0;
     float *tri = nullptr;  // F_padded x PEDP_TRI_STRIDE floats on the device
-    float *tri2 = nullptr; // F_padded/2 pair-interleaved general-origin records (18 floats each)
+    float *tri2 = nullptr; // F_padded/2 pair-interleaved general-origin records (24 floats each)
+    void *spheres = nullptr;  // n_clusters x float4 bounding spheres of 16-triangle clusters
+    int64_t n_clusters = 0;
     int64_t F_padded = 0;  // multiple of 8; pad records can never be hit (all zero => det == 0)
 };
 

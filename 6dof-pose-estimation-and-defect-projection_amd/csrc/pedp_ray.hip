@@ -32,6 +32,18 @@
 // key = (bits(t) << 32) | triangle id orders by t (t >= 0: IEEE bits are monotone), then by
 // triangle index -- the oracle's tie rule, independent of execution order.
 //
+// Variant 3 (default when all rays share one origin), ray per lane WITH conservative
+// culling -- still every triangle is accounted for, most of them by a bound instead of a
+// test.  Triangles are taken in clusters of 16 consecutive records with a bounding sphere
+// (mesh build); per call every cluster gets its cone from the shared origin (unit axis v,
+// cos/sin of the half-angle psi); rays are binned by direction (octahedral map, 256 x 256
+// cells in Hilbert-curve order, counting sort) so a wave holds 64 rays of one small solid angle, whose cone
+// (axis a, half-angle theta) is reduced in-kernel from the actual rays.  A ray of the wave can
+// only hit a triangle of the cluster if angle(a, v) <= theta + psi, so clusters with
+// v.a < cos(theta + psi) are skipped; the test runs lane-parallel (lane l tests cluster
+// base + l, one ballot per 64 clusters) and the survivors are swept exactly like variant 1.
+// Culling is conservative (margins below), so results stay bit-identical to the oracle.
+//
 // Variant 2, triangle per lane: few rays against a big mesh.  Lanes own consecutive
 // triangles (coalesced 16-B loads of the AoS records), 4 wave-uniform rays per wave, and the
 // packed key is min-reduced across the 64 lanes: the wavefront-wide min-t reduction.
@@ -39,6 +51,8 @@
 #include <new>
 
 namespace {
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 constexpr unsigned long long KEY_MISS = 0xFFFFFFFFFFFFFFFFull;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -267,6 +281,272 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
     if (ray < N && best != KEY_MISS) atomicMin(&keys[ray], best);
 }
 
+// ------------------------------------------------------------------ culled sweep (shared origin)
+constexpr int CL_TRIS = 16;                              // triangles per cluster
+constexpr int CL_GROUPS = CL_TRIS / (2 * RPL_PAIRS);     // loop groups per cluster (4)
+constexpr int BIN_BITS = 8;                              // 256 x 256 direction cells
+constexpr int BIN_CELLS = 1 << (2 * BIN_BITS);
+
+// bounding sphere (center, radius) of each cluster's real triangles; radius < 0: empty
+__global__ void cluster_sphere_kernel(const float *__restrict__ aos, int64_t F, int64_t n_clusters,
+                                      float4 *__restrict__ sph) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    int n = 0;
+    for (int k = 0; k < CL_TRIS; ++k) {
+        int64_t f = c * CL_TRIS + k;
+        if (f >= F) break;
+        const float *r = aos + f * PEDP_TRI_STRIDE;
+        for (int a = 0; a < 3; ++a) {
+            float p0 = r[a], p1 = r[a] + r[3 + a], p2 = r[a] + r[6 + a];
+            lo[a] = fminf(lo[a], fminf(p0, fminf(p1, p2)));
+            hi[a] = fmaxf(hi[a], fmaxf(p0, fmaxf(p1, p2)));
+        }
+        ++n;
+    }
+    if (n == 0) { sph[c] = make_float4(0.f, 0.f, 0.f, -1.f); return; }
+    float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    float r2 = 0.f;
+    for (int k = 0; k < n; ++k) {
+        const float *r = aos + (c * CL_TRIS + k) * PEDP_TRI_STRIDE;
+        for (int v = 0; v < 3; ++v) {
+            float px = r[0] + (v ? r[3 * v] : 0.f) - cx, py = r[1] + (v ? r[3 * v + 1] : 0.f) - cy,
+                  pz = r[2] + (v ? r[3 * v + 2] : 0.f) - cz;
+            r2 = fmaxf(r2, px * px + py * py + pz * pz);
+        }
+    }
+    // inflate: vertices re-derived from (v0, e1, e2) and fp32 accept decisions near the rim
+    float rad = sqrtf(r2) * 1.001f + 1e-5f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f;
+    sph[c] = make_float4(cx, cy, cz, rad);
+}
+
+// per call: cone of each cluster seen from the shared origin.  rec[2c] = (vx, vy, vz, cos psi),
+// rec[2c+1].x = sin psi.  cos psi = -2: the origin is inside the sphere (never cull);
+// cos psi = 2: empty cluster (always cull).
+__global__ void cluster_cone_kernel(const float4 *__restrict__ sph, int64_t n_clusters, const float *__restrict__ rays6,
+                                    const int *__restrict__ shared_flag, float4 *__restrict__ rec) {
+    if (*shared_flag == 0) return;
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    const float4 s = sph[c];
+    float4 a = make_float4(0.f, 0.f, 1.f, -2.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s.w < 0.f) {
+        a.w = 2.f;
+    } else {
+        float vx = s.x - rays6[0], vy = s.y - rays6[1], vz = s.z - rays6[2];
+        float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (dist > s.w * 1.0001f && dist > 0.f) {
+            float inv = 1.0f / dist;
+            float sn = fminf(s.w * inv * 1.0001f, 1.0f);
+            a = make_float4(vx * inv, vy * inv, vz * inv, sqrtf(fmaxf(0.f, 1.0f - sn * sn)));
+            b.x = sn;
+        }
+    }
+    rec[2 * c] = a;
+    rec[2 * c + 1] = b;
+}
+
+// ---- direction binning (counting sort by Hilbert-ordered cell of the octahedral map)
+__device__ __forceinline__ void octa(float dx, float dy, float dz, float &u, float &v) {
+    float n = fabsf(dx) + fabsf(dy) + fabsf(dz);
+    float inv = n > 0.f ? 1.0f / n : 0.f;
+    float px = dx * inv, py = dy * inv;
+    if (dz < 0.f) {
+        float qx = (1.0f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f);
+        float qy = (1.0f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
+        px = qx; py = qy;
+    }
+    u = px; v = py;
+}
+__device__ __forceinline__ unsigned enc_f(float f) {  // order-preserving float -> uint
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
+}
+// Hilbert curve index of cell (x, y) on the 2^BIN_BITS grid.  Consecutive indices are always
+// neighbouring cells (no long jumps, unlike Morton order), so ANY run of 64 sorted rays -- one
+// wave -- covers a compact patch of directions.
+__device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y) {
+    const unsigned n = 1u << BIN_BITS;
+    unsigned d = 0;
+#pragma unroll
+    for (unsigned s = n >> 1; s > 0; s >>= 1) {
+        const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0u) {
+            if (rx == 1u) { x = n - 1u - x; y = n - 1u - y; }
+            const unsigned t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
+// bounds[0..3] = enc(min u), enc(max u), enc(min v), enc(max v); preset by the host memsets
+__global__ void ray_bounds_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
+                                  unsigned *__restrict__ bounds) {
+    if (*shared_flag == 0) return;
+    unsigned lo_u = 0xFFFFFFFFu, hi_u = 0u, lo_v = 0xFFFFFFFFu, hi_v = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        float u, v;
+        octa(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], u, v);
+        if (u == u && v == v) {
+            unsigned eu = enc_f(u), ev = enc_f(v);
+            lo_u = eu < lo_u ? eu : lo_u; hi_u = eu > hi_u ? eu : hi_u;
+            lo_v = ev < lo_v ? ev : lo_v; hi_v = ev > hi_v ? ev : hi_v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned t;
+        t = __shfl_xor(lo_u, off, 64); lo_u = t < lo_u ? t : lo_u;
+        t = __shfl_xor(hi_u, off, 64); hi_u = t > hi_u ? t : hi_u;
+        t = __shfl_xor(lo_v, off, 64); lo_v = t < lo_v ? t : lo_v;
+        t = __shfl_xor(hi_v, off, 64); hi_v = t > hi_v ? t : hi_v;
+    }
+    __shared__ unsigned red[4][4];  // [wave][which]: same-address atomics are slow, one set per block
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = lo_u; red[wave][1] = hi_u; red[wave][2] = lo_v; red[wave][3] = hi_v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo_u = red[w][0] < lo_u ? red[w][0] : lo_u; hi_u = red[w][1] > hi_u ? red[w][1] : hi_u;
+            lo_v = red[w][2] < lo_v ? red[w][2] : lo_v; hi_v = red[w][3] > hi_v ? red[w][3] : hi_v;
+        }
+        atomicMin(&bounds[0], lo_u); atomicMax(&bounds[1], hi_u);
+        atomicMin(&bounds[2], lo_v); atomicMax(&bounds[3], hi_v);
+    }
+}
+
+__device__ __forceinline__ unsigned ray_cell(const float *__restrict__ rays6, int64_t i, const unsigned *__restrict__ bounds) {
+    float u, v;
+    octa(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], u, v);
+    const float u0 = dec_f(bounds[0]), u1 = dec_f(bounds[1]), v0 = dec_f(bounds[2]), v1 = dec_f(bounds[3]);
+    const float su = u1 > u0 ? (float)(1 << BIN_BITS) / (u1 - u0) : 0.f, sv = v1 > v0 ? (float)(1 << BIN_BITS) / (v1 - v0) : 0.f;
+    int qu = (int)((u - u0) * su), qv = (int)((v - v0) * sv);
+    qu = qu < 0 ? 0 : (qu > (1 << BIN_BITS) - 1 ? (1 << BIN_BITS) - 1 : qu);
+    qv = qv < 0 ? 0 : (qv > (1 << BIN_BITS) - 1 ? (1 << BIN_BITS) - 1 : qv);
+    if (!(u == u) || !(v == v)) { qu = 0; qv = 0; }
+    return hilbert_index((unsigned)qu, (unsigned)qv);
+}
+
+__global__ void ray_count_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
+                                 const unsigned *__restrict__ bounds, unsigned *__restrict__ hist) {
+    if (*shared_flag == 0) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) atomicAdd(&hist[ray_cell(rays6, i, bounds)], 1u);
+}
+
+// exclusive scan of BIN_CELLS counters, one workgroup of 1024 threads (64 cells each)
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const int *__restrict__ shared_flag, unsigned *__restrict__ hist) {
+    if (*shared_flag == 0) return;
+    __shared__ unsigned part[1024];
+    constexpr int PER = BIN_CELLS / 1024;
+    unsigned loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { loc[k] = hist[threadIdx.x * PER + k]; sum += loc[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { hist[threadIdx.x * PER + k] = run; run += loc[k]; }
+}
+
+__global__ void ray_scatter_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
+                                   const unsigned *__restrict__ bounds, unsigned *__restrict__ cursor /* scanned */,
+                                   unsigned *__restrict__ perm) {
+    if (*shared_flag == 0) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) perm[atomicAdd(&cursor[ray_cell(rays6, i, bounds)], 1u)] = (unsigned)i;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_cull_kernel(
+    const f2 *__restrict__ rec, const float *__restrict__ aos, const float4 *__restrict__ cones, int n_clusters,
+    const float *__restrict__ rays6, const unsigned *__restrict__ perm, int64_t N,
+    unsigned long long *__restrict__ keys, const int *__restrict__ shared_flag) {
+    if (*shared_flag == 0) return;
+    constexpr int PF = PAIR_SH / 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * RPL_BLOCK + threadIdx.x;
+    const int64_t ri = perm[k < N ? k : N - 1];  // tail lanes re-run the last ray, never store
+    Ray r;
+    r.ox = rays6[6 * ri + 0]; r.oy = rays6[6 * ri + 1]; r.oz = rays6[6 * ri + 2];
+    r.dx = rays6[6 * ri + 3]; r.dy = rays6[6 * ri + 4]; r.dz = rays6[6 * ri + 5];
+
+    // cone of this wave's rays: axis = normalised sum of unit directions, cos(theta) = min dot
+    const float inv = rsqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
+    const float ux = r.dx * inv, uy = r.dy * inv, uz = r.dz * inv;
+    float ax = wave_sum_f(ux), ay = wave_sum_f(uy), az = wave_sum_f(uz);
+    const float ainv = rsqrtf(ax * ax + ay * ay + az * az);
+    ax *= ainv; ay *= ainv; az *= ainv;
+    float ct = wave_min_f(ux * ax + uy * ay + uz * az) - 1e-5f;  // margin: rsqrt + rounding
+    // wide or degenerate (NaN) packets do not cull: every comparison below is then false
+    const bool can_cull = ct > 0.1f;
+    const float st = sqrtf(fmaxf(0.f, 1.0f - ct * ct)) + 1e-5f;
+
+    unsigned long long best = KEY_MISS;
+    for (int base = 0; base < n_clusters; base += 64) {
+        const int c = base + lane;
+        bool keep = false;
+        if (c < n_clusters) {
+            const float4 ca = cones[2 * c];
+            const float sp = cones[2 * c + 1].x;
+            const float cosv = ca.x * ax + ca.y * ay + ca.z * az;
+            const float lim = ct * ca.w - st * sp - 1e-5f;  // cos(theta + psi), lowered by a margin
+            const bool culled = (ca.w > 1.5f) || (can_cull && ca.w > -1.5f && cosv < lim);
+            keep = !culled;
+        }
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        while (mask != 0) {  // wave-uniform loop over the surviving clusters
+            const int cl = base + __builtin_ctzll(mask);
+            mask &= mask - 1;
+#pragma unroll 1
+            for (int gi = 0; gi < CL_GROUPS; ++gi) {
+                const int g = cl * CL_GROUPS + gi;
+                const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
+                f2 sc[RPL_PAIRS];
+#pragma unroll
+                for (int p = 0; p < RPL_PAIRS; ++p) sc[p] = inside_score(eval_pair_shared(r, t + p * PF));
+                const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
+                if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {
+                    const int f0 = g * (2 * RPL_PAIRS);
+#pragma unroll
+                    for (int q = 0; q < 2 * RPL_PAIRS; ++q) {
+                        const float s = (q & 1) ? sc[q >> 1].y : sc[q >> 1].x;
+                        if (s >= 0.0f) {
+                            MT m = mt_eval(r, aos + (size_t)(f0 + q) * PEDP_TRI_STRIDE);
+                            if (mt_accept(m)) {
+                                unsigned long long key = mt_key(m, (unsigned)(f0 + q));
+                                best = key < best ? key : best;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (k < N && best != KEY_MISS) atomicMin(&keys[ri], best);
+}
+
 // ------------------------------------------------------------------ sweep, triangle per lane
 constexpr int TPL_BLOCK = 256;
 constexpr int TPL_RAYS = 4;
@@ -390,6 +670,13 @@ int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t
         hipLaunchKernelGGL(pair_general_kernel, dim3(grid), dim3(256), 0, c->stream, m->tri, m->F_padded, m->tri2);
         e = hipGetLastError();
     }
+    m->n_clusters = m->F_padded / CL_TRIS;
+    if (e == hipSuccess) e = hipMalloc((void **)&m->spheres, sizeof(float4) * (size_t)m->n_clusters);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cluster_sphere_kernel, dim3((unsigned)((m->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
+                           m->tri, F, m->n_clusters, (float4 *)m->spheres);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (d_verts) (void)hipFree(d_verts);
     if (d_tris) (void)hipFree(d_tris);
@@ -407,6 +694,7 @@ void pedp_mesh_destroy(pedp_mesh_t m) {
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->tri) (void)hipFree(m->tri);
     if (m->tri2) (void)hipFree(m->tri2);
+    if (m->spheres) (void)hipFree(m->spheres);
     delete m;
 }
 
@@ -420,7 +708,7 @@ int pedp_mesh_size(pedp_mesh_t m, int64_t *V, int64_t *F) {
 int pedp_raycast_configure(pedp_ctx_t c, int tri_chunks, int variant) {
     PEDP_REQUIRE(c, "pedp_raycast_configure: null context");
     PEDP_REQUIRE(tri_chunks >= 0 && tri_chunks % 8 == 0, "pedp_raycast_configure: tri_chunks must be a multiple of 8");
-    PEDP_REQUIRE(variant >= 0 && variant <= 2, "pedp_raycast_configure: variant must be 0, 1 or 2");
+    PEDP_REQUIRE(variant >= 0 && variant <= 3, "pedp_raycast_configure: variant must be 0..3");
     c->ray_tri_chunks = tri_chunks;
     c->ray_variant = variant;
     return PEDP_OK;
@@ -456,12 +744,22 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
     PEDP_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)N, c->stream));
 
     int variant = c->ray_variant;
-    if (variant == 0) variant = (N < 16384) ? 2 : 1;
-    if (variant == 1) {
-        st = c->ray_aux.reserve(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2) + 256);
+    if (variant == 0) variant = (N < 16384) ? 2 : 3;
+    if (variant == 1 || variant == 3) {
+        // aux layout: [flag + bounds: 256 B][shared pair records][cone records][hist][perm]
+        const size_t sz_tri3 = align256(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2));
+        const size_t sz_cone = align256(sizeof(float4) * 2 * (size_t)mesh->n_clusters);
+        const size_t sz_hist = align256(sizeof(unsigned) * BIN_CELLS);
+        const size_t sz_perm = align256(sizeof(unsigned) * (size_t)N);
+        st = c->ray_aux.reserve(256 + sz_tri3 + sz_cone + sz_hist + sz_perm);
         if (st) return st;
-        int *flag = (int *)c->ray_aux.ptr;
-        float *tri3 = (float *)((char *)c->ray_aux.ptr + 256);
+        char *aux = (char *)c->ray_aux.ptr;
+        int *flag = (int *)aux;
+        unsigned *bounds = (unsigned *)(aux + 16);
+        float *tri3 = (float *)(aux + 256);
+        float4 *cones = (float4 *)(aux + 256 + sz_tri3);
+        unsigned *hist = (unsigned *)(aux + 256 + sz_tri3 + sz_cone);
+        unsigned *perm = (unsigned *)(aux + 256 + sz_tri3 + sz_cone + sz_hist);
         PEDP_HIP_CHECK(hipMemsetAsync(flag, 0xFF, sizeof(int), c->stream));
         hipLaunchKernelGGL(origin_check_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag);
         hipLaunchKernelGGL(pair_shared_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream,
@@ -478,8 +776,26 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         int64_t grid = ray_blocks * n_chunks;
         PEDP_REQUIRE(grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
         PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(ray_sweep_rpl_kernel<true>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
-                           (const f2 *)tri3, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
+        if (variant == 3) {
+            // shared origin: cluster cones, direction binning, culled sweep
+            static const unsigned bounds_init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+            PEDP_HIP_CHECK(hipMemcpyAsync(bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice, c->stream));
+            PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * BIN_CELLS, c->stream));
+            hipLaunchKernelGGL(cluster_cone_kernel, dim3((unsigned)((mesh->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
+                               (const float4 *)mesh->spheres, mesh->n_clusters, d_rays, flag, cones);
+            hipLaunchKernelGGL(ray_bounds_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag, bounds);
+            hipLaunchKernelGGL(ray_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
+                               bounds, hist);
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, flag, hist);
+            hipLaunchKernelGGL(ray_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
+                               bounds, hist, perm);
+            hipLaunchKernelGGL(ray_sweep_cull_kernel, dim3((unsigned)ray_blocks), dim3(RPL_BLOCK), 0, c->stream,
+                               (const f2 *)tri3, mesh->tri, (const float4 *)cones, (int)mesh->n_clusters, d_rays, perm, N,
+                               keys, flag);
+        } else {
+            hipLaunchKernelGGL(ray_sweep_rpl_kernel<true>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
+                               (const f2 *)tri3, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
+        }
         hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
                            (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
     } else {

@@ -13,7 +13,7 @@ def _same(res, ref):
 
 
 @pytest.mark.parametrize("config", ["tiny", "parity"])
-@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 64), (2, 0), (2, 16)])
+@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 64), (2, 0), (2, 16), (3, 0)])
 def test_frame_bit_exact(ctx, oracle, config, variant, chunks):
     from pedp_hip import _lib, synth
 
@@ -54,7 +54,7 @@ def test_general_origins_and_unnormalised_directions(ctx, oracle):
     d = (tgt - o) * rng.uniform(0.01, 3.0, size=(n, 1))
     rays = np.hstack([o, d]).astype(np.float32)
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         _lib.raycast_configure(ctx, 0, variant)
         try:
             _same(mesh.cast_rays(rays), oracle.raycast(f.verts_posed, f.tris, rays))
@@ -103,7 +103,7 @@ def test_tie_takes_lowest_triangle_index(ctx, oracle):
     t = np.vstack([filler, [[3, 4, 5]], filler, [[6, 7, 8]]]).astype(np.uint32)
     rays = np.tile(np.array([[0.2, 0.3, 0, 0, 0, 1]], np.float32), (130, 1))
     mesh = _lib.Mesh(ctx, v, t)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         _lib.raycast_configure(ctx, 8, variant)
         try:
             r = mesh.cast_rays(rays)
@@ -125,14 +125,43 @@ def test_shared_and_mixed_origins_same_bits(ctx, oracle):
     mixed = rays.copy()
     mixed[-1, 0] = np.nextafter(mixed[-1, 0], np.float32(10))   # one ulp off in the last ray
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
-    _lib.raycast_configure(ctx, 0, 1)
-    try:
-        a, b = mesh.cast_rays(rays), mesh.cast_rays(mixed)
-    finally:
-        _lib.raycast_configure(ctx, 0, 0)
-    _same(a, oracle.raycast(f.verts_posed, f.tris, rays))
-    _same(b, oracle.raycast(f.verts_posed, f.tris, mixed))
-    assert np.array_equal(a["primitive_ids"][:-1], b["primitive_ids"][:-1])
+    ref_a, ref_b = oracle.raycast(f.verts_posed, f.tris, rays), oracle.raycast(f.verts_posed, f.tris, mixed)
+    for variant in (1, 3):
+        _lib.raycast_configure(ctx, 0, variant)
+        try:
+            a, b = mesh.cast_rays(rays), mesh.cast_rays(mixed)
+        finally:
+            _lib.raycast_configure(ctx, 0, 0)
+        _same(a, ref_a)
+        _same(b, ref_b)
+        assert np.array_equal(a["primitive_ids"][:-1], b["primitive_ids"][:-1])
+
+
+def test_culling_is_conservative_on_hard_packets(ctx, oracle):
+    """Culled sweep (variant 3) on ray sets that stress the cone logic: origin outside / in the
+    hole / inside the tube, rays in all directions (wide packets), rays aimed exactly at
+    vertices (edge hits), zero and NaN directions."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    rng = np.random.default_rng(11)
+    n = 20000
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    centre = f.T_gt[:3, 3]
+    for origin in (np.zeros(3), centre, centre + f.T_gt[:3, :3] @ [60.0, 0.0, 0.0]):
+        d = rng.normal(size=(n, 3))
+        d[:50] = 0.0
+        d[50:60] = np.nan
+        d[5000:10000] = f.verts_posed[rng.integers(0, len(f.verts_posed), 5000)] - origin
+        rays = np.hstack([np.tile(origin, (n, 1)), d]).astype(np.float32)
+        _lib.raycast_configure(ctx, 0, 3)
+        try:
+            got = mesh.cast_rays(rays)
+        finally:
+            _lib.raycast_configure(ctx, 0, 0)
+        ref = oracle.raycast(f.verts_posed, f.tris, rays)
+        assert np.isfinite(ref["t_hit"]).sum() > 1000
+        _same(got, ref)
 
 
 def test_bad_arguments_raise(ctx):

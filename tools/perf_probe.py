@@ -11,7 +11,7 @@ f = synth.Frame(cfg)
 mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
 print("config", cfg, "rays", f.n_rays, "tris", f.n_tris, flush=True)
 res = None
-for variant, chunks in [(1, 0), (1, 8), (1, 16), (1, 32), (1, 64), (2, 32)]:
+for variant, chunks in [(1, 0), (1, 32), (3, 0), (0, 0)]:
     _lib.raycast_configure(ctx, chunks, variant)
     ts = []
     for rep in range(4):
