@@ -40,6 +40,10 @@
 #include <cmath>
 #include <new>
 
+#ifndef PEDP_NN_EXPERIMENT
+#define PEDP_NN_EXPERIMENT 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -214,6 +218,18 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
                 // software pipeline: the matrix pipe works on tile+u+1 while the VALU folds tile+u
                 f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
                 const f32x4 cur = acc[sb];
+#if PEDP_NN_EXPERIMENT == 1   /* MFMA only (wrong results): pure matrix-pipe rate of this loop shape */
+                b1[sb] = fminf(b1[sb], cur[0]);
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#elif PEDP_NN_EXPERIMENT == 2 /* 3-op epilogue (wrong results) */
+                float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
+                b1[sb] = fminf(b1[sb], v);
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+#else
                 float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
                 t1[sb] = v < b1[sb] ? tile + u : t1[sb];
                 b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
                 acc[sb] = nxt;
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // then its 6 VALU ops
+#endif
             }
         }
 #pragma unroll
@@ -239,10 +256,10 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     }
 }
 
-// Exact selection, one thread per candidate point: window = min b1 + 2 eps; re-score the 4
-// rows of every (chunk, lane group) whose best tile is inside the window in float64 (the
-// oracle's formula, lexicographic (d^2, index) min); a second tile inside the window sends
-// the point to nn_fallback.
+// Exact selection, four threads per candidate point (thread gl of a point walks groups gl,
+// gl+4, ...): window = min b1 + 2 eps; every (chunk, lane group) whose best tile is inside the
+// window has its 4 rows re-scored in float64 (the oracle's formula, lexicographic (d^2, index)
+// min); a second tile inside the window sends the point to nn_fallback.
 __global__ __launch_bounds__(256) void nn_select_kernel(
     IcpState *__restrict__ st, int n_tiles, int total_waves, int64_t cap, const float *__restrict__ tr_b1,
     const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt, int64_t Nt,
@@ -251,39 +268,55 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     int32_t *__restrict__ fb_list) {
     if (st->done) return;
     const int count = st->n_cand;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = tid >> 2, gl = tid & 3;
+    if ((tid & ~63) >= 4 * count) return;  // whole wave beyond the list
+    const bool live = k < count;
+    const int kk = live ? k : 0;
     const NnSplit sp = nn_split(count, n_tiles, total_waves, cap);
     const int groups = sp.n_ch * 4;
     float m = __uint_as_float(0x7F800000u), m2 = m;
-    for (int g = 0; g < groups; ++g) {
-        m = fminf(m, tr_b1[(size_t)g * sp.stride + k]);
-        m2 = fminf(m2, tr_b2[(size_t)g * sp.stride + k]);
+    for (int g = gl; g < groups; g += 4) {
+        m = fminf(m, tr_b1[(size_t)g * sp.stride + kk]);
+        m2 = fminf(m2, tr_b2[(size_t)g * sp.stride + kk]);
     }
-    const int i = list[k];
-    const float e = eps[k], Si = S[k];
-    if (!(m + Si <= r2f + 4.0f * e + 4.8e-7f * Si)) {  // certainly farther than r
-        idx_out[i] = -1;
-        d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
-        return;
-    }
+    m = fminf(m, __shfl_xor(m, 1, 64)); m = fminf(m, __shfl_xor(m, 2, 64));
+    m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
+    const int i = list[kk];
+    const float e = eps[kk], Si = S[kk];
+    const bool maybe = m + Si <= r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
     const float win = m + 2.0f * e;
-    const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
     double bd = __longlong_as_double(0x7FF0000000000000ll);
     int bj = 0x7FFFFFFF;
-    for (int g = 0; g < groups; ++g) {
-        if (tr_b1[(size_t)g * sp.stride + k] <= win) {
-            const int64_t row0 = (int64_t)tr_t1[(size_t)g * sp.stride + k] * 16 + 4 * (g & 3);
+    if (live && maybe) {
+        const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
+        for (int g = gl; g < groups; g += 4) {
+            if (tr_b1[(size_t)g * sp.stride + kk] <= win) {
+                const int64_t row0 = (int64_t)tr_t1[(size_t)g * sp.stride + kk] * 16 + 4 * (g & 3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + r;
-                if (row < Nt) lexmin(bd, bj, dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]), (int)row);
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r;
+                    if (row < Nt) lexmin(bd, bj, dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]), (int)row);
+                }
             }
         }
     }
-    idx_out[i] = bj;
-    d2_out[i] = bd;
-    if (m2 <= win) fb_list[atomicAdd(&st->fb_count, 1)] = i;  // ambiguous: exact brute force decides
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {
+        const double od = __shfl_xor(bd, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        lexmin(bd, bj, od, oj);
+    }
+    if (live && gl == 0) {
+        if (!maybe) {
+            idx_out[i] = -1;
+            d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
+        } else {
+            idx_out[i] = bj;
+            d2_out[i] = bd;
+            if (m2 <= win) fb_list[atomicAdd(&st->fb_count, 1)] = i;  // ambiguous: exact brute force decides
+        }
+    }
 }
 
 // One wave per ambiguous point: exact brute force in float64.
@@ -549,11 +582,22 @@ __device__ void svd3_dev(const double *Ain, double *U, double *w, double *V) {
 
 // pass p (0 = initial correspondence pass).  Records fitness/rmse of the pass, decides
 // whether the loop ends, otherwise derives the next update from the packet.
-__global__ void icp_solve_kernel(IcpState *__restrict__ st, const double *__restrict__ packet, int pass,
-                                 int max_iter, int estimator, double n_source, double rel_fitness,
-                                 double rel_rmse, double *__restrict__ trace) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *__restrict__ st, double *__restrict__ packet,
+                                                       const double *__restrict__ partials, int pass, int max_iter,
+                                                       int estimator, double n_source, double rel_fitness,
+                                                       double rel_rmse, double *__restrict__ trace) {
     if (st->done) return;
+    // single-GPU runs fold icp_reduce into this launch (partials != null); with an all-reduce
+    // hook the packet was reduced (and summed over ranks) before.
+    if (partials) {
+        if (threadIdx.x < PACKET) {
+            double v = 0.0;
+            for (int b = 0; b < ACC_BLOCKS; ++b) v += partials[(size_t)b * PACKET + threadIdx.x];
+            packet[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     st->fb_count = 0;
     st->n_cand = 0;
     const double K = packet[28];
@@ -701,7 +745,7 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
     {
         const float r2f = (float)(r * r) * 1.00001f;
-        int64_t grid = (Ns + 255) / 256;
+        int64_t grid = (4 * Ns + 255) / 256;
         hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, n_tiles,
                            w.total_waves, w.cap, w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, Nt, w.P, w.eps, w.S, w.list, r2f,
                            w.idx, w.d2, w.fb);
@@ -777,7 +821,7 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
             if (rc) return rc;
             hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, c->stream, w.st,
                                prm->estimator, w.P, Ns, target->pts, target->normals, w.idx, w.d2, r2, w.partials);
-            hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.partials, w.packet);
+            if (prm->allreduce) hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.partials, w.packet);
         } else {
             PEDP_HIP_CHECK(hipMemsetAsync(w.packet, 0, sizeof(double) * 32, c->stream));
             if (pass == 0 && Ns > 0) PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, c->stream));
@@ -789,7 +833,8 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
                 return PEDP_ERR_COLLECTIVE;
             }
         }
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.packet, pass, max_iter,
+        const double *fold = (!degenerate && !prm->allreduce) ? w.partials : nullptr;
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.packet, fold, pass, max_iter,
                            prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
                            prm->relative_rmse, trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
