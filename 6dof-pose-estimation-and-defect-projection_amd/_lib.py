@@ -55,6 +55,7 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "pedp_cluster_poses": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, _P(C.c_int)]),
 }
@@ -230,6 +231,13 @@ def nn_last_sweep_ms(ctx):
     ms = C.c_float(0)
     check(load().pedp_nn_last_sweep_ms(ctx._h, C.byref(ms)), "pedp_nn_last_sweep_ms")
     return ms.value
+
+
+def icp_last_stats(ctx):
+    """(passes, pairs swept by the MFMA kernel, points sent to the exact fallback) of the last icp()."""
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    check(load().pedp_icp_last_stats(ctx._h, C.byref(a), C.byref(b), C.byref(c)), "pedp_icp_last_stats")
+    return a.value, b.value, c.value
 
 
 def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,

@@ -67,6 +67,8 @@ struct IcpState {
     int iters;
     int fb_count;
     int n_cand;   // scene points that can still be inliers this pass (compacted)
+    long long sum_cand;  // statistics over the passes of this registration
+    long long sum_fb;
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -598,6 +600,8 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *__restrict__ st
         __syncthreads();
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->sum_cand += st->n_cand;
+    st->sum_fb += st->fb_count;
     st->fb_count = 0;
     st->n_cand = 0;
     const double K = packet[28];
@@ -844,6 +848,10 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
+    c->icp_last_cand = hp->sum_cand;
+    c->icp_last_fb = hp->sum_fb;
+    c->icp_last_passes = hp->iters + 1;
+    c->icp_last_nt = Nt;
     if (fitness) *fitness = hp->fitness;
     if (inlier_rmse) *inlier_rmse = hp->rmse;
     if (n_iter_done) *n_iter_done = hp->iters;
@@ -890,6 +898,14 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     PEDP_HIP_CHECK(hipMemcpyAsync(idx, w.idx, sizeof(int32_t) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipMemcpyAsync(d2, w.d2, sizeof(double) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_icp_last_stats(pedp_ctx_t c, int64_t *passes, int64_t *pairs_swept, int64_t *fallback_points) {
+    PEDP_REQUIRE(c, "pedp_icp_last_stats: null context");
+    if (passes) *passes = c->icp_last_passes;
+    if (pairs_swept) *pairs_swept = c->icp_last_cand * c->icp_last_nt;
+    if (fallback_points) *fallback_points = c->icp_last_fb;
     return PEDP_OK;
 }
 

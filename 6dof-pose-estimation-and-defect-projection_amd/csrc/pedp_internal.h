@@ -53,6 +53,7 @@ struct pedp_ctx_s {
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;
     // ICP
     pedp_scratch icp_ws;
+    long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
 };

@@ -74,8 +74,12 @@ int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N
                  float *t_hit, uint32_t *prim_id, float *uv);
 
 /* Tuning knobs of the sweep (0 = keep default): triangle chunks per ray block
- * (multiple of 8: chunk c is served by XCD c % 8) and sweep variant
- * (0 auto, 1 ray-per-lane, 2 triangle-per-lane with wave-wide min). */
+ * (multiple of 8: chunk c is served by XCD c % 8) and sweep variant:
+ *   0 auto (2 below 16,384 rays, else 3)
+ *   1 ray-per-lane, every ray tested against every triangle
+ *   2 triangle-per-lane with a wavefront-wide min-t reduction
+ *   3 ray-per-lane with conservative cluster culling when all rays share one origin
+ *     (falls back to 1 on the device otherwise).  All variants return identical bits. */
 int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
 
 /* Milliseconds the last pedp_raycast spent in its sweep kernel (HIP events on the
@@ -130,6 +134,12 @@ int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
 int pedp_nn(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const double T[16],
             int32_t *idx, double *d2);
 int pedp_nn_last_sweep_ms(pedp_ctx_t ctx, float *ms);
+
+/* Work statistics of the last pedp_icp on this context: correspondence passes run, (scene,
+ * target) pairs the MFMA sweep evaluated (scene points farther than the radius from the
+ * target's bounding box are dropped before the sweep), and points whose fp32 filter was
+ * ambiguous and went through the exact float64 brute-force kernel. */
+int pedp_icp_last_stats(pedp_ctx_t ctx, int64_t *passes, int64_t *pairs_swept, int64_t *fallback_points);
 
 /* ---------------------------------------------------------------- cluster_poses
  * Replaces mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68; caller

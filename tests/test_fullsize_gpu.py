@@ -1,0 +1,84 @@
+"""GPU parity at BASELINE.json's full sizes.  The oracle's BVH gives the bit-exact reference
+in about a second on the GPU box's host cores; on top of it, size-independent properties:
+all sweep variants agree, ray order does not matter, ICP recovers the known pose."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(res, ref):
+    assert np.array_equal(res["primitive_ids"], ref["primitive_ids"])
+    assert np.array_equal(res["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def frame100k():
+    from pedp_hip import synth
+
+    return synth.Frame("bench_100k")
+
+
+def test_bench_100k_rays_bit_exact_all_variants(ctx, oracle, frame100k):
+    from pedp_hip import _lib
+
+    f = frame100k
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    assert np.isfinite(ref["t_hit"]).sum() == 35863            # hit count of this frame (oracle)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    for variant in (3, 1):                                       # culled, exhaustive
+        _lib.raycast_configure(ctx, 0, variant)
+        try:
+            got = mesh.cast_rays(f.rays6)
+        finally:
+            _lib.raycast_configure(ctx, 0, 0)
+        _same(got, ref)
+        assert np.array_equal(got["primitive_uvs"].view(np.uint32), ref["primitive_uvs"].view(np.uint32))
+    # permutation invariance: shuffling the rays shuffles the answers, nothing else
+    perm = np.random.default_rng(0).permutation(f.n_rays)
+    shuffled = mesh.cast_rays(f.rays6[perm], want_uv=False)
+    assert np.array_equal(shuffled["primitive_ids"], ref["primitive_ids"][perm])
+    assert np.array_equal(shuffled["t_hit"].view(np.uint32), ref["t_hit"][perm].view(np.uint32))
+    # general-origin path on the same frame: one origin nudged -> device falls back, same bits elsewhere
+    nudged = f.rays6.copy()
+    nudged[12345, 0] = 1e-3
+    g = mesh.cast_rays(nudged, want_uv=False)
+    keep = np.arange(f.n_rays) != 12345
+    assert np.array_equal(g["primitive_ids"][keep], ref["primitive_ids"][keep])
+
+
+def test_bench_100k_icp_matches_oracle_and_ground_truth(ctx, oracle, frame100k):
+    from pedp_hip import _lib
+
+    f = frame100k
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    res = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=4, relative_fitness=-1, relative_rmse=-1,
+                   want_corr=True, want_trace=True)
+    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=4, rel_fitness=-1, rel_rmse=-1)
+    assert np.array_equal(res["corr"], ref["corr"])
+    assert res["fitness"] == ref["fitness"] and abs(res["inlier_rmse"] - ref["inlier_rmse"]) < 1e-9
+    assert np.abs(res["trace"][:, 2:] - ref["trace"][:, 2:]).max() < 1e-5
+    passes, pairs, fb = _lib.icp_last_stats(ctx)
+    assert passes == 5 and 0 < pairs < 5 * len(scene) * len(f.model_points) * 0.25   # bounding-box culling at work
+    # 20 iterations land on the ground-truth pose (0.5 mm depth noise)
+    full = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1)
+    assert np.abs(np.linalg.inv(full["T"]) - f.T_gt).max() < 0.05
+    # exact NN over ALL pairs (no radius): indices and float64 distances equal the KD-tree oracle
+    idx, d2 = _lib.nn(ctx, src, tgt, f.icp_init())
+    ridx, rd2 = oracle.nn(oracle.transform(f.icp_init(), scene), f.model_points, kdtree=True)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_bench_1m_config_rays(ctx, oracle):
+    """BASELINE config 4 at one GPU: 1M-triangle mesh, 1280x720 dense frame (921,600 rays)."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("bench_1m")
+    assert f.n_tris == 1_000_000 and f.n_rays == 921_600
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    got = mesh.cast_rays(f.rays6)
+    _same(got, ref)
+    assert np.isfinite(ref["t_hit"]).sum() > 50_000
