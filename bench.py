@@ -153,6 +153,14 @@ def main():
     _lib.raycast_configure(ctx, 0, 0)
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, tools/pmc_target.py + tools/summarize_pmc.py)
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                traffic = json.load(fh)
+        except OSError:
+            pass
         ms_per_step = 1e3 * elapsed / args.steps
         ray_stage = float(np.mean(sweep_ms))
         icp_mean = float(np.mean(icp_ms))
@@ -182,7 +190,8 @@ def main():
             "pose_error_vs_gt": float(np.abs(np.linalg.inv(res["T"]) - frame.T_gt).max()),
             # dominant kernel of the step by time: the MFMA nearest-neighbour sweep
             "roofline": {"kernel": "nn_sweep_kernel", "bound": "mfma", "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": nn,
+                         "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
+                         "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"), "kernel_ms": nn,
                          "note": f"{FLOP_PER_PAIR} flop x {len(scene)} scene x {len(frame.model_points)} model points "
                                  "(all pairs, one correspondence pass) / HIP-event duration of the sweep kernel; "
                                  "inside a step the same kernel runs on the bounding-box survivors only "
@@ -191,6 +200,7 @@ def main():
             "roofline_ray_sweep": {"kernel": "ray_sweep_rpl_kernel<shared origin>", "bound": "valu_fp32",
                                    "achieved": FLOP_PER_TEST * tests / (brute * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                    "unit": "TFLOP/s", "frac": FLOP_PER_TEST * tests / (brute * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                   "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"),
                                    "kernel_ms": brute, "mrays_per_s": n_rays / (brute * 1e-3) / 1e6,
                                    "executed_tflops": 21.0 * tests / (brute * 1e-3) / 1e12,
                                    "note": f"{FLOP_PER_TEST} algorithmic flop per test (SURVEY s8d); the shared-origin "
