@@ -157,6 +157,8 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (cl->pts) (void)hipFree(cl->pts);
     if (cl->normals) (void)hipFree(cl->normals);
     if (cl->tgt4) (void)hipFree(cl->tgt4);
+    if (cl->perm) (void)hipFree(cl->perm);
+    if (cl->tile_sph) (void)hipFree(cl->tile_sph);
     delete cl;
 }
 

@@ -54,6 +54,9 @@ constexpr int NN_WAVES = 4;
 constexpr int NN_PTS_PER_WG = NN_SB * 16 * NN_WAVES;  // 512
 constexpr int NN_TU = 4;    // target tiles fetched ahead
 constexpr int NN_MAX_CHUNKS = 32;   // target chunks per scene block (device-chosen, <= this)
+constexpr int NN_CHUNK_TILES = 2048;  // most tiles a chunk may hold (survivor list lives in LDS)
+constexpr int SORT_BITS = 5;          // spatial sort: 32^3 Hilbert-ordered cells over the cloud's bounding box
+constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
 constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
 constexpr int ACC_BLOCKS = 256;
 constexpr int ACC_THREADS = 256;
@@ -66,7 +69,10 @@ struct IcpState {
     int done;
     int iters;
     int fb_count;
-    int n_cand;   // scene points that can still be inliers this pass (compacted)
+    int n_cand;   // slots of the compacted candidate list this pass (128 per scene block)
+    int n_blocks; // scene blocks (one per transform wave with at least one candidate)
+    int last_n_sb, last_n_ch;  // split of the most recent sweep (statistics)
+    long long last_tiles;      // surviving (scene block, target tile) pairs of that sweep
     long long sum_cand;  // statistics over the passes of this registration
     long long sum_fb;
 };
@@ -81,66 +87,222 @@ __device__ __forceinline__ double dist2(double ax, double ay, double az, double 
     return dadd(dadd(dmul(dx, dx), dmul(dy, dy)), dmul(dz, dz));
 }
 
-// ------------------------------------------------------------------ target preparation
-// float4 (x', y', z', |t'|^2) per target point, centred on c; pad rows can never win.
-__global__ void pack_target_kernel(const double *__restrict__ pts, int64_t N, int64_t N_pad, double cx,
-                                   double cy, double cz, float4 *__restrict__ out) {
+// ------------------------------------------------------------------ spatial order of a cloud
+// Counting sort by the Hilbert-curve index of the point's cell in a 32^3 grid over the bounding box:
+// consecutive entries of `perm` are neighbours in space, so 128-point scene blocks and 16-point
+// target tiles are compact and their bounding spheres are small.  Order inside a cell is
+// arbitrary (atomics); nothing downstream depends on it.
+// 3-D Hilbert index of cell (x, y, z), SORT_BITS bits per axis (Skilling, "Programming the
+// Hilbert curve", 2004: axes -> transpose, then bit interleave).  Unlike Morton order, points
+// that are consecutive along the curve are always neighbours in space, so no 128-point scene
+// block or 16-point target tile straddles a long jump (such blocks would defeat the culling).
+__device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z) {
+    unsigned X[3] = {x, y, z};
+    const unsigned M = 1u << (SORT_BITS - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned Pm = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= Pm;
+            else { const unsigned t = (X[0] ^ X[i]) & Pm; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    unsigned h = 0;
+#pragma unroll
+    for (int b = SORT_BITS - 1; b >= 0; --b)
+        h = (h << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+    return h;
+}
+__device__ __forceinline__ unsigned point_cell(const double *__restrict__ pts, int64_t i, double lox, double loy,
+                                               double loz, double sx, double sy, double sz) {
+    int qx = (int)((pts[3 * i] - lox) * sx), qy = (int)((pts[3 * i + 1] - loy) * sy), qz = (int)((pts[3 * i + 2] - loz) * sz);
+    const int top = (1 << SORT_BITS) - 1;
+    qx = qx < 0 ? 0 : (qx > top ? top : qx);
+    qy = qy < 0 ? 0 : (qy > top ? top : qy);
+    qz = qz < 0 ? 0 : (qz > top ? top : qz);
+    return hilbert3((unsigned)qx, (unsigned)qy, (unsigned)qz);
+}
+__global__ void cell_count_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
+                                  double sx, double sy, double sz, unsigned *__restrict__ hist) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N_pad) return;
-    if (i >= N) { out[i] = make_float4(0.f, 0.f, 0.f, 1e30f); return; }
+    if (i < N) atomicAdd(&hist[point_cell(pts, i, lox, loy, loz, sx, sy, sz)], 1u);
+}
+__global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ hist) {
+    __shared__ unsigned part[1024];
+    constexpr int PER = SORT_CELLS / 1024;
+    unsigned loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { loc[k] = hist[threadIdx.x * PER + k]; sum += loc[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { hist[threadIdx.x * PER + k] = run; run += loc[k]; }
+}
+__global__ void cell_scatter_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
+                                    double sx, double sy, double sz, unsigned *__restrict__ cursor,
+                                    int32_t *__restrict__ perm) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) perm[atomicAdd(&cursor[point_cell(pts, i, lox, loy, loz, sx, sy, sz)], 1u)] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------ target preparation
+// Sorted target operand: row k holds point perm[k] as float4 (x', y', z', |t'|^2), centred on
+// c; pad rows can never win.  One bounding sphere per 16-row tile (centred coordinates);
+// radius < 0 marks a tile without real points.
+__global__ void pack_target_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm, int64_t N,
+                                   int64_t N_pad, double cx, double cy, double cz, float4 *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N_pad) return;
+    if (k >= N) { out[k] = make_float4(0.f, 0.f, 0.f, 1e30f); return; }
+    const int64_t i = perm[k];
     float x = (float)(pts[3 * i] - cx), y = (float)(pts[3 * i + 1] - cy), z = (float)(pts[3 * i + 2] - cz);
     double w = (double)x * x + (double)y * y + (double)z * z;
-    out[i] = make_float4(x, y, z, (float)w);
+    out[k] = make_float4(x, y, z, (float)w);
+}
+__global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int64_t n_tiles_all,
+                                   float4 *__restrict__ sph) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles_all) return;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    int n = 0;
+    for (int r = 0; r < 16; ++r) {
+        int64_t k = t * 16 + r;
+        if (k >= N) break;
+        const float4 p = t4[k];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+        ++n;
+    }
+    if (n == 0) { sph[t] = make_float4(0.f, 0.f, 0.f, -1.f); return; }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    float r2 = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const float4 p = t4[t * 16 + r];
+        const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+        r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+    }
+    sph[t] = make_float4(cx, cy, cz, sqrtf(r2) * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f);
 }
 
 // ------------------------------------------------------------------ transform + pack
 // mode 0: P <- T * src (first pass; T = init), mode 1: P <- upd * P.
-// box: target AABB (lo xyz, hi xyz); a point whose distance to it is > r has no neighbour
-// within r (d_nn >= d_box) and is written off as "no correspondence" right here.
-__global__ __launch_bounds__(256) void icp_transform_pack_kernel(
-    IcpState *__restrict__ st, int mode, const double *__restrict__ src, double *__restrict__ P, int64_t N,
-    float4 *__restrict__ B, float *__restrict__ eps, float *__restrict__ S, int32_t *__restrict__ list,
-    int32_t *__restrict__ idx_out, double *__restrict__ d2_out, float Tn, float T2, float r1, double r2cut,
-    double lox, double loy, double loz, double hix, double hiy, double hiz) {
-    if (st->done) return;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool cand = false;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (i < N) {
-        const double *M = mode == 0 ? st->T : st->upd;
-        const double *in = mode == 0 ? src : P;
-        double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-        double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
-        double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
-        double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
-        P[3 * i] = nx; P[3 * i + 1] = ny; P[3 * i + 2] = nz;
-        double ex = fmax(fmax(lox - nx, nx - hix), 0.0), ey = fmax(fmax(loy - ny, ny - hiy), 0.0),
-               ez = fmax(fmax(loz - nz, nz - hiz), 0.0);
-        cand = (ex * ex + ey * ey + ez * ez) <= r2cut;  // r2cut = r^2 (1 + 1e-12): rounding-safe
-        sx = (float)(nx - st->centroid[0]); sy = (float)(ny - st->centroid[1]); sz = (float)(nz - st->centroid[2]);
-        if (!cand) {
-            idx_out[i] = -1;
-            d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
-        }
+// A wave takes 128 consecutive points of the scene's spatial order (two per lane).  Points
+// farther than r from the target's bounding box (lo, hi) have no neighbour within r
+// (d_nn >= d_box) and are written off as "no correspondence" here.  If any point of the wave
+// survives, the wave claims one 128-slot scene block (atomic counter), compacts its survivors
+// into it, pads the rest with dummies (list = -1) and stores the block's bounding sphere --
+// so every scene block of the sweep is one compact patch of space.
+struct PackPoint {
+    bool cand;
+    int i;
+    float sx, sy, sz;
+};
+__device__ __forceinline__ PackPoint pack_one(const IcpState *__restrict__ st, int mode, const double *__restrict__ src,
+                                              double *__restrict__ P, const int32_t *__restrict__ perm, int64_t k,
+                                              int64_t N, int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
+                                              double r2cut, double lox, double loy, double loz, double hix, double hiy,
+                                              double hiz) {
+    PackPoint o;
+    o.cand = false; o.i = -1; o.sx = o.sy = o.sz = 0.f;
+    if (k >= N) return o;
+    const int64_t i = perm[k];
+    const double *M = mode == 0 ? st->T : st->upd;
+    const double *in = mode == 0 ? src : P;
+    double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+    double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+    double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+    P[3 * i] = nx; P[3 * i + 1] = ny; P[3 * i + 2] = nz;
+    double ex = fmax(fmax(lox - nx, nx - hix), 0.0), ey = fmax(fmax(loy - ny, ny - hiy), 0.0),
+           ez = fmax(fmax(loz - nz, nz - hiz), 0.0);
+    o.cand = (ex * ex + ey * ey + ez * ez) <= r2cut;  // r2cut = r^2 (1 + 1e-12): rounding-safe
+    o.i = (int)i;
+    o.sx = (float)(nx - st->centroid[0]); o.sy = (float)(ny - st->centroid[1]); o.sz = (float)(nz - st->centroid[2]);
+    if (!o.cand) {
+        idx_out[i] = -1;
+        d2_out[i] = __longlong_as_double(0x7FF0000000000000ll);
     }
-    // wave-aggregated append to the candidate list
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-    if (mask == 0) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __builtin_ctzll(mask)) base = atomicAdd(&st->n_cand, __builtin_popcountll(mask));
-    base = __shfl(base, __builtin_ctzll(mask), 64);
-    if (!cand) return;
-    const int slot = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    B[slot] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
+    return o;
+}
+__device__ __forceinline__ void pack_store(const PackPoint &p, int slot, float4 *__restrict__ B, float *__restrict__ eps,
+                                           float *__restrict__ S, int32_t *__restrict__ list, float Tn, float T2, float r1) {
+    B[slot] = make_float4(-2.0f * p.sx, -2.0f * p.sy, -2.0f * p.sz, 1.0f);
     // Error bound of the fp32 surrogate relative to the float64 distance, for points whose
     // nearest neighbour is closer than r1 (see DESIGN.md "NN filter bound"):
     //   eps = 2^-23 * (5 * (2*|s'|_1*Tn + T2) + 2*min(r1, |s'|_1 + Tn)*(Tn + |s'|_1))
-    float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
+    float s1 = fabsf(p.sx) + fabsf(p.sy) + fabsf(p.sz);
     float Mi = 2.0f * s1 * Tn + T2;
     eps[slot] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
-    S[slot] = sx * sx + sy * sy + sz * sz;
-    list[slot] = (int)i;
+    S[slot] = p.sx * p.sx + p.sy * p.sy + p.sz * p.sz;
+    list[slot] = p.i;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void icp_transform_pack_kernel(
+    IcpState *__restrict__ st, int mode, const double *__restrict__ src, double *__restrict__ P,
+    const int32_t *__restrict__ perm, int64_t N, float4 *__restrict__ B, float *__restrict__ eps, float *__restrict__ S,
+    int32_t *__restrict__ list, float4 *__restrict__ blk_sph, int32_t *__restrict__ idx_out,
+    double *__restrict__ d2_out, float Tn, float T2, float r1, double r2cut, double lox, double loy, double loz,
+    double hix, double hiy, double hiz) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t k0 = wave * 128 + lane;
+    const PackPoint p0 = pack_one(st, mode, src, P, perm, k0, N, idx_out, d2_out, r2cut, lox, loy, loz, hix, hiy, hiz);
+    const PackPoint p1 = pack_one(st, mode, src, P, perm, k0 + 64, N, idx_out, d2_out, r2cut, lox, loy, loz, hix, hiy, hiz);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0.cand), m1 = __builtin_amdgcn_ballot_w64(p1.cand);
+    const int c0 = __builtin_popcountll(m0), cnt = c0 + __builtin_popcountll(m1);
+    if (cnt == 0) return;  // wave-uniform
+    int blk = 0;
+    if (lane == 0) blk = atomicAdd(&st->n_blocks, 1);
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int base = blk * 128;
+    if (p0.cand) pack_store(p0, base + __builtin_popcountll(m0 & lt), B, eps, S, list, Tn, T2, r1);
+    if (p1.cand) pack_store(p1, base + c0 + __builtin_popcountll(m1 & lt), B, eps, S, list, Tn, T2, r1);
+    for (int s = cnt + lane; s < 128; s += 64) {  // dummies: never inliers, never selected
+        B[base + s] = make_float4(0.f, 0.f, 0.f, 1.f);
+        eps[base + s] = 0.f;
+        S[base + s] = 3e38f;
+        list[base + s] = -1;
+    }
+    // bounding sphere of the block's real points (centred fp32 coordinates)
+    const float big = 3e38f;
+    float lx = fminf(p0.cand ? p0.sx : big, p1.cand ? p1.sx : big), hx = fmaxf(p0.cand ? p0.sx : -big, p1.cand ? p1.sx : -big);
+    float ly = fminf(p0.cand ? p0.sy : big, p1.cand ? p1.sy : big), hy = fmaxf(p0.cand ? p0.sy : -big, p1.cand ? p1.sy : -big);
+    float lz = fminf(p0.cand ? p0.sz : big, p1.cand ? p1.sz : big), hz = fmaxf(p0.cand ? p0.sz : -big, p1.cand ? p1.sz : -big);
+    lx = wave_min_f32(lx); hx = wave_max_f32(hx);
+    ly = wave_min_f32(ly); hy = wave_max_f32(hy);
+    lz = wave_min_f32(lz); hz = wave_max_f32(hz);
+    if (lane == 0) {
+        const float cx = 0.5f * (lx + hx), cy = 0.5f * (ly + hy), cz = 0.5f * (lz + hz);
+        const float ex = hx - cx, ey = hy - cy, ez = hz - cz;
+        const float rad = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f;
+        blk_sph[blk] = make_float4(cx, cy, cz, rad);
+    }
 }
 
 // ------------------------------------------------------------------ NN sweep (MFMA)
@@ -148,21 +310,25 @@ __device__ __forceinline__ void lexmin(double &d, int &j, double od, int oj) {
     if (od < d || (od == d && oj < j)) { d = od; j = oj; }
 }
 
-// Work split, decided on the device from the candidate count: n_sb scene blocks of 128
-// points x n_ch target chunks, one wave each.  Chunks are multiples of NN_TU tiles.
+// Work split, decided on the device from the scene-block count: n_sb scene blocks of 128
+// slots x n_ch target chunks, one wave each.  Chunks are multiples of NN_TU tiles and hold at
+// most NN_CHUNK_TILES tiles (their survivor list lives in LDS).
 struct NnSplit {
     int n_sb, n_ch, tiles_per_chunk;
     int64_t stride;  // points per (chunk, lane group) plane of the triple arrays
 };
-__device__ __forceinline__ NnSplit nn_split(int count, int n_tiles, int total_waves, int64_t cap) {
+__device__ __forceinline__ NnSplit nn_split(int n_blocks, int n_tiles, int total_waves, int64_t cap) {
     NnSplit sp;
-    sp.n_sb = (count + NN_SB * 16 - 1) / (NN_SB * 16);
-    int ch = total_waves / (sp.n_sb > 0 ? sp.n_sb : 1);
-    int by_tiles = n_tiles / (4 * NN_TU);                                   // >= 16 tiles per chunk
-    int by_cap = (int)(cap / ((int64_t)(sp.n_sb > 0 ? sp.n_sb : 1) * NN_SB * 16));  // triple storage
+    sp.n_sb = n_blocks;
+    const int nsb = sp.n_sb > 0 ? sp.n_sb : 1;
+    int ch = total_waves / nsb;
+    const int by_tiles = n_tiles / (4 * NN_TU);                 // >= 16 tiles per chunk
+    const int by_cap = (int)(cap / ((int64_t)nsb * NN_SB * 16));  // triple storage
+    const int need = (n_tiles + NN_CHUNK_TILES - 1) / NN_CHUNK_TILES;  // LDS survivor list
     ch = ch < by_tiles ? ch : by_tiles;
     ch = ch < by_cap ? ch : by_cap;
     ch = ch < NN_MAX_CHUNKS ? ch : NN_MAX_CHUNKS;
+    ch = ch < need ? need : ch;  // the host sizes cap and NN_MAX_CHUNKS so this never conflicts
     ch = ch < 1 ? 1 : ch;
     int tpc = (n_tiles + ch - 1) / ch;
     tpc = (tpc + NN_TU - 1) / NN_TU * NN_TU;
@@ -172,16 +338,26 @@ __device__ __forceinline__ NnSplit nn_split(int count, int n_tiles, int total_wa
     return sp;
 }
 
-// Triples of wave (sb, ch): tr_b1 / tr_t1 / tr_b2 [(ch * 4 + q) * stride + point]
+// Triples of wave (sb, ch): tr_b1 / tr_t1 / tr_b2 [(ch * 4 + q) * stride + slot]
+//
+// Only target tiles that can hold a neighbour within r of some point of the scene block are
+// swept: tile t survives iff |c_block - c_tile| <= r + rad_block + rad_tile (bounding spheres,
+// margins included).  A tile that is skipped has all its points farther than r from all points
+// of the block, so it cannot contain the nearest neighbour of an INLIER; for a point without
+// any neighbour within r the answer is "no correspondence" whichever tiles were visited.  The
+// test runs lane-parallel over the chunk (one ballot per 64 tiles) into an LDS list, then the
+// software-pipelined MFMA loop walks the list.  With r = infinity (pedp_nn) nothing is skipped:
+// that is the dense all-pairs sweep.
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
-    const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64 */, int n_tiles,
-    const float *__restrict__ srcf /* compacted, N_s_pad x 4 */, float *__restrict__ tr_b1,
-    int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2, int64_t cap, int total_waves) {
+    const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64, sorted */, int n_tiles,
+    const float4 *__restrict__ tile_sph, const float *__restrict__ srcf /* slots x 4 */,
+    const float4 *__restrict__ blk_sph, float r_search, float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1,
+    float *__restrict__ tr_b2, int64_t cap, int total_waves, int32_t *__restrict__ wave_tiles) {
+    __shared__ unsigned surv[NN_WAVES][NN_CHUNK_TILES + 2 * NN_TU];
     if (st->done) return;
-    const int count = st->n_cand;
-    const NnSplit sp = nn_split(count, n_tiles, total_waves, cap);
-    const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * NN_WAVES + (threadIdx.x >> 6);
+    const NnSplit sp = nn_split(st->n_blocks, n_tiles, total_waves, cap);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * NN_WAVES + wv;
     // chunk-major: the 4 waves of a workgroup sweep the same target chunk (shared L1 lines)
     const int ch = w / (sp.n_sb > 0 ? sp.n_sb : 1), sb_id = w - ch * sp.n_sb;
     if (sp.n_sb == 0 || ch >= sp.n_ch) return;  // wave-uniform
@@ -189,7 +365,30 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const int frag = (lane & 15) * 4 + (lane >> 4);  // float offset inside a 16-point tile
     const int t0 = ch * sp.tiles_per_chunk;
     int t1e = t0 + sp.tiles_per_chunk;
-    if (t1e > n_tiles) t1e = n_tiles;  // n_tiles and the chunk size are multiples of NN_TU
+    if (t1e > n_tiles) t1e = n_tiles;
+
+    // ---- which tiles of this chunk can matter for this scene block
+    const float4 bs = blk_sph[sb_id];
+    unsigned *mine = surv[wv];
+    int n_s = 0;
+    for (int tb = t0; tb < t1e; tb += 64) {
+        const int t = tb + lane;
+        bool keep = false;
+        if (t < t1e) {
+            const float4 ts = tile_sph[t];
+            const float dx = ts.x - bs.x, dy = ts.y - bs.y, dz = ts.z - bs.z;
+            const float lim = r_search + bs.w + ts.w;
+            keep = (ts.w >= 0.f) && !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) mine[n_s + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned)t;
+        n_s += __builtin_popcountll(mask);
+    }
+    if (lane == 0) wave_tiles[w] = n_s;  // statistics (plain store: a single counter would serialise 4k atomics)
+    // pad to a multiple of NN_TU plus one prefetch batch with a tile that can never win
+    const int n_pad = (n_s + NN_TU - 1) / NN_TU * NN_TU;
+    if (lane < n_pad + NN_TU - n_s) mine[n_s + lane] = (unsigned)n_tiles;  // first pad tile (|t|^2 = 1e30)
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
 
     float b[NN_SB];
 #pragma unroll
@@ -197,64 +396,63 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     float b1[NN_SB], b2[NN_SB];
     int t1[NN_SB];
 #pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = t0; }
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = n_tiles; }
 
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float *ap = tgtf + (size_t)t0 * 64 + frag;
-    float a[NN_TU];
+    if (n_s > 0) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        unsigned tid[NN_TU], tidn[NN_TU];
+        float a[NN_TU];
 #pragma unroll
-    for (int u = 0; u < NN_TU; ++u) a[u] = ap[u * 64];
-    f32x4 acc[NN_SB];
+        for (int u = 0; u < NN_TU; ++u) { tid[u] = mine[u]; a[u] = tgtf[(size_t)tid[u] * 64 + frag]; }
+        f32x4 acc[NN_SB];
 #pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
-    for (int tile = t0; tile < t1e; tile += NN_TU) {
-        ap += NN_TU * 64;
-        float an[NN_TU];
+        for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
+        for (int k = 0; k < n_pad; k += NN_TU) {
+            float an[NN_TU];
 #pragma unroll
-        for (int u = 0; u < NN_TU; ++u) an[u] = ap[u * 64];  // next batch (pad tiles exist behind the end)
+            for (int u = 0; u < NN_TU; ++u) { tidn[u] = mine[k + NN_TU + u]; an[u] = tgtf[(size_t)tidn[u] * 64 + frag]; }
 #pragma unroll
-        for (int u = 0; u < NN_TU; ++u) {
-            const float a_next = (u + 1 < NN_TU) ? a[u + 1] : an[0];
+            for (int u = 0; u < NN_TU; ++u) {
+                const float a_next = (u + 1 < NN_TU) ? a[u + 1] : an[0];
+                const int tile = (int)tid[u];
 #pragma unroll
-            for (int sb = 0; sb < NN_SB; ++sb) {
-                // software pipeline: the matrix pipe works on tile+u+1 while the VALU folds tile+u
-                f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
-                const f32x4 cur = acc[sb];
+                for (int sb = 0; sb < NN_SB; ++sb) {
+                    // software pipeline: the matrix pipe works on the next tile while the VALU folds this one
+                    f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
+                    const f32x4 cur = acc[sb];
 #if PEDP_NN_EXPERIMENT == 1   /* MFMA only (wrong results): pure matrix-pipe rate of this loop shape */
-                b1[sb] = fminf(b1[sb], cur[0]);
-                acc[sb] = nxt;
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    b1[sb] = fminf(b1[sb], cur[0]);
+                    acc[sb] = nxt;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
 #elif PEDP_NN_EXPERIMENT == 2 /* 3-op epilogue (wrong results) */
-                float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
-                b1[sb] = fminf(b1[sb], v);
-                acc[sb] = nxt;
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
+                    b1[sb] = fminf(b1[sb], v);
+                    acc[sb] = nxt;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
 #else
-                float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
-                t1[sb] = v < b1[sb] ? tile + u : t1[sb];
-                b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
-                b1[sb] = fminf(b1[sb], v);
-                acc[sb] = nxt;
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // then its 6 VALU ops
+                    float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
+                    t1[sb] = v < b1[sb] ? tile : t1[sb];
+                    b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
+                    b1[sb] = fminf(b1[sb], v);
+                    acc[sb] = nxt;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // then its 6 VALU ops
 #endif
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < NN_TU; ++u) a[u] = an[u];
+            for (int u = 0; u < NN_TU; ++u) { a[u] = an[u]; tid[u] = tidn[u]; }
+        }
     }
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) {
-        const int64_t k = base + sb * 16 + j;
-        if (k < count) {
-            const size_t o = (size_t)(ch * 4 + q) * sp.stride + k;
-            tr_b1[o] = b1[sb];
-            tr_t1[o] = t1[sb];
-            tr_b2[o] = b2[sb];
-        }
+        const size_t o = (size_t)(ch * 4 + q) * sp.stride + (size_t)(base + sb * 16 + j);
+        tr_b1[o] = b1[sb];
+        tr_t1[o] = t1[sb];
+        tr_b2[o] = b2[sb];
     }
 }
 
@@ -264,18 +462,19 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
 // min); a second tile inside the window sends the point to nn_fallback.
 __global__ __launch_bounds__(256) void nn_select_kernel(
     IcpState *__restrict__ st, int n_tiles, int total_waves, int64_t cap, const float *__restrict__ tr_b1,
-    const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt, int64_t Nt,
-    const double *__restrict__ P, const float *__restrict__ eps, const float *__restrict__ S,
-    const int32_t *__restrict__ list, float r2f, int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
-    int32_t *__restrict__ fb_list) {
+    const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt,
+    const int32_t *__restrict__ tperm /* sorted row -> target index */, int64_t Nt, const double *__restrict__ P,
+    const float *__restrict__ eps, const float *__restrict__ S, const int32_t *__restrict__ list, float r2f,
+    int32_t *__restrict__ idx_out, double *__restrict__ d2_out, int32_t *__restrict__ fb_list) {
     if (st->done) return;
-    const int count = st->n_cand;
+    const int count = st->n_blocks * (NN_SB * 16);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = tid >> 2, gl = tid & 3;
     if ((tid & ~63) >= 4 * count) return;  // whole wave beyond the list
-    const bool live = k < count;
-    const int kk = live ? k : 0;
-    const NnSplit sp = nn_split(count, n_tiles, total_waves, cap);
+    const int kk = k < count ? k : 0;
+    const int i = k < count ? list[kk] : -1;
+    const bool live = i >= 0;  // dummies carry -1
+    const NnSplit sp = nn_split(st->n_blocks, n_tiles, total_waves, cap);
     const int groups = sp.n_ch * 4;
     float m = __uint_as_float(0x7F800000u), m2 = m;
     for (int g = gl; g < groups; g += 4) {
@@ -284,7 +483,6 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     }
     m = fminf(m, __shfl_xor(m, 1, 64)); m = fminf(m, __shfl_xor(m, 2, 64));
     m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
-    const int i = list[kk];
     const float e = eps[kk], Si = S[kk];
     const bool maybe = m + Si <= r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
     const float win = m + 2.0f * e;
@@ -298,7 +496,10 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row0 + r;
-                    if (row < Nt) lexmin(bd, bj, dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]), (int)row);
+                    if (row < Nt) {
+                        const int64_t j = tperm[row];
+                        lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
+                    }
                 }
             }
         }
@@ -321,24 +522,66 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     }
 }
 
-// One wave per ambiguous point: exact brute force in float64.
+// Statistics of the most recent sweep: total surviving tiles over its waves (one workgroup).
+__global__ __launch_bounds__(1024) void nn_stats_kernel(IcpState *__restrict__ st, int n_tiles, int total_waves,
+                                                         int64_t cap, const int32_t *__restrict__ wave_tiles) {
+    __shared__ long long part[16];
+    const NnSplit sp = nn_split(st->last_n_sb, n_tiles, total_waves, cap);
+    const int n_waves = sp.n_sb * sp.n_ch;
+    long long v = 0;
+    for (int w = threadIdx.x; w < n_waves; w += 1024) v += wave_tiles[w];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        st->last_tiles = t;
+    }
+}
+
+// One wave per ambiguous point: exact float64 search.  Only tiles whose bounding sphere comes
+// within r of the point can hold a neighbour within r, so lanes test tile spheres in parallel
+// and the wave scans the survivors' rows; with r = infinity (pedp_nn) that is every row.
 __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__restrict__ st,
                                                           const int32_t *__restrict__ fb_list,
-                                                          const double *__restrict__ tgt, int64_t Nt,
-                                                          const double *__restrict__ P,
+                                                          const double *__restrict__ tgt,
+                                                          const int32_t *__restrict__ tperm, int64_t Nt,
+                                                          const float4 *__restrict__ tile_sph, int n_tiles,
+                                                          float r_search, const double *__restrict__ P,
                                                           int32_t *__restrict__ idx_out,
                                                           double *__restrict__ d2_out) {
     if (st->done) return;
     const int lane = threadIdx.x & 63;
     const int n = st->fb_count;
+    const double cx = st->centroid[0], cy = st->centroid[1], cz = st->centroid[2];
     for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const int i = fb_list[w];
         const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
+        const float sx = (float)(px - cx), sy = (float)(py - cy), sz = (float)(pz - cz);
+        const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
         double bd = __longlong_as_double(0x7FF0000000000000ll);
         int bj = 0x7FFFFFFF;
-        for (int64_t row = lane; row < Nt; row += 64) {
-            double d = dist2(px, py, pz, tgt[3 * row], tgt[3 * row + 1], tgt[3 * row + 2]);
-            if (d < bd) { bd = d; bj = (int)row; }  // rows ascend per lane: ties keep the lower
+        for (int tb = 0; tb < n_tiles; tb += 64) {
+            const int t = tb + lane;
+            bool keep = false;
+            if (t < n_tiles) {
+                const float4 ts = tile_sph[t];
+                const float dx = ts.x - sx, dy = ts.y - sy, dz = ts.z - sz;
+                const float lim = r_search + ts.w + slack;
+                keep = (ts.w >= 0.f) && !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+            }
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+            while (mask != 0) {  // wave-uniform: lanes 0..15 take the rows of one surviving tile
+                const int tile = tb + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int64_t row = (int64_t)tile * 16 + (lane & 15);
+                if (lane < 16 && row < Nt) {
+                    const int64_t j = tperm[row];
+                    lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
+                }
+            }
         }
 #pragma unroll
         for (int off = 1; off <= 32; off <<= 1) {
@@ -600,10 +843,13 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *__restrict__ st
         __syncthreads();
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    st->sum_cand += st->n_cand;
+    st->sum_cand += (long long)st->n_blocks * (NN_SB * 16);
+    st->last_n_sb = st->n_blocks;
     st->sum_fb += st->fb_count;
     st->fb_count = 0;
     st->n_cand = 0;
+    st->n_blocks = 0;
+
     const double K = packet[28];
     double fit = 0.0, rmse = 0.0;
     if (K > 0.0) { fit = K / n_source; rmse = sqrt(packet[27] / K); }
@@ -669,10 +915,12 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct IcpWorkspace {
     IcpState *st;
     double *P, *d2, *partials, *packet, *trace;
-    float4 *B;
-    const float4 *tgt4;
+    float4 *B, *blk_sph;
+    const float4 *tgt4, *tile_sph;
+    const int32_t *src_perm, *tgt_perm;
     float *eps, *S;
-    int32_t *idx, *fb, *list;
+    int32_t *idx, *fb, *list, *wave_tiles;
+    int sweep_blocks;
     float *tr_b1, *tr_b2;
     int32_t *tr_t1;
     int64_t Ns_pad, Nt_pad, cap;
@@ -696,9 +944,17 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     size_t o_idx = take(sizeof(int32_t) * (size_t)w.Ns_pad);
     size_t o_fb = take(sizeof(int32_t) * (size_t)w.Ns_pad);
     size_t o_list = take(sizeof(int32_t) * (size_t)w.Ns_pad);
+    size_t o_bsph = take(sizeof(float4) * (size_t)(w.Ns_pad / 128 + 1));
+    size_t o_wt = 0;  // sized below, once cap is known
     // per-(point, lane group, chunk) triples: room for 4 groups x (points x chunks <= cap)
     w.total_waves = 16 * c->num_cus;  // 4 waves per SIMD when the split uses all of them
     w.cap = w.Ns_pad > (int64_t)w.total_waves * NN_SB * 16 ? w.Ns_pad : (int64_t)w.total_waves * NN_SB * 16;
+    {   // every chunk's survivor list must fit LDS: at least `need` chunks, for any block count
+        const int64_t need = (w.Nt_pad / 16 + NN_CHUNK_TILES - 1) / NN_CHUNK_TILES;
+        if (w.cap < w.Ns_pad * need) w.cap = w.Ns_pad * need;
+    }
+    w.sweep_blocks = (w.total_waves + NN_WAVES - 1) / NN_WAVES + (int)(w.cap / (NN_SB * 16) / NN_WAVES) + 1;
+    o_wt = take(sizeof(int32_t) * (size_t)w.sweep_blocks * NN_WAVES);
     size_t o_b1 = take(sizeof(float) * 4 * (size_t)w.cap);
     size_t o_t1 = take(sizeof(int32_t) * 4 * (size_t)w.cap);
     size_t o_b2 = take(sizeof(float) * 4 * (size_t)w.cap);
@@ -717,6 +973,8 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     w.idx = (int32_t *)(b + o_idx);
     w.fb = (int32_t *)(b + o_fb);
     w.list = (int32_t *)(b + o_list);
+    w.blk_sph = (float4 *)(b + o_bsph);
+    w.wave_tiles = (int32_t *)(b + o_wt);
     w.tr_b1 = (float *)(b + o_b1);
     w.tr_t1 = (int32_t *)(b + o_t1);
     w.tr_b2 = (float *)(b + o_b2);
@@ -732,31 +990,54 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     // not an inlier anyway); huge radii fall back to the cloud scale inside the kernel.
     const float r1 = (float)(r * 1.01);
     const double r2cut = r * r * (1.0 + 1e-12);
+    const float r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
     const int n_tiles = (int)(w.Nt_pad / 16);
     {
-        int64_t grid = (Ns + 255) / 256;
+        int64_t grid = (Ns + 511) / 512;  // 128 points per wave, 4 waves per workgroup
         hipLaunchKernelGGL(icp_transform_pack_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, mode,
-                           src->pts, w.P, Ns, w.B, w.eps, w.S, w.list, w.idx, w.d2, tp.Tn, tp.T2, r1, r2cut,
-                           tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
+                           src->pts, w.P, w.src_perm, Ns, w.B, w.eps, w.S, w.list, w.blk_sph, w.idx, w.d2, tp.Tn, tp.T2,
+                           r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
     }
     if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
-    // triple storage per group is `cap` points-times-chunks; the device-side split keeps
-    // (scene blocks x chunks) within it.
-    hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)((w.total_waves + NN_WAVES - 1) / NN_WAVES +
-                                                         (unsigned)(w.Ns_pad / NN_PTS_PER_WG))),
-                       dim3(NN_WAVES * 64), 0, c->stream, w.st, (const float *)w.tgt4, n_tiles, (const float *)w.B,
-                       w.tr_b1, w.tr_t1, w.tr_b2, w.cap, w.total_waves);
+    // triple storage per group is `cap` slots-times-chunks; the device-side split keeps
+    // (scene blocks x chunks) within it.  Launch enough waves for either extreme of the split.
+    hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)w.sweep_blocks), dim3(NN_WAVES * 64), 0, c->stream, w.st, (const float *)w.tgt4, n_tiles, w.tile_sph,
+                       (const float *)w.B, w.blk_sph, r_search, w.tr_b1, w.tr_t1, w.tr_b2, w.cap, w.total_waves, w.wave_tiles);
     if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
     {
         const float r2f = (float)(r * r) * 1.00001f;
-        int64_t grid = (4 * Ns + 255) / 256;
+        int64_t grid = (4 * w.Ns_pad + 255) / 256;
         hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, n_tiles,
-                           w.total_waves, w.cap, w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, Nt, w.P, w.eps, w.S, w.list, r2f,
-                           w.idx, w.d2, w.fb);
+                           w.total_waves, w.cap, w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S,
+                           w.list, r2f, w.idx, w.d2, w.fb);
     }
-    hipLaunchKernelGGL(nn_fallback_kernel, dim3(4 * c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, tgt->pts, Nt,
-                       w.P, w.idx, w.d2);
+    hipLaunchKernelGGL(nn_fallback_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, tgt->pts, w.tgt_perm,
+                       Nt, w.tile_sph, n_tiles, r_search, w.P, w.idx, w.d2);
     PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
+// Spatial order of a cloud (device counting sort), cached in the handle.
+int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
+    if (cl->perm || cl->N == 0) return PEDP_OK;
+    PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
+    unsigned *hist = nullptr;
+    PEDP_HIP_CHECK(hipMalloc((void **)&hist, sizeof(unsigned) * SORT_CELLS));
+    PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * SORT_CELLS, c->stream));
+    double sc[3];
+    for (int k = 0; k < 3; ++k) {
+        double ext = cl->hi[k] - cl->lo[k];
+        sc[k] = ext > 0.0 ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
+    }
+    const unsigned grid = (unsigned)((cl->N + 255) / 256);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1],
+                       cl->lo[2], sc[0], sc[1], sc[2], hist);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1],
+                       cl->lo[2], sc[0], sc[1], sc[2], hist, (int32_t *)cl->perm);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    PEDP_HIP_CHECK(hipFree(hist));
     return PEDP_OK;
 }
 
@@ -768,13 +1049,18 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     tp.T2 = tgt->T2;
     for (int k = 0; k < 3; ++k) { tp.lo[k] = tgt->lo[k]; tp.hi[k] = tgt->hi[k]; }
     if (tgt->tgt4) return PEDP_OK;
+    int rc = ensure_spatial_perm(c, tgt);
+    if (rc) return rc;
     // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
     PEDP_HIP_CHECK(hipMalloc(&tgt->tgt4, sizeof(float4) * (size_t)pad));
+    PEDP_HIP_CHECK(hipMalloc(&tgt->tile_sph, sizeof(float4) * (size_t)(pad / 16)));
     tgt->tgt4_pad = pad;
     int64_t grid = (pad + 255) / 256;
-    hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts, tgt->N, pad,
-                       tp.c[0], tp.c[1], tp.c[2], (float4 *)tgt->tgt4);
+    hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
+                       (const int32_t *)tgt->perm, tgt->N, pad, tp.c[0], tp.c[1], tp.c[2], (float4 *)tgt->tgt4);
+    hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((pad / 16 + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float4 *)tgt->tgt4, tgt->N, pad / 16, (float4 *)tgt->tile_sph);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -809,6 +1095,11 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     rc = ensure_target_pack(c, target, tp);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
+    w.tile_sph = (const float4 *)target->tile_sph;
+    w.tgt_perm = (const int32_t *)target->perm;
+    rc = ensure_spatial_perm(c, source);
+    if (rc) return rc;
+    w.src_perm = (const int32_t *)source->perm;
 
     IcpState h{};
     for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
@@ -843,12 +1134,16 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
                            prm->relative_rmse, trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
     }
+    if (!degenerate)
+        hipLaunchKernelGGL(nn_stats_kernel, dim3(1), dim3(1024), 0, c->stream, w.st, (int)(w.Nt_pad / 16), w.total_waves,
+                           w.cap, w.wave_tiles);
     PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     if (corr && Ns > 0) PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)Ns, hipMemcpyDeviceToHost, c->stream));
     if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
-    c->icp_last_cand = hp->sum_cand;
+    // (scene slot, target point) pairs the MFMAs evaluated: last sweep's tile count x passes
+    c->icp_last_cand = hp->last_tiles * 16 * (NN_SB * 16) * (hp->iters + 1);
     c->icp_last_fb = hp->sum_fb;
     c->icp_last_passes = hp->iters + 1;
     c->icp_last_nt = Nt;
@@ -886,6 +1181,11 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     rc = ensure_target_pack(c, target, tp);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
+    w.tile_sph = (const float4 *)target->tile_sph;
+    w.tgt_perm = (const int32_t *)target->perm;
+    rc = ensure_spatial_perm(c, source);
+    if (rc) return rc;
+    w.src_perm = (const int32_t *)source->perm;
     IcpState *hp = (IcpState *)c->pinned;
     IcpState h{};
     for (int k = 0; k < 16; ++k) { h.T[k] = T[k]; h.upd[k] = T[k]; }
@@ -904,7 +1204,7 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
 int pedp_icp_last_stats(pedp_ctx_t c, int64_t *passes, int64_t *pairs_swept, int64_t *fallback_points) {
     PEDP_REQUIRE(c, "pedp_icp_last_stats: null context");
     if (passes) *passes = c->icp_last_passes;
-    if (pairs_swept) *pairs_swept = c->icp_last_cand * c->icp_last_nt;
+    if (pairs_swept) *pairs_swept = c->icp_last_cand;
     if (fallback_points) *fallback_points = c->icp_last_fb;
     return PEDP_OK;
 }

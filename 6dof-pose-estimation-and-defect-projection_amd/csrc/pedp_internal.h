@@ -84,7 +84,11 @@ struct pedp_cloud_s {
     float Tn = 0.f;  // max |t'|_1
     float T2 = 0.f;  // max |t'|_2^2
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // axis-aligned bounding box of the points
-    // Built on first use as an ICP target: float4 (x', y', z', |t'|^2), padded.
+    // Built on first use in ICP: spatial order of the points (device int32[N]); as a target
+    // additionally the sorted float4 operand (x', y', z', |t'|^2), padded, and one bounding
+    // sphere per 16-row tile.
+    void *perm = nullptr;
     void *tgt4 = nullptr;
+    void *tile_sph = nullptr;
     int64_t tgt4_pad = 0;
 };

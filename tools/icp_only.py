@@ -1,0 +1,14 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pedp_hip import _lib, synth
+ctx = _lib.Context(0)
+f = synth.Frame("bench_100k")
+mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+depth = mesh.cast_rays(f.rays6, want_uv=False)["t_hit"]
+src = _lib.Cloud(ctx, f.scene(depth)); tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+for rep in range(3):
+    t0 = time.perf_counter()
+    r = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1)
+    t1 = time.perf_counter()
+    print(f"icp {1e3*(t1-t0):.2f} ms", _lib.icp_last_stats(ctx), r["fitness"], flush=True)
