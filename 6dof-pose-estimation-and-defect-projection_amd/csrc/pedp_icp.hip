@@ -38,6 +38,7 @@
 //                        fitness / rmse / convergence.
 #include "pedp_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #ifndef PEDP_NN_EXPERIMENT
@@ -53,8 +54,9 @@ constexpr int NN_SB = 8;    // scene blocks of 16 points per wave
 constexpr int NN_WAVES = 4;
 constexpr int NN_PTS_PER_WG = NN_SB * 16 * NN_WAVES;  // 512
 constexpr int NN_TU = 4;    // target tiles fetched ahead
-constexpr int NN_MAX_CHUNKS = 32;   // target chunks per scene block (device-chosen, <= this)
-constexpr int NN_CHUNK_TILES = 2048;  // most tiles a chunk may hold (survivor list lives in LDS)
+constexpr int NN_LIST = 2048;       // most tiles one sweep wave walks (its list lives in LDS)
+constexpr int SEG_MIN = 32;         // tiles per sweep segment at least
+constexpr int CULL_WORDS = 8;       // 64-tile mask words one cull wave fills
 constexpr int SORT_BITS = 5;          // spatial sort: 32^3 Hilbert-ordered cells over the cloud's bounding box
 constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
 constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
@@ -71,8 +73,8 @@ struct IcpState {
     int fb_count;
     int n_cand;   // slots of the compacted candidate list this pass (128 per scene block)
     int n_blocks; // scene blocks (one per transform wave with at least one candidate)
-    int last_n_sb, last_n_ch;  // split of the most recent sweep (statistics)
-    long long last_tiles;      // surviving (scene block, target tile) pairs of that sweep
+    int n_segs, seg_len;       // sweep segments of this pass and their length in tiles
+    long long sum_tiles;       // surviving (scene block, target tile) pairs, summed over passes
     long long sum_cand;  // statistics over the passes of this registration
     long long sum_fb;
 };
@@ -119,19 +121,35 @@ __device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z)
         h = (h << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
     return h;
 }
+// Cell of point i; points outside the region [lo, lo + extent) all share the extra bucket
+// SORT_CELLS (they are no ICP candidates; one bucket keeps them off the border cells).
 __device__ __forceinline__ unsigned point_cell(const double *__restrict__ pts, int64_t i, double lox, double loy,
                                                double loz, double sx, double sy, double sz) {
-    int qx = (int)((pts[3 * i] - lox) * sx), qy = (int)((pts[3 * i + 1] - loy) * sy), qz = (int)((pts[3 * i + 2] - loz) * sz);
-    const int top = (1 << SORT_BITS) - 1;
-    qx = qx < 0 ? 0 : (qx > top ? top : qx);
-    qy = qy < 0 ? 0 : (qy > top ? top : qy);
-    qz = qz < 0 ? 0 : (qz > top ? top : qz);
-    return hilbert3((unsigned)qx, (unsigned)qy, (unsigned)qz);
+    const double fx = (pts[3 * i] - lox) * sx, fy = (pts[3 * i + 1] - loy) * sy, fz = (pts[3 * i + 2] - loz) * sz;
+    const double top = (double)(1 << SORT_BITS);
+    if (!(fx >= 0.0 && fx < top && fy >= 0.0 && fy < top && fz >= 0.0 && fz < top)) return (unsigned)SORT_CELLS;
+    return hilbert3((unsigned)(int)fx, (unsigned)(int)fy, (unsigned)(int)fz);
+}
+// one atomic per wave for the (possibly huge) outside bucket, per-lane atomics for real cells
+__device__ __forceinline__ unsigned cell_add(unsigned *__restrict__ ctr, unsigned cell, bool active) {
+    const bool outside = active && cell == (unsigned)SORT_CELLS;
+    const unsigned long long om = __builtin_amdgcn_ballot_w64(outside);
+    unsigned res = 0;
+    if (om != 0ull) {
+        const int lane = threadIdx.x & 63, leader = __builtin_ctzll(om);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&ctr[SORT_CELLS], (unsigned)__builtin_popcountll(om));
+        base = __shfl(base, leader, 64);
+        if (outside) res = base + (unsigned)__builtin_popcountll(om & ((1ull << lane) - 1ull));
+    }
+    if (active && !outside) res = atomicAdd(&ctr[cell], 1u);
+    return res;
 }
 __global__ void cell_count_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
                                   double sx, double sy, double sz, unsigned *__restrict__ hist) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) atomicAdd(&hist[point_cell(pts, i, lox, loy, loz, sx, sy, sz)], 1u);
+    const bool active = i < N;
+    (void)cell_add(hist, active ? point_cell(pts, i, lox, loy, loz, sx, sy, sz) : 0u, active);
 }
 __global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ hist) {
     __shared__ unsigned part[1024];
@@ -150,12 +168,15 @@ __global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ 
     unsigned run = part[threadIdx.x] - sum;
 #pragma unroll
     for (int k = 0; k < PER; ++k) { hist[threadIdx.x * PER + k] = run; run += loc[k]; }
+    if (threadIdx.x == 1023) hist[SORT_CELLS] = run;  // the outside bucket follows all real cells
 }
 __global__ void cell_scatter_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
                                     double sx, double sy, double sz, unsigned *__restrict__ cursor,
                                     int32_t *__restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) perm[atomicAdd(&cursor[point_cell(pts, i, lox, loy, loz, sx, sy, sz)], 1u)] = (int32_t)i;
+    const bool active = i < N;
+    const unsigned at = cell_add(cursor, active ? point_cell(pts, i, lox, loy, loz, sx, sy, sz) : 0u, active);
+    if (active) perm[at] = (int32_t)i;
 }
 
 // ------------------------------------------------------------------ target preparation
@@ -289,19 +310,39 @@ __global__ __launch_bounds__(256) void icp_transform_pack_kernel(
         S[base + s] = 3e38f;
         list[base + s] = -1;
     }
-    // bounding sphere of the block's real points (centred fp32 coordinates)
+    // Bounding spheres of the block's eight 16-slot sub-blocks (centred fp32 coordinates).
+    // Consecutive NON-EMPTY cells of the space-filling curve can be far apart (the curve
+    // leaves a surface and re-enters it elsewhere), so one sphere per 128 slots can be huge;
+    // per sub-block the sweep keeps a target tile only if it is near SOME sub-block.
+    __shared__ float stage[4][3][128];
+    float (*sg)[128] = stage[threadIdx.x >> 6];
+    if (p0.cand) { const int sl = __builtin_popcountll(m0 & lt); sg[0][sl] = p0.sx; sg[1][sl] = p0.sy; sg[2][sl] = p0.sz; }
+    if (p1.cand) { const int sl = c0 + __builtin_popcountll(m1 & lt); sg[0][sl] = p1.sx; sg[1][sl] = p1.sy; sg[2][sl] = p1.sz; }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
     const float big = 3e38f;
-    float lx = fminf(p0.cand ? p0.sx : big, p1.cand ? p1.sx : big), hx = fmaxf(p0.cand ? p0.sx : -big, p1.cand ? p1.sx : -big);
-    float ly = fminf(p0.cand ? p0.sy : big, p1.cand ? p1.sy : big), hy = fmaxf(p0.cand ? p0.sy : -big, p1.cand ? p1.sy : -big);
-    float lz = fminf(p0.cand ? p0.sz : big, p1.cand ? p1.sz : big), hz = fmaxf(p0.cand ? p0.sz : -big, p1.cand ? p1.sz : -big);
-    lx = wave_min_f32(lx); hx = wave_max_f32(hx);
-    ly = wave_min_f32(ly); hy = wave_max_f32(hy);
-    lz = wave_min_f32(lz); hz = wave_max_f32(hz);
-    if (lane == 0) {
-        const float cx = 0.5f * (lx + hx), cy = 0.5f * (ly + hy), cz = 0.5f * (lz + hz);
-        const float ex = hx - cx, ey = hy - cy, ez = hz - cz;
-        const float rad = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f;
-        blk_sph[blk] = make_float4(cx, cy, cz, rad);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int sl = half * 64 + lane;
+        const bool real = sl < cnt;
+        const float x = real ? sg[0][sl] : 0.f, y = real ? sg[1][sl] : 0.f, z = real ? sg[2][sl] : 0.f;
+        float lx = real ? x : big, hx = real ? x : -big, ly = real ? y : big, hy = real ? y : -big, lz = real ? z : big,
+              hz = real ? z : -big;
+#pragma unroll
+        for (int off = 1; off <= 8; off <<= 1) {
+            lx = fminf(lx, __shfl_xor(lx, off, 64)); hx = fmaxf(hx, __shfl_xor(hx, off, 64));
+            ly = fminf(ly, __shfl_xor(ly, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64));
+            lz = fminf(lz, __shfl_xor(lz, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
+        }
+        if ((lane & 15) == 0) {
+            float4 sp = make_float4(0.f, 0.f, 0.f, -1.f);  // empty sub-block: matches nothing
+            if (hx >= lx) {
+                const float cx = 0.5f * (lx + hx), cy = 0.5f * (ly + hy), cz = 0.5f * (lz + hz);
+                const float ex = hx - cx, ey = hy - cy, ez = hz - cz;
+                sp = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f +
+                                                 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f);
+            }
+            blk_sph[(size_t)blk * NN_SB + (sl >> 4)] = sp;
+        }
     }
 }
 
@@ -310,81 +351,155 @@ __device__ __forceinline__ void lexmin(double &d, int &j, double od, int oj) {
     if (od < d || (od == d && oj < j)) { d = od; j = oj; }
 }
 
-// Work split, decided on the device from the scene-block count: n_sb scene blocks of 128
-// slots x n_ch target chunks, one wave each.  Chunks are multiples of NN_TU tiles and hold at
-// most NN_CHUNK_TILES tiles (their survivor list lives in LDS).
-struct NnSplit {
-    int n_sb, n_ch, tiles_per_chunk;
-    int64_t stride;  // points per (chunk, lane group) plane of the triple arrays
-};
-__device__ __forceinline__ NnSplit nn_split(int n_blocks, int n_tiles, int total_waves, int64_t cap) {
-    NnSplit sp;
-    sp.n_sb = n_blocks;
-    const int nsb = sp.n_sb > 0 ? sp.n_sb : 1;
-    int ch = total_waves / nsb;
-    const int by_tiles = n_tiles / (4 * NN_TU);                 // >= 16 tiles per chunk
-    const int by_cap = (int)(cap / ((int64_t)nsb * NN_SB * 16));  // triple storage
-    const int need = (n_tiles + NN_CHUNK_TILES - 1) / NN_CHUNK_TILES;  // LDS survivor list
-    ch = ch < by_tiles ? ch : by_tiles;
-    ch = ch < by_cap ? ch : by_cap;
-    ch = ch < NN_MAX_CHUNKS ? ch : NN_MAX_CHUNKS;
-    ch = ch < need ? need : ch;  // the host sizes cap and NN_MAX_CHUNKS so this never conflicts
-    ch = ch < 1 ? 1 : ch;
-    int tpc = (n_tiles + ch - 1) / ch;
-    tpc = (tpc + NN_TU - 1) / NN_TU * NN_TU;
-    sp.n_ch = (n_tiles + tpc - 1) / tpc;
-    sp.tiles_per_chunk = tpc;
-    sp.stride = (int64_t)sp.n_sb * NN_SB * 16;  // n_ch * stride <= cap by construction
-    return sp;
+// ---- 1. cull: which target tiles can matter for which scene block (bit mask per block) ----
+// Tile t survives for a block iff for some 16-slot sub-block |c_sub - c_tile| <= r + rad_sub +
+// rad_tile (bounding spheres, margins included).  A skipped tile has all its points farther
+// than r from all points of the block, so it cannot contain the nearest neighbour of an
+// INLIER; for a point without any neighbour within r the answer is "no correspondence"
+// whichever tiles were visited.  One wave per (block, CULL_WORDS x 64 tiles): lane l tests tile
+// base + l, the ballot IS the mask word.  With r = infinity (pedp_nn) every bit is set: the
+// dense all-pairs sweep.
+__global__ __launch_bounds__(256) void nn_cull_kernel(const IcpState *__restrict__ st, const float4 *__restrict__ tile_sph,
+                                                      int n_tiles, int n_words, const float4 *__restrict__ blk_sph,
+                                                      float r_search, unsigned long long *__restrict__ mask,
+                                                      int32_t *__restrict__ blk_cnt) {
+    if (st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int groups = (n_words + CULL_WORDS - 1) / CULL_WORDS;
+    const int blk = wg / groups, grp = wg - blk * groups;
+    if (blk >= st->n_blocks) return;  // wave-uniform
+    float4 bs[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) bs[sb] = blk_sph[(size_t)blk * NN_SB + sb];
+    int w1 = (grp + 1) * CULL_WORDS;
+    if (w1 > n_words) w1 = n_words;
+    int cnt = 0;
+    for (int wi = grp * CULL_WORDS; wi < w1; ++wi) {
+        const int t = wi * 64 + lane;
+        const float4 ts = tile_sph[t < n_tiles ? t : 0];
+        bool keep = false;
+#pragma unroll
+        for (int sb = 0; sb < NN_SB; ++sb) {
+            const float dx = ts.x - bs[sb].x, dy = ts.y - bs[sb].y, dz = ts.z - bs[sb].z;
+            const float lim = r_search + bs[sb].w + ts.w;
+            keep |= (bs[sb].w >= 0.f) & !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+        }
+        keep = keep && (t < n_tiles) && (ts.w >= 0.f);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) mask[(size_t)blk * n_words + wi] = m;
+        cnt += __builtin_popcountll(m);
+    }
+    if (lane == 0 && cnt > 0) atomicAdd(&blk_cnt[blk], cnt);
 }
 
-// Triples of wave (sb, ch): tr_b1 / tr_t1 / tr_b2 [(ch * 4 + q) * stride + slot]
-//
-// Only target tiles that can hold a neighbour within r of some point of the scene block are
-// swept: tile t survives iff |c_block - c_tile| <= r + rad_block + rad_tile (bounding spheres,
-// margins included).  A tile that is skipped has all its points farther than r from all points
-// of the block, so it cannot contain the nearest neighbour of an INLIER; for a point without
-// any neighbour within r the answer is "no correspondence" whichever tiles were visited.  The
-// test runs lane-parallel over the chunk (one ballot per 64 tiles) into an LDS list, then the
-// software-pipelined MFMA loop walks the list.  With r = infinity (pedp_nn) nothing is skipped:
-// that is the dense all-pairs sweep.
+// ---- 2. segments: cut every block's survivor list into pieces of seg_len tiles ----
+// One workgroup.  seg_len is chosen so that all pieces fit the segment table (max_segs) and
+// is at least SEG_MIN: heavy blocks simply get more pieces, so every sweep wave has the same
+// amount of work whatever the spatial distribution.
+__global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__ st, int32_t *__restrict__ blk_cnt,
+                                                          int32_t *__restrict__ blk_segstart, int32_t *__restrict__ seg_blk,
+                                                          int32_t *__restrict__ seg_rank0, int32_t *__restrict__ seg_n,
+                                                          int max_segs) {
+    if (st->done) return;
+    __shared__ long long red[16];
+    __shared__ int scan[1024];
+    __shared__ long long total_s;
+    const int nb = st->n_blocks, tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = tid * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    long long loc = 0;
+    for (int b = b0; b < b1; ++b) loc += blk_cnt[b];
+    long long v = loc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        long long t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        total_s = t;
+    }
+    __syncthreads();
+    const long long total = total_s;
+    long long room = (long long)max_segs - nb;
+    if (room < 1) room = 1;
+    long long sl = (total + room - 1) / room;
+    if (sl < SEG_MIN) sl = SEG_MIN;
+    sl = (sl + NN_TU - 1) / NN_TU * NN_TU;
+    if (sl > NN_LIST) sl = NN_LIST;  // cannot happen: the host sizes max_segs for the dense case
+    const int seg_len = (int)sl;
+    int mine = 0;
+    for (int b = b0; b < b1; ++b) mine += (blk_cnt[b] + seg_len - 1) / seg_len;
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    int at = scan[tid] - mine;
+    for (int b = b0; b < b1; ++b) {
+        const int c = blk_cnt[b];
+        blk_cnt[b] = 0;  // ready for the next pass
+        blk_segstart[b] = at;
+        for (int r0 = 0; r0 < c; r0 += seg_len) {
+            if (at < max_segs) { seg_blk[at] = b; seg_rank0[at] = r0; seg_n[at] = (c - r0 < seg_len) ? c - r0 : seg_len; }
+            ++at;
+        }
+    }
+    if (tid == 1023) {
+        blk_segstart[nb] = scan[1023];
+        st->n_segs = scan[1023] < max_segs ? scan[1023] : max_segs;
+        st->seg_len = seg_len;
+        st->sum_tiles += total;
+    }
+}
+
+// ---- 3. sweep: one wave per segment ----
+// Triples of segment s: tr_b1 / tr_t1 / tr_b2 [(s * 4 + q) * 128 + slot in block]
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64, sorted */, int n_tiles,
-    const float4 *__restrict__ tile_sph, const float *__restrict__ srcf /* slots x 4 */,
-    const float4 *__restrict__ blk_sph, float r_search, float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1,
-    float *__restrict__ tr_b2, int64_t cap, int total_waves, int32_t *__restrict__ wave_tiles) {
-    __shared__ unsigned surv[NN_WAVES][NN_CHUNK_TILES + 2 * NN_TU];
+    int n_words, const unsigned long long *__restrict__ mask, const int32_t *__restrict__ seg_blk,
+    const int32_t *__restrict__ seg_rank0, const int32_t *__restrict__ seg_n, const float *__restrict__ srcf /* slots x 4 */,
+    float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2) {
+    __shared__ unsigned surv[NN_WAVES][NN_LIST + 2 * NN_TU];
     if (st->done) return;
-    const NnSplit sp = nn_split(st->n_blocks, n_tiles, total_waves, cap);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x * NN_WAVES + wv;
-    // chunk-major: the 4 waves of a workgroup sweep the same target chunk (shared L1 lines)
-    const int ch = w / (sp.n_sb > 0 ? sp.n_sb : 1), sb_id = w - ch * sp.n_sb;
-    if (sp.n_sb == 0 || ch >= sp.n_ch) return;  // wave-uniform
-    const int64_t base = (int64_t)sb_id * (NN_SB * 16);
+    const int seg = blockIdx.x * NN_WAVES + wv;
+    if (seg >= st->n_segs) return;  // wave-uniform
+    const int blk = seg_blk[seg], r0 = seg_rank0[seg], n_s = seg_n[seg];
+    const int64_t base = (int64_t)blk * (NN_SB * 16);
     const int frag = (lane & 15) * 4 + (lane >> 4);  // float offset inside a 16-point tile
-    const int t0 = ch * sp.tiles_per_chunk;
-    int t1e = t0 + sp.tiles_per_chunk;
-    if (t1e > n_tiles) t1e = n_tiles;
 
-    // ---- which tiles of this chunk can matter for this scene block
-    const float4 bs = blk_sph[sb_id];
+    // ---- expand ranks [r0, r0 + n_s) of the block's mask into the LDS tile list
     unsigned *mine = surv[wv];
-    int n_s = 0;
-    for (int tb = t0; tb < t1e; tb += 64) {
-        const int t = tb + lane;
-        bool keep = false;
-        if (t < t1e) {
-            const float4 ts = tile_sph[t];
-            const float dx = ts.x - bs.x, dy = ts.y - bs.y, dz = ts.z - bs.z;
-            const float lim = r_search + bs.w + ts.w;
-            keep = (ts.w >= 0.f) && !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+    {
+        int running = 0;
+        const unsigned long long *mw = mask + (size_t)blk * n_words;
+        for (int wg = 0; wg < n_words && running < r0 + n_s; wg += 64) {
+            unsigned long long word = (wg + lane < n_words) ? mw[wg + lane] : 0ull;
+            const int pc = __builtin_popcountll(word);
+            int incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            int rank = running + incl - pc;
+            if (pc > 0 && rank < r0 + n_s && rank + pc > r0) {
+                const unsigned tile0 = (unsigned)(wg + lane) * 64u;
+                while (word != 0ull) {
+                    const int bit = __builtin_ctzll(word);
+                    word &= word - 1ull;
+                    if (rank >= r0 && rank < r0 + n_s) mine[rank - r0] = tile0 + (unsigned)bit;
+                    ++rank;
+                }
+            }
+            running += __shfl(incl, 63, 64);
         }
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) mine[n_s + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned)t;
-        n_s += __builtin_popcountll(mask);
     }
-    if (lane == 0) wave_tiles[w] = n_s;  // statistics (plain store: a single counter would serialise 4k atomics)
     // pad to a multiple of NN_TU plus one prefetch batch with a tile that can never win
     const int n_pad = (n_s + NN_TU - 1) / NN_TU * NN_TU;
     if (lane < n_pad + NN_TU - n_s) mine[n_s + lane] = (unsigned)n_tiles;  // first pad tile (|t|^2 = 1e30)
@@ -449,19 +564,20 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) {
-        const size_t o = (size_t)(ch * 4 + q) * sp.stride + (size_t)(base + sb * 16 + j);
+        const size_t o = ((size_t)seg * 4 + q) * (NN_SB * 16) + (size_t)(sb * 16 + j);
         tr_b1[o] = b1[sb];
         tr_t1[o] = t1[sb];
         tr_b2[o] = b2[sb];
     }
 }
 
-// Exact selection, four threads per candidate point (thread gl of a point walks groups gl,
-// gl+4, ...): window = min b1 + 2 eps; every (chunk, lane group) whose best tile is inside the
-// window has its 4 rows re-scored in float64 (the oracle's formula, lexicographic (d^2, index)
-// min); a second tile inside the window sends the point to nn_fallback.
+// ---- 4. exact selection, four threads per slot (thread gl of a slot reads lane group gl of
+// every segment of its block): window = min b1 + 2 eps; every (segment, lane group) whose best
+// tile is inside the window has its 4 rows re-scored in float64 (the oracle's formula,
+// lexicographic (d^2, index) min); a second tile inside the window sends the slot to
+// nn_fallback.
 __global__ __launch_bounds__(256) void nn_select_kernel(
-    IcpState *__restrict__ st, int n_tiles, int total_waves, int64_t cap, const float *__restrict__ tr_b1,
+    IcpState *__restrict__ st, const int32_t *__restrict__ blk_segstart, const float *__restrict__ tr_b1,
     const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt,
     const int32_t *__restrict__ tperm /* sorted row -> target index */, int64_t Nt, const double *__restrict__ P,
     const float *__restrict__ eps, const float *__restrict__ S, const int32_t *__restrict__ list, float r2f,
@@ -474,12 +590,13 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     const int kk = k < count ? k : 0;
     const int i = k < count ? list[kk] : -1;
     const bool live = i >= 0;  // dummies carry -1
-    const NnSplit sp = nn_split(st->n_blocks, n_tiles, total_waves, cap);
-    const int groups = sp.n_ch * 4;
+    const int blk = kk >> 7, slot = kk & 127;
+    const int s0 = blk_segstart[blk], s1 = blk_segstart[blk + 1];
     float m = __uint_as_float(0x7F800000u), m2 = m;
-    for (int g = gl; g < groups; g += 4) {
-        m = fminf(m, tr_b1[(size_t)g * sp.stride + kk]);
-        m2 = fminf(m2, tr_b2[(size_t)g * sp.stride + kk]);
+    for (int sg = s0; sg < s1; ++sg) {
+        const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
+        m = fminf(m, tr_b1[o]);
+        m2 = fminf(m2, tr_b2[o]);
     }
     m = fminf(m, __shfl_xor(m, 1, 64)); m = fminf(m, __shfl_xor(m, 2, 64));
     m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
@@ -490,9 +607,10 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     int bj = 0x7FFFFFFF;
     if (live && maybe) {
         const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
-        for (int g = gl; g < groups; g += 4) {
-            if (tr_b1[(size_t)g * sp.stride + kk] <= win) {
-                const int64_t row0 = (int64_t)tr_t1[(size_t)g * sp.stride + kk] * 16 + 4 * (g & 3);
+        for (int sg = s0; sg < s1; ++sg) {
+            const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
+            if (tr_b1[o] <= win) {
+                const int64_t row0 = (int64_t)tr_t1[o] * 16 + 4 * gl;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row0 + r;
@@ -517,67 +635,60 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
         } else {
             idx_out[i] = bj;
             d2_out[i] = bd;
-            if (m2 <= win) fb_list[atomicAdd(&st->fb_count, 1)] = i;  // ambiguous: exact brute force decides
+            if (m2 <= win) fb_list[atomicAdd(&st->fb_count, 1)] = kk;  // ambiguous: exact search decides
         }
     }
 }
 
-// Statistics of the most recent sweep: total surviving tiles over its waves (one workgroup).
-__global__ __launch_bounds__(1024) void nn_stats_kernel(IcpState *__restrict__ st, int n_tiles, int total_waves,
-                                                         int64_t cap, const int32_t *__restrict__ wave_tiles) {
-    __shared__ long long part[16];
-    const NnSplit sp = nn_split(st->last_n_sb, n_tiles, total_waves, cap);
-    const int n_waves = sp.n_sb * sp.n_ch;
-    long long v = 0;
-    for (int w = threadIdx.x; w < n_waves; w += 1024) v += wave_tiles[w];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long t = 0;
-        for (int k = 0; k < 16; ++k) t += part[k];
-        st->last_tiles = t;
-    }
-}
-
-// One wave per ambiguous point: exact float64 search.  Only tiles whose bounding sphere comes
-// within r of the point can hold a neighbour within r, so lanes test tile spheres in parallel
-// and the wave scans the survivors' rows; with r = infinity (pedp_nn) that is every row.
+// ---- 5. ambiguous slots: exact float64 search, one wave per slot.  Candidate tiles are the
+// block's surviving tiles (mask) that also come within r of THIS point (lane-parallel sphere
+// test per non-empty mask word); their rows are scanned four tiles at a time (16 lanes each).
 __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__restrict__ st,
                                                           const int32_t *__restrict__ fb_list,
+                                                          const int32_t *__restrict__ list,
+                                                          const unsigned long long *__restrict__ mask, int n_words,
+                                                          const float4 *__restrict__ tile_sph, float r_search,
                                                           const double *__restrict__ tgt,
                                                           const int32_t *__restrict__ tperm, int64_t Nt,
-                                                          const float4 *__restrict__ tile_sph, int n_tiles,
-                                                          float r_search, const double *__restrict__ P,
+                                                          const double *__restrict__ P,
                                                           int32_t *__restrict__ idx_out,
                                                           double *__restrict__ d2_out) {
     if (st->done) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & 15;
     const int n = st->fb_count;
     const double cx = st->centroid[0], cy = st->centroid[1], cz = st->centroid[2];
     for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
-        const int i = fb_list[w];
+        const int kk = fb_list[w];
+        const int i = list[kk];
+        const unsigned long long *mw = mask + (size_t)(kk >> 7) * n_words;
         const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
         const float sx = (float)(px - cx), sy = (float)(py - cy), sz = (float)(pz - cz);
         const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
         double bd = __longlong_as_double(0x7FF0000000000000ll);
         int bj = 0x7FFFFFFF;
-        for (int tb = 0; tb < n_tiles; tb += 64) {
-            const int t = tb + lane;
+        for (int wi = 0; wi < n_words; ++wi) {
+            const unsigned long long word = mw[wi];  // wave-uniform
+            if (word == 0ull) continue;
             bool keep = false;
-            if (t < n_tiles) {
-                const float4 ts = tile_sph[t];
+            if ((word >> lane) & 1ull) {
+                const float4 ts = tile_sph[wi * 64 + lane];
                 const float dx = ts.x - sx, dy = ts.y - sy, dz = ts.z - sz;
                 const float lim = r_search + ts.w + slack;
-                keep = (ts.w >= 0.f) && !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+                keep = !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
             }
-            unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-            while (mask != 0) {  // wave-uniform: lanes 0..15 take the rows of one surviving tile
-                const int tile = tb + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int64_t row = (int64_t)tile * 16 + (lane & 15);
-                if (lane < 16 && row < Nt) {
+            unsigned long long near = __builtin_amdgcn_ballot_w64(keep);
+            while (near != 0ull) {
+                int tile = -1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {  // peel up to four set bits, group g takes the g-th
+                    if (near != 0ull) {
+                        const int bit = __builtin_ctzll(near);
+                        near &= near - 1ull;
+                        if (g == grp) tile = wi * 64 + bit;
+                    }
+                }
+                const int64_t row = (int64_t)tile * 16 + sub;
+                if (tile >= 0 && row < Nt) {
                     const int64_t j = tperm[row];
                     lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
                 }
@@ -844,7 +955,6 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *__restrict__ st
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     st->sum_cand += (long long)st->n_blocks * (NN_SB * 16);
-    st->last_n_sb = st->n_blocks;
     st->sum_fb += st->fb_count;
     st->fb_count = 0;
     st->n_cand = 0;
@@ -919,17 +1029,29 @@ struct IcpWorkspace {
     const float4 *tgt4, *tile_sph;
     const int32_t *src_perm, *tgt_perm;
     float *eps, *S;
-    int32_t *idx, *fb, *list, *wave_tiles;
-    int sweep_blocks;
+    int32_t *idx, *fb, *list;
+    unsigned long long *mask;                         // [blocks_cap][n_words] surviving-tile bits
+    int32_t *blk_cnt, *blk_segstart;                  // [blocks_cap], [blocks_cap + 1]
+    int32_t *seg_blk, *seg_rank0, *seg_n;             // [max_segs]
     float *tr_b1, *tr_b2;
     int32_t *tr_t1;
-    int64_t Ns_pad, Nt_pad, cap;
-    int total_waves;
+    int64_t Ns_pad, Nt_pad, blocks_cap;
+    int n_words, max_segs;
 };
 
 int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorkspace &w) {
     w.Ns_pad = (int64_t)align_up((size_t)(Ns > 0 ? Ns : 1), NN_PTS_PER_WG);
     w.Nt_pad = (int64_t)align_up((size_t)(Nt > 0 ? Nt : 1), 16 * NN_TU);
+    w.blocks_cap = w.Ns_pad / (NN_SB * 16) + 1;
+    const int64_t n_tiles = w.Nt_pad / 16;
+    w.n_words = (int)((n_tiles + 63) / 64);
+    // segment table: enough pieces that even the dense case (every tile survives for every
+    // block) keeps a piece within the LDS list of one wave
+    int64_t ms = (w.blocks_cap * n_tiles + NN_LIST - 1) / NN_LIST + w.blocks_cap;
+    if (ms < 8192) ms = 8192;
+    PEDP_REQUIRE(ms < (int64_t)1 << 22, "pedp_icp: problem too large for the segment table (%lld x %lld points)",
+                 (long long)Ns, (long long)Nt);
+    w.max_segs = (int)ms;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_st = take(sizeof(IcpState));
@@ -944,20 +1066,17 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     size_t o_idx = take(sizeof(int32_t) * (size_t)w.Ns_pad);
     size_t o_fb = take(sizeof(int32_t) * (size_t)w.Ns_pad);
     size_t o_list = take(sizeof(int32_t) * (size_t)w.Ns_pad);
-    size_t o_bsph = take(sizeof(float4) * (size_t)(w.Ns_pad / 128 + 1));
-    size_t o_wt = 0;  // sized below, once cap is known
-    // per-(point, lane group, chunk) triples: room for 4 groups x (points x chunks <= cap)
-    w.total_waves = 16 * c->num_cus;  // 4 waves per SIMD when the split uses all of them
-    w.cap = w.Ns_pad > (int64_t)w.total_waves * NN_SB * 16 ? w.Ns_pad : (int64_t)w.total_waves * NN_SB * 16;
-    {   // every chunk's survivor list must fit LDS: at least `need` chunks, for any block count
-        const int64_t need = (w.Nt_pad / 16 + NN_CHUNK_TILES - 1) / NN_CHUNK_TILES;
-        if (w.cap < w.Ns_pad * need) w.cap = w.Ns_pad * need;
-    }
-    w.sweep_blocks = (w.total_waves + NN_WAVES - 1) / NN_WAVES + (int)(w.cap / (NN_SB * 16) / NN_WAVES) + 1;
-    o_wt = take(sizeof(int32_t) * (size_t)w.sweep_blocks * NN_WAVES);
-    size_t o_b1 = take(sizeof(float) * 4 * (size_t)w.cap);
-    size_t o_t1 = take(sizeof(int32_t) * 4 * (size_t)w.cap);
-    size_t o_b2 = take(sizeof(float) * 4 * (size_t)w.cap);
+    size_t o_bsph = take(sizeof(float4) * NN_SB * (size_t)w.blocks_cap);
+    size_t o_mask = take(sizeof(unsigned long long) * (size_t)w.blocks_cap * (size_t)w.n_words);
+    size_t o_bcnt = take(sizeof(int32_t) * (size_t)w.blocks_cap);
+    size_t o_bseg = take(sizeof(int32_t) * (size_t)(w.blocks_cap + 1));
+    size_t o_sblk = take(sizeof(int32_t) * (size_t)w.max_segs);
+    size_t o_srk = take(sizeof(int32_t) * (size_t)w.max_segs);
+    size_t o_sn = take(sizeof(int32_t) * (size_t)w.max_segs);
+    const size_t tr = (size_t)w.max_segs * 4 * (NN_SB * 16);
+    size_t o_b1 = take(sizeof(float) * tr);
+    size_t o_t1 = take(sizeof(int32_t) * tr);
+    size_t o_b2 = take(sizeof(float) * tr);
     int st = c->icp_ws.reserve(off);
     if (st) return st;
     char *b = (char *)c->icp_ws.ptr;
@@ -974,10 +1093,17 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorks
     w.fb = (int32_t *)(b + o_fb);
     w.list = (int32_t *)(b + o_list);
     w.blk_sph = (float4 *)(b + o_bsph);
-    w.wave_tiles = (int32_t *)(b + o_wt);
+    w.mask = (unsigned long long *)(b + o_mask);
+    w.blk_cnt = (int32_t *)(b + o_bcnt);
+    w.blk_segstart = (int32_t *)(b + o_bseg);
+    w.seg_blk = (int32_t *)(b + o_sblk);
+    w.seg_rank0 = (int32_t *)(b + o_srk);
+    w.seg_n = (int32_t *)(b + o_sn);
     w.tr_b1 = (float *)(b + o_b1);
     w.tr_t1 = (int32_t *)(b + o_t1);
     w.tr_b2 = (float *)(b + o_b2);
+    // the per-block survivor counters start at zero (the segment kernel re-zeroes them per pass)
+    PEDP_HIP_CHECK(hipMemsetAsync(w.blk_cnt, 0, sizeof(int32_t) * (size_t)w.blocks_cap, c->stream));
     return PEDP_OK;
 }
 
@@ -999,46 +1125,86 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
                            r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
     }
     if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
-    // triple storage per group is `cap` slots-times-chunks; the device-side split keeps
-    // (scene blocks x chunks) within it.  Launch enough waves for either extreme of the split.
-    hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)w.sweep_blocks), dim3(NN_WAVES * 64), 0, c->stream, w.st, (const float *)w.tgt4, n_tiles, w.tile_sph,
-                       (const float *)w.B, w.blk_sph, r_search, w.tr_b1, w.tr_t1, w.tr_b2, w.cap, w.total_waves, w.wave_tiles);
+    {
+        const int64_t groups = (w.n_words + CULL_WORDS - 1) / CULL_WORDS;
+        const int64_t waves = w.blocks_cap * groups;
+        hipLaunchKernelGGL(nn_cull_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, w.st, w.tile_sph,
+                           n_tiles, w.n_words, w.blk_sph, r_search, w.mask, w.blk_cnt);
+        hipLaunchKernelGGL(nn_segment_kernel, dim3(1), dim3(1024), 0, c->stream, w.st, w.blk_cnt, w.blk_segstart,
+                           w.seg_blk, w.seg_rank0, w.seg_n, w.max_segs);
+        hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)((w.max_segs + NN_WAVES - 1) / NN_WAVES)), dim3(NN_WAVES * 64),
+                           0, c->stream, w.st, (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0,
+                           w.seg_n, (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);
+    }
     if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
     {
         const float r2f = (float)(r * r) * 1.00001f;
         int64_t grid = (4 * w.Ns_pad + 255) / 256;
-        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, n_tiles,
-                           w.total_waves, w.cap, w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S,
-                           w.list, r2f, w.idx, w.d2, w.fb);
+        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,
+                           w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx, w.d2,
+                           w.fb);
     }
-    hipLaunchKernelGGL(nn_fallback_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, tgt->pts, w.tgt_perm,
-                       Nt, w.tile_sph, n_tiles, r_search, w.P, w.idx, w.d2);
+    hipLaunchKernelGGL(nn_fallback_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, w.list, w.mask,
+                       w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
 
-// Spatial order of a cloud (device counting sort), cached in the handle.
-int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
-    if (cl->perm || cl->N == 0) return PEDP_OK;
-    PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
+// Spatial order of a cloud (device counting sort), cached in the handle.  The 32^3 cells are
+// laid over `roi` (lo xyz, hi xyz), not over the whole cloud: for a scene cloud that is the
+// region the target can occupy (its bounding box + radius, moved into the scene frame with
+// the inverse of the first registration's init), so the resolution goes where candidate
+// points are; points outside are clamped to the border cells (they are no candidates).  The
+// order is rebuilt if a later call's region has moved by more than half its size.
+int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl, const double *roi) {
+    if (cl->N == 0) return PEDP_OK;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = roi ? roi[k] : cl->lo[k]; hi[k] = roi ? roi[3 + k] : cl->hi[k]; }
+    if (cl->perm) {
+        bool moved = false;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = cl->perm_hi[k] - cl->perm_lo[k];
+            if (std::fabs(0.5 * (lo[k] + hi[k]) - 0.5 * (cl->perm_lo[k] + cl->perm_hi[k])) > 0.5 * ext + 1e-12) moved = true;
+        }
+        if (!moved) return PEDP_OK;
+    } else {
+        PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
+    }
+    for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = lo[k]; cl->perm_hi[k] = hi[k]; }
     unsigned *hist = nullptr;
-    PEDP_HIP_CHECK(hipMalloc((void **)&hist, sizeof(unsigned) * SORT_CELLS));
-    PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * SORT_CELLS, c->stream));
+    PEDP_HIP_CHECK(hipMalloc((void **)&hist, sizeof(unsigned) * (SORT_CELLS + 1)));
+    PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (SORT_CELLS + 1), c->stream));
     double sc[3];
     for (int k = 0; k < 3; ++k) {
-        double ext = cl->hi[k] - cl->lo[k];
+        double ext = hi[k] - lo[k];
         sc[k] = ext > 0.0 ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
     }
     const unsigned grid = (unsigned)((cl->N + 255) / 256);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1],
-                       cl->lo[2], sc[0], sc[1], sc[2], hist);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2],
+                       sc[0], sc[1], sc[2], hist);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1],
-                       cl->lo[2], sc[0], sc[1], sc[2], hist, (int32_t *)cl->perm);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2],
+                       sc[0], sc[1], sc[2], hist, (int32_t *)cl->perm);
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     PEDP_HIP_CHECK(hipFree(hist));
     return PEDP_OK;
+}
+
+// Region of the scene frame the target can reach: corners of (target box + r) through inv(init).
+void scene_roi(pedp_cloud_t tgt, double r, const double init[16], double roi[6]) {
+    // init maps scene -> target: x_t = R x_s + t  =>  x_s = R^T (x_t - t)
+    const double rr = std::isfinite(r) && r < 1e15 ? r : 0.0;
+    for (int k = 0; k < 3; ++k) { roi[k] = 1e300; roi[3 + k] = -1e300; }
+    for (int corner = 0; corner < 8; ++corner) {
+        double p[3];
+        for (int k = 0; k < 3; ++k) p[k] = ((corner >> k) & 1 ? tgt->hi[k] + rr : tgt->lo[k] - rr) - init[4 * k + 3];
+        for (int k = 0; k < 3; ++k) {
+            const double v = init[0 * 4 + k] * p[0] + init[1 * 4 + k] * p[1] + init[2 * 4 + k] * p[2];
+            if (v < roi[k]) roi[k] = v;
+            if (v > roi[3 + k]) roi[3 + k] = v;
+        }
+    }
 }
 
 // Target-side operand of the sweep, built once per cloud and kept in the handle (the
@@ -1049,7 +1215,7 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     tp.T2 = tgt->T2;
     for (int k = 0; k < 3; ++k) { tp.lo[k] = tgt->lo[k]; tp.hi[k] = tgt->hi[k]; }
     if (tgt->tgt4) return PEDP_OK;
-    int rc = ensure_spatial_perm(c, tgt);
+    int rc = ensure_spatial_perm(c, tgt, nullptr);
     if (rc) return rc;
     // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
@@ -1097,8 +1263,12 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     w.tgt4 = (const float4 *)target->tgt4;
     w.tile_sph = (const float4 *)target->tile_sph;
     w.tgt_perm = (const int32_t *)target->perm;
-    rc = ensure_spatial_perm(c, source);
-    if (rc) return rc;
+    {
+        double roi[6];
+        scene_roi(target, r, init, roi);
+        rc = ensure_spatial_perm(c, source, roi);
+        if (rc) return rc;
+    }
     w.src_perm = (const int32_t *)source->perm;
 
     IcpState h{};
@@ -1134,16 +1304,12 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
                            prm->relative_rmse, trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
     }
-    if (!degenerate)
-        hipLaunchKernelGGL(nn_stats_kernel, dim3(1), dim3(1024), 0, c->stream, w.st, (int)(w.Nt_pad / 16), w.total_waves,
-                           w.cap, w.wave_tiles);
     PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     if (corr && Ns > 0) PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)Ns, hipMemcpyDeviceToHost, c->stream));
     if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
-    // (scene slot, target point) pairs the MFMAs evaluated: last sweep's tile count x passes
-    c->icp_last_cand = hp->last_tiles * 16 * (NN_SB * 16) * (hp->iters + 1);
+    c->icp_last_cand = hp->sum_tiles * 16 * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
     c->icp_last_fb = hp->sum_fb;
     c->icp_last_passes = hp->iters + 1;
     c->icp_last_nt = Nt;
@@ -1183,7 +1349,7 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     w.tgt4 = (const float4 *)target->tgt4;
     w.tile_sph = (const float4 *)target->tile_sph;
     w.tgt_perm = (const int32_t *)target->perm;
-    rc = ensure_spatial_perm(c, source);
+    rc = ensure_spatial_perm(c, source, nullptr);  // no radius: order over the whole cloud
     if (rc) return rc;
     w.src_perm = (const int32_t *)source->perm;
     IcpState *hp = (IcpState *)c->pinned;

@@ -88,6 +88,7 @@ struct pedp_cloud_s {
     // additionally the sorted float4 operand (x', y', z', |t'|^2), padded, and one bounding
     // sphere per 16-row tile.
     void *perm = nullptr;
+    double perm_lo[3] = {0, 0, 0}, perm_hi[3] = {0, 0, 0};  // region the spatial order was built over
     void *tgt4 = nullptr;
     void *tile_sph = nullptr;
     int64_t tgt4_pad = 0;
