@@ -593,10 +593,17 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     const int blk = kk >> 7, slot = kk & 127;
     const int s0 = blk_segstart[blk], s1 = blk_segstart[blk + 1];
     float m = __uint_as_float(0x7F800000u), m2 = m;
-    for (int sg = s0; sg < s1; ++sg) {
-        const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
-        m = fminf(m, tr_b1[o]);
-        m2 = fminf(m2, tr_b2[o]);
+    for (int sg = s0; sg < s1; sg += 4) {  // four segments per trip: eight loads in flight
+        float v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sq = sg + u < s1 ? sg + u : s1 - 1;
+            const size_t o = ((size_t)sq * 4 + gl) * (NN_SB * 16) + slot;
+            v1[u] = tr_b1[o];
+            v2[u] = tr_b2[o];
+        }
+        m = fminf(fminf(m, fminf(v1[0], v1[1])), fminf(v1[2], v1[3]));
+        m2 = fminf(fminf(m2, fminf(v2[0], v2[1])), fminf(v2[2], v2[3]));
     }
     m = fminf(m, __shfl_xor(m, 1, 64)); m = fminf(m, __shfl_xor(m, 2, 64));
     m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
@@ -938,18 +945,26 @@ __device__ void svd3_dev(const double *Ain, double *U, double *w, double *V) {
 
 // pass p (0 = initial correspondence pass).  Records fitness/rmse of the pass, decides
 // whether the loop ends, otherwise derives the next update from the packet.
-__global__ __launch_bounds__(64) void icp_solve_kernel(IcpState *__restrict__ st, double *__restrict__ packet,
-                                                       const double *__restrict__ partials, int pass, int max_iter,
-                                                       int estimator, double n_source, double rel_fitness,
-                                                       double rel_rmse, double *__restrict__ trace) {
+__global__ __launch_bounds__(256) void icp_solve_kernel(IcpState *__restrict__ st, double *__restrict__ packet,
+                                                        const double *__restrict__ partials, int pass, int max_iter,
+                                                        int estimator, double n_source, double rel_fitness,
+                                                        double rel_rmse, double *__restrict__ trace) {
     if (st->done) return;
     // single-GPU runs fold icp_reduce into this launch (partials != null); with an all-reduce
-    // hook the packet was reduced (and summed over ranks) before.
+    // hook the packet was reduced (and summed over ranks) before.  Fixed order: 8 slices of 32
+    // partials each, then the slices in order -- run-to-run bit-stable.
     if (partials) {
+        __shared__ double slice[8][32];
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double v = 0.0;
+        if (k < PACKET)
+            for (int b = part * (ACC_BLOCKS / 8); b < (part + 1) * (ACC_BLOCKS / 8); ++b) v += partials[(size_t)b * PACKET + k];
+        slice[part][k] = v;
+        __syncthreads();
         if (threadIdx.x < PACKET) {
-            double v = 0.0;
-            for (int b = 0; b < ACC_BLOCKS; ++b) v += partials[(size_t)b * PACKET + threadIdx.x];
-            packet[threadIdx.x] = v;
+            double t = 0.0;
+            for (int q = 0; q < 8; ++q) t += slice[q][threadIdx.x];
+            packet[threadIdx.x] = t;
         }
         __syncthreads();
     }
@@ -1299,7 +1314,7 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
             }
         }
         const double *fold = (!degenerate && !prm->allreduce) ? w.partials : nullptr;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.packet, fold, pass, max_iter,
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, c->stream, w.st, w.packet, fold, pass, max_iter,
                            prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
                            prm->relative_rmse, trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
