@@ -159,6 +159,7 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (cl->tgt4) (void)hipFree(cl->tgt4);
     if (cl->perm) (void)hipFree(cl->perm);
     if (cl->tile_sph) (void)hipFree(cl->tile_sph);
+    if (cl->tile_sph4) (void)hipFree(cl->tile_sph4);
     delete cl;
 }
 

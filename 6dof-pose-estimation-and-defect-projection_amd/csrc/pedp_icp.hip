@@ -53,10 +53,13 @@ constexpr int PACKET = 29;  // doubles per partial-sum packet
 constexpr int NN_SB = 8;    // scene blocks of 16 points per wave
 constexpr int NN_WAVES = 4;
 constexpr int NN_PTS_PER_WG = NN_SB * 16 * NN_WAVES;  // 512
-constexpr int NN_TU = 4;    // target tiles fetched ahead
-constexpr int NN_LIST = 2048;       // most tiles one sweep wave walks (its list lives in LDS)
-constexpr int SEG_MIN = 32;         // tiles per sweep segment at least
-constexpr int CULL_WORDS = 8;       // 64-tile mask words one cull wave fills
+constexpr int NN_TU = 4;    // rows are padded to multiples of 16 * NN_TU (= the largest unit)
+// A target UNIT is QT MFMA tiles (16 QT rows): the granularity of culling, of the sweep's
+// fold-and-compare epilogue and of the exact re-scoring.  QT = 1 inside a registration with a
+// finite radius (finest culling), QT = 4 for dense sweeps (3 instead of 6 VALU ops per MFMA).
+constexpr int NN_LIST_TILES = 2048; // most MFMA tiles one sweep wave walks (its unit list lives in LDS)
+constexpr int SEG_MIN_TILES = 32;   // MFMA tiles per sweep segment at least
+constexpr int CULL_WORDS = 8;       // 64-unit mask words one cull wave fills
 constexpr int SORT_BITS = 5;          // spatial sort: 32^3 Hilbert-ordered cells over the cloud's bounding box
 constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
 constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
@@ -181,8 +184,8 @@ __global__ void cell_scatter_kernel(const double *__restrict__ pts, int64_t N, d
 
 // ------------------------------------------------------------------ target preparation
 // Sorted target operand: row k holds point perm[k] as float4 (x', y', z', |t'|^2), centred on
-// c; pad rows can never win.  One bounding sphere per 16-row tile (centred coordinates);
-// radius < 0 marks a tile without real points.
+// c; pad rows can never win.  One bounding sphere per 64-row unit (centred coordinates);
+// radius < 0 marks a unit without real points.
 __global__ void pack_target_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm, int64_t N,
                                    int64_t N_pad, double cx, double cy, double cz, float4 *__restrict__ out) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,14 +196,14 @@ __global__ void pack_target_kernel(const double *__restrict__ pts, const int32_t
     double w = (double)x * x + (double)y * y + (double)z * z;
     out[k] = make_float4(x, y, z, (float)w);
 }
-__global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int64_t n_tiles_all,
+__global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int64_t n_units_all, int UNIT_ROWS,
                                    float4 *__restrict__ sph) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles_all) return;
+    if (t >= n_units_all) return;
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
     int n = 0;
-    for (int r = 0; r < 16; ++r) {
-        int64_t k = t * 16 + r;
+    for (int r = 0; r < UNIT_ROWS; ++r) {
+        int64_t k = t * UNIT_ROWS + r;
         if (k >= N) break;
         const float4 p = t4[k];
         lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
@@ -212,7 +215,7 @@ __global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int
     const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
     float r2 = 0.f;
     for (int r = 0; r < n; ++r) {
-        const float4 p = t4[t * 16 + r];
+        const float4 p = t4[t * UNIT_ROWS + r];
         const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
         r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
     }
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void nn_cull_kernel(const IcpState *__restrict
 __global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__ st, int32_t *__restrict__ blk_cnt,
                                                           int32_t *__restrict__ blk_segstart, int32_t *__restrict__ seg_blk,
                                                           int32_t *__restrict__ seg_rank0, int32_t *__restrict__ seg_n,
-                                                          int max_segs) {
+                                                          int max_segs, int SEG_MIN, int NN_LIST) {
     if (st->done) return;
     __shared__ long long red[16];
     __shared__ int scan[1024];
@@ -459,12 +462,13 @@ __global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__
 
 // ---- 3. sweep: one wave per segment ----
 // Triples of segment s: tr_b1 / tr_t1 / tr_b2 [(s * 4 + q) * 128 + slot in block]
+template <int QT>
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64, sorted */, int n_tiles,
     int n_words, const unsigned long long *__restrict__ mask, const int32_t *__restrict__ seg_blk,
     const int32_t *__restrict__ seg_rank0, const int32_t *__restrict__ seg_n, const float *__restrict__ srcf /* slots x 4 */,
     float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2) {
-    __shared__ unsigned surv[NN_WAVES][NN_LIST + 2 * NN_TU];
+    __shared__ unsigned surv[NN_WAVES][NN_LIST_TILES / QT + 8];
     if (st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int seg = blockIdx.x * NN_WAVES + wv;
@@ -500,39 +504,41 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
             running += __shfl(incl, 63, 64);
         }
     }
-    // pad to a multiple of NN_TU plus one prefetch batch with a tile that can never win
-    const int n_pad = (n_s + NN_TU - 1) / NN_TU * NN_TU;
-    if (lane < n_pad + NN_TU - n_s) mine[n_s + lane] = (unsigned)n_tiles;  // first pad tile (|t|^2 = 1e30)
+    // one pad unit behind the list for the prefetch of the last trip: rows that can never win
+    if (lane == 0) mine[n_s] = (unsigned)n_tiles;  // first pad unit (|t|^2 = 1e30)
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
 
     float b[NN_SB];
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) b[sb] = srcf[(base + sb * 16) * 4 + frag];
-    float b1[NN_SB], b2[NN_SB];
+    float b1[NN_SB], b2[NN_SB], vq[NN_SB];
     int t1[NN_SB];
 #pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = n_tiles; }
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; vq[sb] = b1[sb]; t1[sb] = n_tiles; }
 
     if (n_s > 0) {
+        // Per unit (QT = 4 MFMA tiles = 64 target rows): the 16 values a lane sees are folded
+        // with two v_min3 per MFMA, and only once per unit the running (best value, unit,
+        // second-best value) is updated: 3 VALU ops per MFMA instead of 6.  The matrix pipe works
+        // on the next tile while the VALU folds this one (software pipeline).
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        unsigned tid[NN_TU], tidn[NN_TU];
-        float a[NN_TU];
+        float a[QT];
+        unsigned unit = mine[0];
 #pragma unroll
-        for (int u = 0; u < NN_TU; ++u) { tid[u] = mine[u]; a[u] = tgtf[(size_t)tid[u] * 64 + frag]; }
+        for (int u = 0; u < QT; ++u) a[u] = tgtf[((size_t)unit * QT + u) * 64 + frag];
         f32x4 acc[NN_SB];
 #pragma unroll
         for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
-        for (int k = 0; k < n_pad; k += NN_TU) {
-            float an[NN_TU];
+        for (int k = 0; k < n_s; ++k) {
+            const unsigned unit_next = mine[k + 1];  // a pad unit follows the last real one
+            float an[QT];
 #pragma unroll
-            for (int u = 0; u < NN_TU; ++u) { tidn[u] = mine[k + NN_TU + u]; an[u] = tgtf[(size_t)tidn[u] * 64 + frag]; }
+            for (int u = 0; u < QT; ++u) an[u] = tgtf[((size_t)unit_next * QT + u) * 64 + frag];
 #pragma unroll
-            for (int u = 0; u < NN_TU; ++u) {
-                const float a_next = (u + 1 < NN_TU) ? a[u + 1] : an[0];
-                const int tile = (int)tid[u];
+            for (int u = 0; u < QT; ++u) {
+                const float a_next = (u + 1 < QT) ? a[u + 1] : an[0];
 #pragma unroll
                 for (int sb = 0; sb < NN_SB; ++sb) {
-                    // software pipeline: the matrix pipe works on the next tile while the VALU folds this one
                     f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
                     const f32x4 cur = acc[sb];
 #if PEDP_NN_EXPERIMENT == 1   /* MFMA only (wrong results): pure matrix-pipe rate of this loop shape */
@@ -540,25 +546,25 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
                     acc[sb] = nxt;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-#elif PEDP_NN_EXPERIMENT == 2 /* 3-op epilogue (wrong results) */
-                    float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
-                    b1[sb] = fminf(b1[sb], v);
-                    acc[sb] = nxt;
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
 #else
-                    float v = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
-                    t1[sb] = v < b1[sb] ? tile : t1[sb];
-                    b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
-                    b1[sb] = fminf(b1[sb], v);
+                    if (u == 0) vq[sb] = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
+                    else vq[sb] = fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), fminf(cur[2], cur[3]));
+                    if (u == QT - 1) {
+                        const float v = vq[sb];
+                        t1[sb] = v < b1[sb] ? (int)unit : t1[sb];
+                        b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
+                        b1[sb] = fminf(b1[sb], v);
+                    }
                     acc[sb] = nxt;
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // then its 6 VALU ops
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                    if (u == QT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // then its VALU ops
+                    else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
 #endif
                 }
             }
 #pragma unroll
-            for (int u = 0; u < NN_TU; ++u) { a[u] = an[u]; tid[u] = tidn[u]; }
+            for (int u = 0; u < QT; ++u) a[u] = an[u];
+            unit = unit_next;
         }
     }
     const int q = lane >> 4, j = lane & 15;
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
 // tile is inside the window has its 4 rows re-scored in float64 (the oracle's formula,
 // lexicographic (d^2, index) min); a second tile inside the window sends the slot to
 // nn_fallback.
+template <int QT>
 __global__ __launch_bounds__(256) void nn_select_kernel(
     IcpState *__restrict__ st, const int32_t *__restrict__ blk_segstart, const float *__restrict__ tr_b1,
     const int32_t *__restrict__ tr_t1, const float *__restrict__ tr_b2, const double *__restrict__ tgt,
@@ -617,13 +624,15 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
         for (int sg = s0; sg < s1; ++sg) {
             const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
             if (tr_b1[o] <= win) {
-                const int64_t row0 = (int64_t)tr_t1[o] * 16 + 4 * gl;
+                const int64_t row0 = (int64_t)tr_t1[o] * (16 * QT) + 4 * gl;  // lane group gl: rows 4gl..4gl+3 of each tile
+                for (int u = 0; u < QT; ++u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + r;
-                    if (row < Nt) {
-                        const int64_t j = tperm[row];
-                        lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = row0 + 16 * u + r;
+                        if (row < Nt) {
+                            const int64_t j = tperm[row];
+                            lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
+                        }
                     }
                 }
             }
@@ -650,6 +659,7 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
 // ---- 5. ambiguous slots: exact float64 search, one wave per slot.  Candidate tiles are the
 // block's surviving tiles (mask) that also come within r of THIS point (lane-parallel sphere
 // test per non-empty mask word); their rows are scanned four tiles at a time (16 lanes each).
+template <int QT>
 __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__restrict__ st,
                                                           const int32_t *__restrict__ fb_list,
                                                           const int32_t *__restrict__ list,
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__rest
                                                           int32_t *__restrict__ idx_out,
                                                           double *__restrict__ d2_out) {
     if (st->done) return;
-    const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & 15;
+    const int lane = threadIdx.x & 63;
     const int n = st->fb_count;
     const double cx = st->centroid[0], cy = st->centroid[1], cz = st->centroid[2];
     for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
@@ -684,18 +694,19 @@ __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__rest
                 keep = !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
             }
             unsigned long long near = __builtin_amdgcn_ballot_w64(keep);
-            while (near != 0ull) {
-                int tile = -1;
+            while (near != 0ull) {  // wave-uniform: 64 lanes = 64 rows = 64 / (16 QT) units per trip
+                constexpr int UPT = 64 / (16 * QT);  // units per trip
+                int unit = -1;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {  // peel up to four set bits, group g takes the g-th
+                for (int g = 0; g < UPT; ++g) {
                     if (near != 0ull) {
                         const int bit = __builtin_ctzll(near);
                         near &= near - 1ull;
-                        if (g == grp) tile = wi * 64 + bit;
+                        if (g == lane / (16 * QT)) unit = wi * 64 + bit;
                     }
                 }
-                const int64_t row = (int64_t)tile * 16 + sub;
-                if (tile >= 0 && row < Nt) {
+                const int64_t row = (int64_t)unit * (16 * QT) + (lane % (16 * QT));
+                if (unit >= 0 && row < Nt) {
                     const int64_t j = tperm[row];
                     lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
                 }
@@ -1052,17 +1063,20 @@ struct IcpWorkspace {
     int32_t *tr_t1;
     int64_t Ns_pad, Nt_pad, blocks_cap;
     int n_words, max_segs;
+    int qt;  // MFMA tiles per target unit for this call (1: culled registration, 4: dense sweep)
 };
 
-int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, IcpWorkspace &w) {
+int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w) {
+    w.qt = qt;
     w.Ns_pad = (int64_t)align_up((size_t)(Ns > 0 ? Ns : 1), NN_PTS_PER_WG);
     w.Nt_pad = (int64_t)align_up((size_t)(Nt > 0 ? Nt : 1), 16 * NN_TU);
     w.blocks_cap = w.Ns_pad / (NN_SB * 16) + 1;
-    const int64_t n_tiles = w.Nt_pad / 16;
+    const int64_t n_tiles = w.Nt_pad / (16 * qt);  // target units
     w.n_words = (int)((n_tiles + 63) / 64);
     // segment table: enough pieces that even the dense case (every tile survives for every
     // block) keeps a piece within the LDS list of one wave
-    int64_t ms = (w.blocks_cap * n_tiles + NN_LIST - 1) / NN_LIST + w.blocks_cap;
+    const int64_t list_units = NN_LIST_TILES / qt;
+    int64_t ms = (w.blocks_cap * n_tiles + list_units - 1) / list_units + w.blocks_cap;
     if (ms < 8192) ms = 8192;
     PEDP_REQUIRE(ms < (int64_t)1 << 22, "pedp_icp: problem too large for the segment table (%lld x %lld points)",
                  (long long)Ns, (long long)Nt);
@@ -1132,7 +1146,7 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     const float r1 = (float)(r * 1.01);
     const double r2cut = r * r * (1.0 + 1e-12);
     const float r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
-    const int n_tiles = (int)(w.Nt_pad / 16);
+    const int n_tiles = (int)(w.Nt_pad / (16 * w.qt));  // target units
     {
         int64_t grid = (Ns + 511) / 512;  // 128 points per wave, 4 waves per workgroup
         hipLaunchKernelGGL(icp_transform_pack_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, mode,
@@ -1140,27 +1154,32 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
                            r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
     }
     if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
+    const float r2f = (float)(r * r) * 1.00001f;
+    const unsigned sel_grid = (unsigned)((4 * w.Ns_pad + 255) / 256);
+    const unsigned sweep_grid = (unsigned)((w.max_segs + NN_WAVES - 1) / NN_WAVES);
     {
         const int64_t groups = (w.n_words + CULL_WORDS - 1) / CULL_WORDS;
         const int64_t waves = w.blocks_cap * groups;
         hipLaunchKernelGGL(nn_cull_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, w.st, w.tile_sph,
                            n_tiles, w.n_words, w.blk_sph, r_search, w.mask, w.blk_cnt);
         hipLaunchKernelGGL(nn_segment_kernel, dim3(1), dim3(1024), 0, c->stream, w.st, w.blk_cnt, w.blk_segstart,
-                           w.seg_blk, w.seg_rank0, w.seg_n, w.max_segs);
-        hipLaunchKernelGGL(nn_sweep_kernel, dim3((unsigned)((w.max_segs + NN_WAVES - 1) / NN_WAVES)), dim3(NN_WAVES * 64),
-                           0, c->stream, w.st, (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0,
-                           w.seg_n, (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);
+                           w.seg_blk, w.seg_rank0, w.seg_n, w.max_segs, SEG_MIN_TILES / w.qt, NN_LIST_TILES / w.qt);
     }
-    if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }
-    {
-        const float r2f = (float)(r * r) * 1.00001f;
-        int64_t grid = (4 * w.Ns_pad + 255) / 256;
-        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,
-                           w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx, w.d2,
-                           w.fb);
-    }
-    hipLaunchKernelGGL(nn_fallback_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, w.list, w.mask,
-                       w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);
+#define PEDP_NN_STAGE(QTV)                                                                                            \
+    do {                                                                                                              \
+        hipLaunchKernelGGL(nn_sweep_kernel<QTV>, dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,            \
+                           (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0, w.seg_n,         \
+                           (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);                                            \
+        if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }                       \
+        hipLaunchKernelGGL(nn_select_kernel<QTV>, dim3(sel_grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,       \
+                           w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx,   \
+                           w.d2, w.fb);                                                                               \
+        hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, w.list,     \
+                           w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);       \
+    } while (0)
+    if (w.qt == 4) PEDP_NN_STAGE(4);
+    else PEDP_NN_STAGE(1);
+#undef PEDP_NN_STAGE
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1236,12 +1255,15 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
     PEDP_HIP_CHECK(hipMalloc(&tgt->tgt4, sizeof(float4) * (size_t)pad));
     PEDP_HIP_CHECK(hipMalloc(&tgt->tile_sph, sizeof(float4) * (size_t)(pad / 16)));
+    PEDP_HIP_CHECK(hipMalloc(&tgt->tile_sph4, sizeof(float4) * (size_t)(pad / 64)));
     tgt->tgt4_pad = pad;
     int64_t grid = (pad + 255) / 256;
     hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
                        (const int32_t *)tgt->perm, tgt->N, pad, tp.c[0], tp.c[1], tp.c[2], (float4 *)tgt->tgt4);
     hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((pad / 16 + 255) / 256)), dim3(256), 0, c->stream,
-                       (const float4 *)tgt->tgt4, tgt->N, pad / 16, (float4 *)tgt->tile_sph);
+                       (const float4 *)tgt->tgt4, tgt->N, pad / 16, 16, (float4 *)tgt->tile_sph);
+    hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((pad / 64 + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float4 *)tgt->tgt4, tgt->N, pad / 64, 64, (float4 *)tgt->tile_sph4);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1268,15 +1290,20 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     const double r = prm->max_correspondence_distance;
     const double n_global = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
 
+    // unit size: fine units while the radius is small against the model (culling decides the
+    // cost), 64-row units when the sweep is dense anyway (cheaper epilogue)
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) diag2 += (target->hi[k] - target->lo[k]) * (target->hi[k] - target->lo[k]);
+    const int qt = (r * r < diag2 / 16.0) ? 1 : 4;
     IcpWorkspace w;
-    int rc = carve_workspace(c, Ns, Nt, max_iter, w);
+    int rc = carve_workspace(c, Ns, Nt, max_iter, qt, w);
     if (rc) return rc;
 
     TargetPrep tp;
     rc = ensure_target_pack(c, target, tp);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
-    w.tile_sph = (const float4 *)target->tile_sph;
+    w.tile_sph = (const float4 *)(qt == 4 ? target->tile_sph4 : target->tile_sph);
     w.tgt_perm = (const int32_t *)target->perm;
     {
         double roi[6];
@@ -1318,13 +1345,22 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
                            prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
                            prm->relative_rmse, trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
+        // Passes after convergence are no-ops on the device but still cost launches; with the
+        // early exit enabled, look at the flag every 8th pass (one 4-byte read-back, identical
+        // on every rank of a sharded run) and stop enqueuing once it is set.
+        if (prm->relative_fitness >= 0.0 && (pass & 7) == 7 && pass < max_iter) {
+            int *flag = (int *)((char *)c->pinned + 4096);
+            PEDP_HIP_CHECK(hipMemcpyAsync(flag, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (*flag) break;
+        }
     }
     PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     if (corr && Ns > 0) PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)Ns, hipMemcpyDeviceToHost, c->stream));
     if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
-    c->icp_last_cand = hp->sum_tiles * 16 * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
+    c->icp_last_cand = hp->sum_tiles * (16 * qt) * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
     c->icp_last_fb = hp->sum_fb;
     c->icp_last_passes = hp->iters + 1;
     c->icp_last_nt = Nt;
@@ -1356,13 +1392,13 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     if (source->N == 0) return PEDP_OK;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     IcpWorkspace w;
-    int rc = carve_workspace(c, source->N, target->N, 0, w);
+    int rc = carve_workspace(c, source->N, target->N, 0, 4, w);  // no radius: dense sweep, 64-row units
     if (rc) return rc;
     TargetPrep tp;
     rc = ensure_target_pack(c, target, tp);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
-    w.tile_sph = (const float4 *)target->tile_sph;
+    w.tile_sph = (const float4 *)target->tile_sph4;
     w.tgt_perm = (const int32_t *)target->perm;
     rc = ensure_spatial_perm(c, source, nullptr);  // no radius: order over the whole cloud
     if (rc) return rc;

@@ -90,6 +90,7 @@ struct pedp_cloud_s {
     void *perm = nullptr;
     double perm_lo[3] = {0, 0, 0}, perm_hi[3] = {0, 0, 0};  // region the spatial order was built over
     void *tgt4 = nullptr;
-    void *tile_sph = nullptr;
+    void *tile_sph = nullptr;   // one sphere per 16 sorted rows
+    void *tile_sph4 = nullptr;  // one sphere per 64 sorted rows
     int64_t tgt4_pad = 0;
 };

@@ -131,3 +131,53 @@ def test_refine_pose_with_icp_full_flow(oracle):
     assert np.array_equal(init, init_ref)                       # caller's matrix mutated the same way
     err = np.abs(np.linalg.inv(best.transformation) - f.T_gt).max()
     assert err < 0.5                                            # and it actually refines towards the truth (mm)
+
+
+def test_dist_hip_backend_single_rank(oracle):
+    """pedp_hip.dist with the product backend on one GPU (no process group): same answers as
+    the plain calls; exercises HipBackend (torch stream hand-over, device packet view)."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import dist as pdist
+    from pedp_hip import synth
+
+    f = _frame()
+    be = pdist.HipBackend(0)
+    t, ids = pdist.sharded_cast_rays(be, f.verts_posed, f.tris, f.rays6)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    assert np.array_equal(ids, ref["primitive_ids"]) and np.array_equal(t.view(np.uint32), ref["t_hit"].view(np.uint32))
+    scene = f.scene(ref["t_hit"])
+    res = pdist.sharded_registration_icp(be, scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iteration=5,
+                                         rel_fitness=-1, rel_rmse=-1)
+    ro = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=5, rel_fitness=-1, rel_rmse=-1)
+    assert res["fitness"] == ro["fitness"] and np.abs(res["T"] - ro["T"]).max() < 1e-5
+    # the all-reduce hook path (icp_reduce kernel + host callback) with an identity "collective"
+    seen = []
+
+    def fake_allreduce(ptr, n, stream):
+        pkt = be.packet_tensor(ptr, n)
+        torch.cuda.current_stream().synchronize()
+        seen.append(float(pkt[28].item()))      # correspondence count of this pass
+
+    from pedp_hip import _lib
+    r2 = _lib.icp(be.ctx, be.make_cloud(scene), be.make_cloud(f.model_points, f.normals), 10.0, f.icp_init(),
+                  max_iteration=5, relative_fitness=-1, relative_rmse=-1, allreduce=fake_allreduce,
+                  n_source_global=len(scene))
+    assert len(seen) == 6 and seen[-1] == round(ro["fitness"] * len(scene))
+    assert np.abs(r2["T"] - ro["T"]).max() < 1e-5
+
+
+def test_icp_with_shuffled_subsampled_target(oracle):
+    """preprocess_target subsamples the model with np.random.choice: a target in random order
+    (no spatial coherence in index order) must give the same exact correspondences."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    keep = np.random.default_rng(5).choice(len(f.model_points), 1500, replace=False)
+    model, normals = f.model_points[keep], f.normals[keep]
+    ctx = _lib.default_context()
+    res = _lib.icp(ctx, _lib.Cloud(ctx, scene), _lib.Cloud(ctx, model, normals), 12.0, f.icp_init(), max_iteration=8,
+                   relative_fitness=-1, relative_rmse=-1, want_corr=True)
+    ref = oracle.icp(scene, model, normals, 12.0, f.icp_init(), max_iter=8, rel_fitness=-1, rel_rmse=-1)
+    assert np.array_equal(res["corr"], ref["corr"]) and np.abs(res["T"] - ref["T"]).max() < 1e-5
