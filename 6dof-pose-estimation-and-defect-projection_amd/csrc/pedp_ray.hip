@@ -479,33 +479,43 @@ __device__ __forceinline__ float wave_min_f(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_cull_kernel(
-    const f2 *__restrict__ rec, const float *__restrict__ aos, const float4 *__restrict__ cones, int n_clusters,
-    const float *__restrict__ rays6, const unsigned *__restrict__ perm, int64_t N,
-    unsigned long long *__restrict__ keys, const int *__restrict__ shared_flag) {
-    if (*shared_flag == 0) return;
-    constexpr int PF = PAIR_SH / 2;
-    const int lane = threadIdx.x & 63;
-    const int64_t k = (int64_t)blockIdx.x * RPL_BLOCK + threadIdx.x;
-    const int64_t ri = perm[k < N ? k : N - 1];  // tail lanes re-run the last ray, never store
-    Ray r;
-    r.ox = rays6[6 * ri + 0]; r.oy = rays6[6 * ri + 1]; r.oz = rays6[6 * ri + 2];
-    r.dx = rays6[6 * ri + 3]; r.dy = rays6[6 * ri + 4]; r.dz = rays6[6 * ri + 5];
+// ---- culled sweep in three balanced steps ------------------------------------------------
+// 1. ray_cull_mask_kernel: one wave per packet (64 direction-sorted rays): cone of the packet,
+//    lane-parallel cluster tests, the ballot of 64 tests IS the mask word of surviving clusters.
+// 2. ray_segment_kernel: cuts every packet's survivor list into segments of seg_len clusters
+//    (>= RSEG_MIN, chosen on the device so all fit the table).  Packets that look along a
+//    surface see hundreds of clusters, most see none: without this step a few waves carried
+//    the kernel (0.52 ms); with it every sweep wave has the same amount of work.
+// 3. ray_sweep_seg_kernel: one wave per segment, ray per lane, the loop body of the exhaustive
+//    kernel on the segment's clusters; packets meet in the same 64-bit atomicMin keys.
+constexpr int RSEG_MIN = 16;    // clusters per segment at least (256 triangles)
+constexpr int RLIST = 2048;     // most clusters one sweep wave walks (LDS list)
 
-    // cone of this wave's rays: axis = normalised sum of unit directions, cos(theta) = min dot
-    const float inv = rsqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
-    const float ux = r.dx * inv, uy = r.dy * inv, uz = r.dz * inv;
+__global__ __launch_bounds__(256) void ray_cull_mask_kernel(const float4 *__restrict__ cones, int n_clusters,
+                                                            int n_words, const float *__restrict__ rays6,
+                                                            const unsigned *__restrict__ perm, int64_t N,
+                                                            unsigned long long *__restrict__ mask,
+                                                            int *__restrict__ pk_cnt, const int *__restrict__ shared_flag) {
+    if (*shared_flag == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t pk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pk * 64 >= N) return;
+    const int64_t k = pk * 64 + lane;
+    const int64_t ri = perm[k < N ? k : N - 1];
+    const float dx = rays6[6 * ri + 3], dy = rays6[6 * ri + 4], dz = rays6[6 * ri + 5];
+    // cone of this packet: axis = normalised sum of unit directions, cos(theta) = min dot
+    const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
     float ax = wave_sum_f(ux), ay = wave_sum_f(uy), az = wave_sum_f(uz);
     const float ainv = rsqrtf(ax * ax + ay * ay + az * az);
     ax *= ainv; ay *= ainv; az *= ainv;
-    float ct = wave_min_f(ux * ax + uy * ay + uz * az) - 1e-5f;  // margin: rsqrt + rounding
+    const float ct = wave_min_f(ux * ax + uy * ay + uz * az) - 1e-5f;  // margin: rsqrt + rounding
     // wide or degenerate (NaN) packets do not cull: every comparison below is then false
     const bool can_cull = ct > 0.1f;
     const float st = sqrtf(fmaxf(0.f, 1.0f - ct * ct)) + 1e-5f;
-
-    unsigned long long best = KEY_MISS;
-    for (int base = 0; base < n_clusters; base += 64) {
-        const int c = base + lane;
+    int cnt = 0;
+    for (int wi = 0; wi < n_words; ++wi) {
+        const int c = wi * 64 + lane;
         bool keep = false;
         if (c < n_clusters) {
             const float4 ca = cones[2 * c];
@@ -515,29 +525,129 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_cull_kernel(
             const bool culled = (ca.w > 1.5f) || (can_cull && ca.w > -1.5f && cosv < lim);
             keep = !culled;
         }
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        while (mask != 0) {  // wave-uniform loop over the surviving clusters
-            const int cl = base + __builtin_ctzll(mask);
-            mask &= mask - 1;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) mask[(size_t)pk * n_words + wi] = m;
+        cnt += __builtin_popcountll(m);
+    }
+    if (lane == 0) pk_cnt[pk] = cnt;
+}
+
+// seg_info[0] = number of segments, seg_info[1] = seg_len
+__global__ __launch_bounds__(1024) void ray_segment_kernel(const int *__restrict__ pk_cnt, int n_packets,
+                                                           int *__restrict__ seg_pk, int *__restrict__ seg_rank0,
+                                                           int *__restrict__ seg_n, int max_segs, int *__restrict__ seg_info,
+                                                           const int *__restrict__ shared_flag) {
+    if (*shared_flag == 0) { if (threadIdx.x == 0) seg_info[0] = 0; return; }
+    __shared__ long long red[16];
+    __shared__ int scan[1024];
+    __shared__ long long total_s;
+    const int tid = threadIdx.x;
+    const int per = (n_packets + 1023) / 1024;
+    const int b0 = tid * per, b1 = (b0 + per < n_packets) ? b0 + per : n_packets;
+    long long v = 0;
+    for (int b = b0; b < b1; ++b) v += pk_cnt[b];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        long long t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        total_s = t;
+    }
+    __syncthreads();
+    long long room = (long long)max_segs - n_packets;
+    if (room < 1) room = 1;
+    long long sl = (total_s + room - 1) / room;
+    if (sl < RSEG_MIN) sl = RSEG_MIN;
+    if (sl > RLIST) sl = RLIST;  // the host sizes max_segs so that this cannot bind
+    const int seg_len = (int)sl;
+    int mine = 0;
+    for (int b = b0; b < b1; ++b) mine += (pk_cnt[b] + seg_len - 1) / seg_len;
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    int at = scan[tid] - mine;
+    for (int b = b0; b < b1; ++b) {
+        const int c = pk_cnt[b];
+        for (int r0 = 0; r0 < c; r0 += seg_len) {
+            if (at < max_segs) { seg_pk[at] = b; seg_rank0[at] = r0; seg_n[at] = (c - r0 < seg_len) ? c - r0 : seg_len; }
+            ++at;
+        }
+    }
+    if (tid == 1023) { seg_info[0] = scan[1023] < max_segs ? scan[1023] : max_segs; seg_info[1] = seg_len; }
+}
+
+__global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
+    const f2 *__restrict__ rec, const float *__restrict__ aos, int n_words, const unsigned long long *__restrict__ mask,
+    const int *__restrict__ seg_pk, const int *__restrict__ seg_rank0, const int *__restrict__ seg_n,
+    const int *__restrict__ seg_info, const float *__restrict__ rays6, const unsigned *__restrict__ perm, int64_t N,
+    unsigned long long *__restrict__ keys) {
+    __shared__ unsigned surv[RPL_BLOCK / 64][RLIST];
+    constexpr int PF = PAIR_SH / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int seg = blockIdx.x * (RPL_BLOCK / 64) + wv;
+    if (seg >= seg_info[0]) return;  // wave-uniform
+    const int pk = seg_pk[seg], r0 = seg_rank0[seg], n_s = seg_n[seg];
+    const int64_t k = (int64_t)pk * 64 + lane;
+    const int64_t ri = perm[k < N ? k : N - 1];  // tail lanes re-run the last ray, never store
+    Ray r;
+    r.ox = rays6[6 * ri + 0]; r.oy = rays6[6 * ri + 1]; r.oz = rays6[6 * ri + 2];
+    r.dx = rays6[6 * ri + 3]; r.dy = rays6[6 * ri + 4]; r.dz = rays6[6 * ri + 5];
+    // expand ranks [r0, r0 + n_s) of the packet's mask into the LDS cluster list
+    unsigned *mine = surv[wv];
+    {
+        int running = 0;
+        const unsigned long long *mw = mask + (size_t)pk * n_words;
+        for (int wg = 0; wg < n_words && running < r0 + n_s; wg += 64) {
+            unsigned long long word = (wg + lane < n_words) ? mw[wg + lane] : 0ull;
+            const int pc = __builtin_popcountll(word);
+            int incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            int rank = running + incl - pc;
+            if (pc > 0 && rank < r0 + n_s && rank + pc > r0) {
+                const unsigned c0 = (unsigned)(wg + lane) * 64u;
+                while (word != 0ull) {
+                    const int bit = __builtin_ctzll(word);
+                    word &= word - 1ull;
+                    if (rank >= r0 && rank < r0 + n_s) mine[rank - r0] = c0 + (unsigned)bit;
+                    ++rank;
+                }
+            }
+            running += __shfl(incl, 63, 64);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    unsigned long long best = KEY_MISS;
+    for (int q = 0; q < n_s; ++q) {
+        const int cl = (int)__builtin_amdgcn_readfirstlane(mine[q]);  // wave-uniform: scalar record loads below
 #pragma unroll 1
-            for (int gi = 0; gi < CL_GROUPS; ++gi) {
-                const int g = cl * CL_GROUPS + gi;
-                const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
-                f2 sc[RPL_PAIRS];
+        for (int gi = 0; gi < CL_GROUPS; ++gi) {
+            const int g = cl * CL_GROUPS + gi;
+            const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
+            f2 sc[RPL_PAIRS];
 #pragma unroll
-                for (int p = 0; p < RPL_PAIRS; ++p) sc[p] = inside_score(eval_pair_shared(r, t + p * PF));
-                const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
-                if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {
-                    const int f0 = g * (2 * RPL_PAIRS);
+            for (int p = 0; p < RPL_PAIRS; ++p) sc[p] = inside_score(eval_pair_shared(r, t + p * PF));
+            const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
+            if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {
+                const int f0 = g * (2 * RPL_PAIRS);
 #pragma unroll
-                    for (int q = 0; q < 2 * RPL_PAIRS; ++q) {
-                        const float s = (q & 1) ? sc[q >> 1].y : sc[q >> 1].x;
-                        if (s >= 0.0f) {
-                            MT m = mt_eval(r, aos + (size_t)(f0 + q) * PEDP_TRI_STRIDE);
-                            if (mt_accept(m)) {
-                                unsigned long long key = mt_key(m, (unsigned)(f0 + q));
-                                best = key < best ? key : best;
-                            }
+                for (int e = 0; e < 2 * RPL_PAIRS; ++e) {
+                    const float s = (e & 1) ? sc[e >> 1].y : sc[e >> 1].x;
+                    if (s >= 0.0f) {
+                        MT m = mt_eval(r, aos + (size_t)(f0 + e) * PEDP_TRI_STRIDE);
+                        if (mt_accept(m)) {
+                            unsigned long long key = mt_key(m, (unsigned)(f0 + e));
+                            best = key < best ? key : best;
                         }
                     }
                 }
@@ -746,20 +856,35 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
     int variant = c->ray_variant;
     if (variant == 0) variant = (N < 16384) ? 2 : 3;
     if (variant == 1 || variant == 3) {
-        // aux layout: [flag + bounds: 256 B][shared pair records][cone records][hist][perm]
+        // aux layout: [flag + bounds + seg info: 256 B][shared pair records][cone records][hist][perm]
+        //             [packet masks][packet counts][segment table]
+        const int64_t n_packets = (N + 63) / 64;
+        const int n_cwords = (int)((mesh->n_clusters + 63) / 64);
+        int64_t max_segs = (n_packets * mesh->n_clusters + RLIST - 1) / RLIST + n_packets;
+        if (max_segs < 65536) max_segs = 65536;
+        PEDP_REQUIRE(max_segs < (int64_t)1 << 26, "pedp_raycast: problem too large for the segment table");
         const size_t sz_tri3 = align256(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2));
         const size_t sz_cone = align256(sizeof(float4) * 2 * (size_t)mesh->n_clusters);
         const size_t sz_hist = align256(sizeof(unsigned) * BIN_CELLS);
         const size_t sz_perm = align256(sizeof(unsigned) * (size_t)N);
-        st = c->ray_aux.reserve(256 + sz_tri3 + sz_cone + sz_hist + sz_perm);
+        const size_t sz_mask = align256(sizeof(unsigned long long) * (size_t)n_packets * (size_t)n_cwords);
+        const size_t sz_pcnt = align256(sizeof(int) * (size_t)n_packets);
+        const size_t sz_seg = align256(sizeof(int) * (size_t)max_segs);
+        st = c->ray_aux.reserve(256 + sz_tri3 + sz_cone + sz_hist + sz_perm + sz_mask + sz_pcnt + 3 * sz_seg);
         if (st) return st;
         char *aux = (char *)c->ray_aux.ptr;
         int *flag = (int *)aux;
         unsigned *bounds = (unsigned *)(aux + 16);
+        int *seg_info = (int *)(aux + 64);
         float *tri3 = (float *)(aux + 256);
         float4 *cones = (float4 *)(aux + 256 + sz_tri3);
         unsigned *hist = (unsigned *)(aux + 256 + sz_tri3 + sz_cone);
         unsigned *perm = (unsigned *)(aux + 256 + sz_tri3 + sz_cone + sz_hist);
+        unsigned long long *pmask = (unsigned long long *)(aux + 256 + sz_tri3 + sz_cone + sz_hist + sz_perm);
+        int *pk_cnt = (int *)((char *)pmask + sz_mask);
+        int *seg_pk = (int *)((char *)pk_cnt + sz_pcnt);
+        int *seg_rank0 = (int *)((char *)seg_pk + sz_seg);
+        int *seg_n = (int *)((char *)seg_rank0 + sz_seg);
         PEDP_HIP_CHECK(hipMemsetAsync(flag, 0xFF, sizeof(int), c->stream));
         hipLaunchKernelGGL(origin_check_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag);
         hipLaunchKernelGGL(pair_shared_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream,
@@ -789,9 +914,13 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
             hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, flag, hist);
             hipLaunchKernelGGL(ray_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
                                bounds, hist, perm);
-            hipLaunchKernelGGL(ray_sweep_cull_kernel, dim3((unsigned)ray_blocks), dim3(RPL_BLOCK), 0, c->stream,
-                               (const f2 *)tri3, mesh->tri, (const float4 *)cones, (int)mesh->n_clusters, d_rays, perm, N,
-                               keys, flag);
+            hipLaunchKernelGGL(ray_cull_mask_kernel, dim3((unsigned)((n_packets + 3) / 4)), dim3(256), 0, c->stream,
+                               (const float4 *)cones, (int)mesh->n_clusters, n_cwords, d_rays, perm, N, pmask, pk_cnt, flag);
+            hipLaunchKernelGGL(ray_segment_kernel, dim3(1), dim3(1024), 0, c->stream, pk_cnt, (int)n_packets, seg_pk,
+                               seg_rank0, seg_n, (int)max_segs, seg_info, flag);
+            hipLaunchKernelGGL(ray_sweep_seg_kernel, dim3((unsigned)((max_segs + 3) / 4)), dim3(RPL_BLOCK), 0, c->stream,
+                               (const f2 *)tri3, mesh->tri, n_cwords, pmask, seg_pk, seg_rank0, seg_n, seg_info, d_rays,
+                               perm, N, keys);
         } else {
             hipLaunchKernelGGL(ray_sweep_rpl_kernel<true>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
                                (const f2 *)tri3, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
