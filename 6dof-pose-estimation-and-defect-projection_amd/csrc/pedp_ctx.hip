@@ -79,6 +79,10 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < PEDP_MAX_SUB; ++k) {
+        if (c->sub[k]) pedp_ctx_destroy(c->sub[k]);
+        c->sub[k] = nullptr;
+    }
     c->ray_keys.release();
     c->ray_in.release();
     c->ray_out.release();

@@ -1272,10 +1272,21 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
 
 extern "C" {
 
-int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
-             const double init[16], double T_out[16], double *fitness, double *inlier_rmse,
-             int32_t *n_iter_done, int32_t *corr, double *trace) {
-    PEDP_REQUIRE(c && source && target && prm && init && T_out, "pedp_icp: null argument");
+}  // extern "C"
+
+namespace {
+
+// One registration = enqueue (all passes, on the executor's stream and workspace) + collect
+// (one synchronisation, results to the host).  The executor is the clouds' own context for
+// pedp_icp and one of its sub-contexts (own stream + workspace) for pedp_icp_batched, where
+// several registrations are in flight at once.
+struct IcpJob {
+    IcpWorkspace w;
+    int max_iter = 0, qt = 1;
+    int64_t Ns = 0, Nt = 0;
+};
+
+int icp_check_args(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm) {
     PEDP_REQUIRE(source->ctx == c && target->ctx == c, "pedp_icp: cloud belongs to another context");
     PEDP_REQUIRE(prm->estimator == PEDP_POINT_TO_PLANE || prm->estimator == PEDP_POINT_TO_POINT,
                  "pedp_icp: unknown estimator %d", prm->estimator);
@@ -1284,33 +1295,52 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
         pedp_set_error("pedp_icp: TransformationEstimationPointToPlane requires target normals");
         return PEDP_ERR_NO_NORMALS;
     }
-    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    return PEDP_OK;
+}
+
+// unit size: fine units while the radius is small against the model (culling decides the
+// cost), 64-row units when the sweep is dense anyway (cheaper epilogue)
+int icp_unit_size(pedp_cloud_t target, double r) {
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) diag2 += (target->hi[k] - target->lo[k]) * (target->hi[k] - target->lo[k]);
+    return (r * r < diag2 / 16.0) ? 1 : 4;
+}
+
+// Cached per-cloud preparation on the owner's stream: sorted target operand + unit spheres,
+// spatial order of the scene over the region the target can reach from `init`.
+int icp_prepare(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, double r, const double *inits, int B, TargetPrep &tp) {
+    int rc = ensure_target_pack(c, target, tp);
+    if (rc) return rc;
+    double roi[6];
+    scene_roi(target, r, inits, roi);
+    for (int b = 1; b < B; ++b) {  // a batch orders the scene over the union of its start poses
+        double rb[6];
+        scene_roi(target, r, inits + 16 * b, rb);
+        for (int k = 0; k < 3; ++k) {
+            roi[k] = rb[k] < roi[k] ? rb[k] : roi[k];
+            roi[3 + k] = rb[3 + k] > roi[3 + k] ? rb[3 + k] : roi[3 + k];
+        }
+    }
+    return ensure_spatial_perm(c, source, roi);
+}
+
+int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
+                const pedp_icp_params *prm, const double init[16], bool want_trace, bool early_stop, IcpJob &job) {
+    PEDP_HIP_CHECK(hipSetDevice(x->device));
     const int64_t Ns = source->N, Nt = target->N;
     const int max_iter = prm->max_iteration;
     const double r = prm->max_correspondence_distance;
     const double n_global = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
-
-    // unit size: fine units while the radius is small against the model (culling decides the
-    // cost), 64-row units when the sweep is dense anyway (cheaper epilogue)
-    double diag2 = 0.0;
-    for (int k = 0; k < 3; ++k) diag2 += (target->hi[k] - target->lo[k]) * (target->hi[k] - target->lo[k]);
-    const int qt = (r * r < diag2 / 16.0) ? 1 : 4;
-    IcpWorkspace w;
-    int rc = carve_workspace(c, Ns, Nt, max_iter, qt, w);
-    if (rc) return rc;
-
-    TargetPrep tp;
-    rc = ensure_target_pack(c, target, tp);
+    job.max_iter = max_iter;
+    job.Ns = Ns;
+    job.Nt = Nt;
+    job.qt = icp_unit_size(target, r);
+    IcpWorkspace &w = job.w;
+    int rc = carve_workspace(x, Ns, Nt, max_iter, job.qt, w);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
-    w.tile_sph = (const float4 *)(qt == 4 ? target->tile_sph4 : target->tile_sph);
+    w.tile_sph = (const float4 *)(job.qt == 4 ? target->tile_sph4 : target->tile_sph);
     w.tgt_perm = (const int32_t *)target->perm;
-    {
-        double roi[6];
-        scene_roi(target, r, init, roi);
-        rc = ensure_spatial_perm(c, source, roi);
-        if (rc) return rc;
-    }
     w.src_perm = (const int32_t *)source->perm;
 
     IcpState h{};
@@ -1318,69 +1348,130 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
     // Open3D: max_correspondence_distance <= 0 or an empty cloud gives an empty result
     const bool degenerate = (r <= 0.0 || Ns == 0 || Nt == 0);
-    IcpState *hp = (IcpState *)c->pinned;
+    IcpState *hp = (IcpState *)x->pinned;
     *hp = h;
-    PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+    PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, x->stream));
     const double r2 = r * r;
     for (int pass = 0; pass <= max_iter; ++pass) {
         if (!degenerate) {
-            rc = enqueue_nn_pass(c, w, source, target, pass == 0 ? 0 : 1, tp, r, false);
+            rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, false);
             if (rc) return rc;
-            hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, c->stream, w.st,
+            hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, x->stream, w.st,
                                prm->estimator, w.P, Ns, target->pts, target->normals, w.idx, w.d2, r2, w.partials);
-            if (prm->allreduce) hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, c->stream, w.st, w.partials, w.packet);
+            if (prm->allreduce) hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, x->stream, w.st, w.partials, w.packet);
         } else {
-            PEDP_HIP_CHECK(hipMemsetAsync(w.packet, 0, sizeof(double) * 32, c->stream));
-            if (pass == 0 && Ns > 0) PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, c->stream));
+            PEDP_HIP_CHECK(hipMemsetAsync(w.packet, 0, sizeof(double) * 32, x->stream));
+            if (pass == 0 && Ns > 0) PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, x->stream));
         }
         if (prm->allreduce) {
-            if (prm->allreduce(prm->allreduce_user, w.packet, PACKET, (void *)c->stream) != 0) {
+            if (prm->allreduce(prm->allreduce_user, w.packet, PACKET, (void *)x->stream) != 0) {
                 pedp_set_error("pedp_icp: all-reduce hook failed in pass %d", pass);
-                (void)hipStreamSynchronize(c->stream);
+                (void)hipStreamSynchronize(x->stream);
                 return PEDP_ERR_COLLECTIVE;
             }
         }
         const double *fold = (!degenerate && !prm->allreduce) ? w.partials : nullptr;
-        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, c->stream, w.st, w.packet, fold, pass, max_iter,
+        hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, x->stream, w.st, w.packet, fold, pass, max_iter,
                            prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
-                           prm->relative_rmse, trace ? w.trace : nullptr);
+                           prm->relative_rmse, want_trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
         // Passes after convergence are no-ops on the device but still cost launches; with the
         // early exit enabled, look at the flag every 8th pass (one 4-byte read-back, identical
         // on every rank of a sharded run) and stop enqueuing once it is set.
-        if (prm->relative_fitness >= 0.0 && (pass & 7) == 7 && pass < max_iter) {
-            int *flag = (int *)((char *)c->pinned + 4096);
-            PEDP_HIP_CHECK(hipMemcpyAsync(flag, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (early_stop && prm->relative_fitness >= 0.0 && (pass & 7) == 7 && pass < max_iter) {
+            int *flag = (int *)((char *)x->pinned + 4096);
+            PEDP_HIP_CHECK(hipMemcpyAsync(flag, &w.st->done, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+            PEDP_HIP_CHECK(hipStreamSynchronize(x->stream));
             if (*flag) break;
         }
     }
-    PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
-    if (corr && Ns > 0) PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)Ns, hipMemcpyDeviceToHost, c->stream));
-    if (trace) PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(max_iter + 1), hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    PEDP_HIP_CHECK(hipMemcpyAsync(hp, w.st, sizeof(IcpState), hipMemcpyDeviceToHost, x->stream));
+    return PEDP_OK;
+}
+
+int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitness, double *inlier_rmse,
+                int32_t *n_iter_done, int32_t *corr, double *trace) {
+    PEDP_HIP_CHECK(hipSetDevice(x->device));
+    const IcpWorkspace &w = job.w;
+    if (corr && job.Ns > 0)
+        PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)job.Ns, hipMemcpyDeviceToHost, x->stream));
+    if (trace)
+        PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(job.max_iter + 1), hipMemcpyDeviceToHost, x->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(x->stream));
+    const IcpState *hp = (const IcpState *)x->pinned;
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
-    c->icp_last_cand = hp->sum_tiles * (16 * qt) * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
-    c->icp_last_fb = hp->sum_fb;
-    c->icp_last_passes = hp->iters + 1;
-    c->icp_last_nt = Nt;
+    x->icp_last_cand = hp->sum_tiles * (16 * job.qt) * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
+    x->icp_last_fb = hp->sum_fb;
+    x->icp_last_passes = hp->iters + 1;
+    x->icp_last_nt = job.Nt;
     if (fitness) *fitness = hp->fitness;
     if (inlier_rmse) *inlier_rmse = hp->rmse;
     if (n_iter_done) *n_iter_done = hp->iters;
     return PEDP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
+             const double init[16], double T_out[16], double *fitness, double *inlier_rmse,
+             int32_t *n_iter_done, int32_t *corr, double *trace) {
+    PEDP_REQUIRE(c && source && target && prm && init && T_out, "pedp_icp: null argument");
+    int rc = icp_check_args(c, source, target, prm);
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    TargetPrep tp;
+    rc = icp_prepare(c, source, target, prm->max_correspondence_distance, init, 1, tp);
+    if (rc) return rc;
+    IcpJob job;
+    rc = icp_enqueue(c, source, target, tp, prm, init, trace != nullptr, true, job);
+    if (rc) return rc;
+    return icp_collect(c, job, T_out, fitness, inlier_rmse, n_iter_done, corr, trace);
+}
+
+// Hypotheses are independent: up to PEDP_MAX_SUB registrations are in flight at once, each on
+// its own stream and workspace (sub-contexts of c), sharing the clouds' cached preparation.
 int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
                      const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse) {
     PEDP_REQUIRE(c && source && target && prm && inits && T_out, "pedp_icp_batched: null argument");
     PEDP_REQUIRE(B >= 0, "pedp_icp_batched: negative batch");
+    PEDP_REQUIRE(!prm->allreduce, "pedp_icp_batched: hypotheses shard across ranks, not within one registration");
+    if (B == 0) return PEDP_OK;
+    int rc = icp_check_args(c, source, target, prm);
+    if (rc) return rc;
     pedp_icp_params p = *prm;
     p.relative_fitness = -1.0;  // no early exit across the batch
     p.relative_rmse = -1.0;
-    for (int b = 0; b < B; ++b) {
-        int rc = pedp_icp(c, source, target, &p, inits + 16 * b, T_out + 16 * b, fitness ? fitness + b : nullptr,
-                          inlier_rmse ? inlier_rmse + b : nullptr, nullptr, nullptr, nullptr);
-        if (rc) return rc;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    TargetPrep tp;
+    rc = icp_prepare(c, source, target, p.max_correspondence_distance, inits, B, tp);
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));  // preparation is visible to the sub-streams
+    const int K = B < PEDP_MAX_SUB ? B : PEDP_MAX_SUB;
+    for (int k = 0; k < K; ++k) {
+        if (!c->sub[k]) {
+            rc = pedp_ctx_create(c->device, nullptr, &c->sub[k]);
+            if (rc) return rc;
+        }
+    }
+    IcpJob jobs[PEDP_MAX_SUB];
+    c->icp_last_cand = c->icp_last_fb = c->icp_last_passes = 0;  // statistics: totals over the batch
+    c->icp_last_nt = target->N;
+    for (int b0 = 0; b0 < B; b0 += K) {
+        const int n = (B - b0 < K) ? B - b0 : K;
+        for (int k = 0; k < n; ++k) {
+            rc = icp_enqueue(c->sub[k], source, target, tp, &p, inits + 16 * (b0 + k), false, false, jobs[k]);
+            if (rc) return rc;
+        }
+        for (int k = 0; k < n; ++k) {
+            rc = icp_collect(c->sub[k], jobs[k], T_out + 16 * (b0 + k), fitness ? fitness + b0 + k : nullptr,
+                             inlier_rmse ? inlier_rmse + b0 + k : nullptr, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            c->icp_last_cand += c->sub[k]->icp_last_cand;
+            c->icp_last_fb += c->sub[k]->icp_last_fb;
+            c->icp_last_passes += c->sub[k]->icp_last_passes;
+        }
     }
     return PEDP_OK;
 }

@@ -35,6 +35,8 @@ struct pedp_scratch {
     void release();
 };
 
+#define PEDP_MAX_SUB 8
+
 struct pedp_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -54,6 +56,7 @@ struct pedp_ctx_s {
     // ICP
     pedp_scratch icp_ws;
     long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
+    pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
 };
@@ -69,6 +72,8 @@ struct pedp_mesh_s {
     float *tri2 = nullptr; // F_padded/2 pair-interleaved general-origin records (24 floats each)
     void *spheres = nullptr;  // n_clusters x float4 bounding spheres of 16-triangle clusters
     int64_t n_clusters = 0;
+    void *super_spheres = nullptr;  // bounding sphere of every 64 clusters (one cull-mask word)
+    int64_t n_super = 0;
     int64_t F_padded = 0;  // multiple of 8; pad records can never be hit (all zero => det == 0)
 };
 

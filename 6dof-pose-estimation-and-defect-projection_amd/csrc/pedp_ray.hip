@@ -321,6 +321,38 @@ __global__ void cluster_sphere_kernel(const float *__restrict__ aos, int64_t F, 
     sph[c] = make_float4(cx, cy, cz, rad);
 }
 
+// bounding sphere of 64 consecutive cluster spheres (one mask word of clusters): lets the cull
+// kernel dismiss 1024 triangles with one test
+__global__ void supercluster_sphere_kernel(const float4 *__restrict__ sph, int64_t n_clusters, int64_t n_super,
+                                           float4 *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_super) return;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    int n = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int64_t c = s * 64 + k;
+        if (c >= n_clusters) break;
+        const float4 q = sph[c];
+        if (q.w < 0.f) continue;
+        lo[0] = fminf(lo[0], q.x - q.w); hi[0] = fmaxf(hi[0], q.x + q.w);
+        lo[1] = fminf(lo[1], q.y - q.w); hi[1] = fmaxf(hi[1], q.y + q.w);
+        lo[2] = fminf(lo[2], q.z - q.w); hi[2] = fmaxf(hi[2], q.z + q.w);
+        ++n;
+    }
+    if (n == 0) { out[s] = make_float4(0.f, 0.f, 0.f, -1.f); return; }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    float rad = 0.f;
+    for (int k = 0; k < 64; ++k) {
+        const int64_t c = s * 64 + k;
+        if (c >= n_clusters) break;
+        const float4 q = sph[c];
+        if (q.w < 0.f) continue;
+        const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+        rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + q.w);
+    }
+    out[s] = make_float4(cx, cy, cz, rad * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f);
+}
+
 // per call: cone of each cluster seen from the shared origin.  rec[2c] = (vx, vy, vz, cos psi),
 // rec[2c+1].x = sin psi.  cos psi = -2: the origin is inside the sphere (never cull);
 // cos psi = 2: empty cluster (always cull).
@@ -491,7 +523,8 @@ __device__ __forceinline__ float wave_min_f(float v) {
 constexpr int RSEG_MIN = 16;    // clusters per segment at least (256 triangles)
 constexpr int RLIST = 2048;     // most clusters one sweep wave walks (LDS list)
 
-__global__ __launch_bounds__(256) void ray_cull_mask_kernel(const float4 *__restrict__ cones, int n_clusters,
+__global__ __launch_bounds__(256) void ray_cull_mask_kernel(const float4 *__restrict__ cones,
+                                                            const float4 *__restrict__ scones, int n_clusters,
                                                             int n_words, const float *__restrict__ rays6,
                                                             const unsigned *__restrict__ perm, int64_t N,
                                                             unsigned long long *__restrict__ mask,
@@ -514,20 +547,37 @@ __global__ __launch_bounds__(256) void ray_cull_mask_kernel(const float4 *__rest
     const bool can_cull = ct > 0.1f;
     const float st = sqrtf(fmaxf(0.f, 1.0f - ct * ct)) + 1e-5f;
     int cnt = 0;
-    for (int wi = 0; wi < n_words; ++wi) {
-        const int c = wi * 64 + lane;
-        bool keep = false;
-        if (c < n_clusters) {
-            const float4 ca = cones[2 * c];
-            const float sp = cones[2 * c + 1].x;
+    // level 1: one test per super-cluster (= one mask word of 64 clusters); lane l takes word
+    // sw + l.  level 2: the 64 clusters of every surviving word.
+    for (int sw = 0; sw < n_words; sw += 64) {
+        const int wl = sw + lane;
+        bool live = false;
+        if (wl < n_words) {
+            const float4 ca = scones[2 * wl];
+            const float sp = scones[2 * wl + 1].x;
             const float cosv = ca.x * ax + ca.y * ay + ca.z * az;
-            const float lim = ct * ca.w - st * sp - 1e-5f;  // cos(theta + psi), lowered by a margin
-            const bool culled = (ca.w > 1.5f) || (can_cull && ca.w > -1.5f && cosv < lim);
-            keep = !culled;
+            const float lim = ct * ca.w - st * sp - 1e-5f;
+            live = !((ca.w > 1.5f) || (can_cull && ca.w > -1.5f && cosv < lim));
+            if (!live) mask[(size_t)pk * n_words + wl] = 0ull;
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (lane == 0) mask[(size_t)pk * n_words + wi] = m;
-        cnt += __builtin_popcountll(m);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+        while (todo != 0ull) {  // wave-uniform
+            const int wi = sw + __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int c = wi * 64 + lane;
+            bool keep = false;
+            if (c < n_clusters) {
+                const float4 ca = cones[2 * c];
+                const float sp = cones[2 * c + 1].x;
+                const float cosv = ca.x * ax + ca.y * ay + ca.z * az;
+                const float lim = ct * ca.w - st * sp - 1e-5f;  // cos(theta + psi), lowered by a margin
+                const bool culled = (ca.w > 1.5f) || (can_cull && ca.w > -1.5f && cosv < lim);
+                keep = !culled;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (lane == 0) mask[(size_t)pk * n_words + wi] = m;
+            cnt += __builtin_popcountll(m);
+        }
     }
     if (lane == 0) pk_cnt[pk] = cnt;
 }
@@ -787,6 +837,13 @@ int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t
                            m->tri, F, m->n_clusters, (float4 *)m->spheres);
         e = hipGetLastError();
     }
+    m->n_super = (m->n_clusters + 63) / 64;
+    if (e == hipSuccess) e = hipMalloc((void **)&m->super_spheres, sizeof(float4) * (size_t)m->n_super);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(supercluster_sphere_kernel, dim3((unsigned)((m->n_super + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float4 *)m->spheres, m->n_clusters, m->n_super, (float4 *)m->super_spheres);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (d_verts) (void)hipFree(d_verts);
     if (d_tris) (void)hipFree(d_tris);
@@ -805,6 +862,7 @@ void pedp_mesh_destroy(pedp_mesh_t m) {
     if (m->tri) (void)hipFree(m->tri);
     if (m->tri2) (void)hipFree(m->tri2);
     if (m->spheres) (void)hipFree(m->spheres);
+    if (m->super_spheres) (void)hipFree(m->super_spheres);
     delete m;
 }
 
@@ -861,10 +919,10 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         const int64_t n_packets = (N + 63) / 64;
         const int n_cwords = (int)((mesh->n_clusters + 63) / 64);
         int64_t max_segs = (n_packets * mesh->n_clusters + RLIST - 1) / RLIST + n_packets;
-        if (max_segs < 65536) max_segs = 65536;
+        if (max_segs < 16384) max_segs = 16384;
         PEDP_REQUIRE(max_segs < (int64_t)1 << 26, "pedp_raycast: problem too large for the segment table");
         const size_t sz_tri3 = align256(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2));
-        const size_t sz_cone = align256(sizeof(float4) * 2 * (size_t)mesh->n_clusters);
+        const size_t sz_cone = align256(sizeof(float4) * 2 * (size_t)(mesh->n_clusters + mesh->n_super));
         const size_t sz_hist = align256(sizeof(unsigned) * BIN_CELLS);
         const size_t sz_perm = align256(sizeof(unsigned) * (size_t)N);
         const size_t sz_mask = align256(sizeof(unsigned long long) * (size_t)n_packets * (size_t)n_cwords);
@@ -906,8 +964,11 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
             static const unsigned bounds_init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
             PEDP_HIP_CHECK(hipMemcpyAsync(bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice, c->stream));
             PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * BIN_CELLS, c->stream));
+            float4 *scones = cones + 2 * mesh->n_clusters;
             hipLaunchKernelGGL(cluster_cone_kernel, dim3((unsigned)((mesh->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
                                (const float4 *)mesh->spheres, mesh->n_clusters, d_rays, flag, cones);
+            hipLaunchKernelGGL(cluster_cone_kernel, dim3((unsigned)((mesh->n_super + 255) / 256)), dim3(256), 0, c->stream,
+                               (const float4 *)mesh->super_spheres, mesh->n_super, d_rays, flag, scones);
             hipLaunchKernelGGL(ray_bounds_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag, bounds);
             hipLaunchKernelGGL(ray_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
                                bounds, hist);
@@ -915,7 +976,8 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
             hipLaunchKernelGGL(ray_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
                                bounds, hist, perm);
             hipLaunchKernelGGL(ray_cull_mask_kernel, dim3((unsigned)((n_packets + 3) / 4)), dim3(256), 0, c->stream,
-                               (const float4 *)cones, (int)mesh->n_clusters, n_cwords, d_rays, perm, N, pmask, pk_cnt, flag);
+                               (const float4 *)cones, (const float4 *)scones, (int)mesh->n_clusters, n_cwords, d_rays, perm, N,
+                               pmask, pk_cnt, flag);
             hipLaunchKernelGGL(ray_segment_kernel, dim3(1), dim3(1024), 0, c->stream, pk_cnt, (int)n_packets, seg_pk,
                                seg_rank0, seg_n, (int)max_segs, seg_info, flag);
             hipLaunchKernelGGL(ray_sweep_seg_kernel, dim3((unsigned)((max_segs + 3) / 4)), dim3(RPL_BLOCK), 0, c->stream,

@@ -140,7 +140,7 @@ def test_icp_batched_matches_single(ctx, oracle):
     f, scene = _frame_scene(oracle, "tiny")
     src = _lib.Cloud(ctx, scene)
     tgt = _lib.Cloud(ctx, f.model_points, f.normals)
-    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(6)])
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(19)])
     T, fit, rmse = _lib.icp_batched(ctx, src, tgt, 10.0, inits, max_iteration=5)
     for b in range(len(inits)):
         ref = oracle.icp(scene, f.model_points, f.normals, 10.0, inits[b], max_iter=5, rel_fitness=-1, rel_rmse=-1)

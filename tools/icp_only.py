@@ -12,3 +12,18 @@ for rep in range(3):
     r = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1)
     t1 = time.perf_counter()
     print(f"icp {1e3*(t1-t0):.2f} ms", _lib.icp_last_stats(ctx), r["fitness"], flush=True)
+# batched: B perturbed start poses, sequential loop vs pedp_icp_batched (8 streams)
+rng = np.random.default_rng(0)
+B = 32
+inits = np.repeat(f.icp_init()[None], B, 0).copy()
+inits[:, :3, 3] += rng.normal(0, 0.5, (B, 3))
+t0 = time.perf_counter()
+seq = [_lib.icp(ctx, src, tgt, 10.0, inits[b], max_iteration=20, relative_fitness=-1, relative_rmse=-1) for b in range(B)]
+t1 = time.perf_counter()
+for rep in range(3):
+    t2 = time.perf_counter()
+    bat = _lib.icp_batched(ctx, src, tgt, 10.0, inits, max_iteration=20)
+    t3 = time.perf_counter()
+    print(f"batched B={B}: {1e3*(t3-t2):.2f} ms  (sequential {1e3*(t1-t0):.2f} ms)", flush=True)
+Tb = bat[0]
+print("max |T_batched - T_seq|", max(np.abs(Tb[b] - seq[b]["T"]).max() for b in range(B)))
