@@ -45,6 +45,11 @@ PROTOTYPES = {
     "pedp_mesh_destroy": (None, [C.c_void_p]),
     "pedp_mesh_size": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64)]),
     "pedp_raycast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_mesh_create_posable": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
+    "pedp_mesh_set_pose": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
+                                       _P(C.c_int64)]),
     "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
@@ -152,20 +157,62 @@ def default_context(device=0):
     return ctx
 
 
-class Mesh:
-    """Device-resident triangle records of one posed mesh (RaycastingScene stand-in)."""
+class Pinhole(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32)]
 
-    def __init__(self, ctx, vertices, triangles):
+
+class Mesh:
+    """Device-resident triangle records of one posed mesh (RaycastingScene stand-in).
+    posable=True keeps the model-frame float64 vertices on the device: set_pose(T) then stands for
+    deepcopy + mesh.transform(T) + from_legacy (float64 transform, float32 cast) without a
+    round trip through the host."""
+
+    def __init__(self, ctx, vertices, triangles, posable=False):
         self.ctx = ctx
-        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        v = np.ascontiguousarray(vertices, dtype=np.float64 if posable else np.float32).reshape(-1, 3)
         t = np.asarray(triangles)
         if t.size and (t.min() < 0):
             raise PedpError("negative vertex index")
         t = np.ascontiguousarray(t, dtype=np.uint32).reshape(-1, 3)
         self.V, self.F = len(v), len(t)
+        self.posable = bool(posable)
         self._h = C.c_void_p()
-        check(load().pedp_mesh_create(ctx._h, _ptr(v), self.V, _ptr(t), self.F, C.byref(self._h)),
-              "pedp_mesh_create")
+        if posable:
+            check(load().pedp_mesh_create_posable(ctx._h, _ptr(v), self.V, _ptr(t), self.F, C.byref(self._h)),
+                  "pedp_mesh_create_posable")
+        else:
+            check(load().pedp_mesh_create(ctx._h, _ptr(v), self.V, _ptr(t), self.F, C.byref(self._h)),
+                  "pedp_mesh_create")
+
+    def set_pose(self, T=None):
+        """Move the resident model-frame vertices by the 4x4 float64 T (None = identity)."""
+        M = None if T is None else np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+        check(load().pedp_mesh_set_pose(self._h, _ptr(M)), "pedp_mesh_set_pose")
+        return self
+
+    def project_heatmap(self, heatmap, intrinsic_matrix, threshold=0.5, origin=(0.0, 0.0, 0.0)):
+        """heatmap_to_points + compute_rays + intersect_rays_with_mesh fused on the device.
+        Returns dict(points M x 3 f64, intensities M f64, pixels M x 2 int32 (x, y),
+        primitive_ids M u32, n_rays)."""
+        h = np.ascontiguousarray(heatmap, dtype=np.float64)
+        if h.ndim != 2:
+            raise PedpError("heat map must be 2-D")
+        K = np.asarray(intrinsic_matrix, dtype=np.float64)
+        cam = Pinhole(K[0, 0], K[1, 1], K[0, 2], K[1, 2], h.shape[1], h.shape[0])
+        o = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
+        cap = int(np.count_nonzero(h > threshold))  # upper bound of the hit count
+        pts = np.empty((cap, 3), np.float64)
+        inten = np.empty(cap, np.float64)
+        pix = np.empty((cap, 2), np.int32)
+        prim = np.empty(cap, np.uint32)
+        n_rays, n_hits = C.c_int64(), C.c_int64()
+        check(load().pedp_project_heatmap(self.ctx._h, self._h, C.byref(cam), _ptr(h), float(threshold), _ptr(o), HOST,
+                                          cap, _ptr(pts), _ptr(inten), _ptr(pix), _ptr(prim), C.byref(n_rays),
+                                          C.byref(n_hits)), "pedp_project_heatmap")
+        m = n_hits.value
+        return {"points": pts[:m], "intensities": inten[:m], "pixels": pix[:m], "primitive_ids": prim[:m],
+                "n_rays": n_rays.value}
 
     def cast_rays(self, rays6, want_uv=True):
         """rays6: N x 6 float32 host array.  Returns dict like RaycastingScene.cast_rays:

@@ -22,6 +22,7 @@ SOURCES = {
     "pedp_ctx.hip": [],
     "pedp_ray.hip": [],
     "pedp_icp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "pedp_project.hip": [],
     "pedp_cluster.cpp": [],
 }
 HEADERS = ["pedp_internal.h", os.path.join("..", "..", "include", "pedp.h")]

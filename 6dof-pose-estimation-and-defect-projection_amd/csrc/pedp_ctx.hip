@@ -88,6 +88,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_out.release();
     c->ray_aux.release();
     c->icp_ws.release();
+    c->proj.release();
+    c->proj_out.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

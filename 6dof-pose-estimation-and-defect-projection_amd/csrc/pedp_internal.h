@@ -55,6 +55,7 @@ struct pedp_ctx_s {
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;
     // ICP
     pedp_scratch icp_ws;
+    pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     void *pinned = nullptr;  // small pinned host block for result read-back
@@ -75,6 +76,11 @@ struct pedp_mesh_s {
     void *super_spheres = nullptr;  // bounding sphere of every 64 clusters (one cull-mask word)
     int64_t n_super = 0;
     int64_t F_padded = 0;  // multiple of 8; pad records can never be hit (all zero => det == 0)
+    // posable meshes keep the model-frame float64 vertices, the float32 posed vertices and the
+    // index buffer resident so that a new pose rebuilds the records on the device
+    double *verts64 = nullptr;
+    float *verts32 = nullptr;
+    uint32_t *idx = nullptr;
 };
 
 struct pedp_cloud_s {

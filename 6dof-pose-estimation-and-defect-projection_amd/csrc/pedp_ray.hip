@@ -794,59 +794,97 @@ __global__ void ray_finalize_kernel(const float *__restrict__ aos, const float *
     }
 }
 
+// TriangleMesh.transform (pose_estimation.py:406-409, defect_projection.py:549-550) followed by
+// from_legacy's float32 cast (defect_projection.py:245): Open3D forms T * (x, y, z, 1) in
+// float64, divides by the fourth component and the tensor mesh stores float32.  One thread per
+// vertex, fixed operation order ((T0 x + T1 y) + T2 z) + T3, no contraction.
+struct Pose16 { double m[16]; };
+
+__global__ void pose_verts_kernel(const double *__restrict__ v64, int64_t V, Pose16 T, int identity,
+                                  float *__restrict__ v32) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const double x = v64[3 * i], y = v64[3 * i + 1], z = v64[3 * i + 2];
+    if (identity) {
+        v32[3 * i] = (float)x;
+        v32[3 * i + 1] = (float)y;
+        v32[3 * i + 2] = (float)z;
+        return;
+    }
+    double h[4];
+    for (int r = 0; r < 4; ++r)
+        h[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T.m[4 * r], x), __dmul_rn(T.m[4 * r + 1], y)),
+                                   __dmul_rn(T.m[4 * r + 2], z)), T.m[4 * r + 3]);
+    v32[3 * i] = (float)(h[0] / h[3]);
+    v32[3 * i + 1] = (float)(h[1] / h[3]);
+    v32[3 * i + 2] = (float)(h[2] / h[3]);
+}
+
 }  // namespace
 
 extern "C" {
 
-int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t *tris, int64_t F,
-                     pedp_mesh_t *out) {
-    PEDP_REQUIRE(c && out, "pedp_mesh_create: null context/output");
-    *out = nullptr;
-    PEDP_REQUIRE(V >= 0 && F >= 0 && F < (int64_t)0x7FFFFF00, "pedp_mesh_create: sizes out of range");
-    PEDP_REQUIRE((verts || V == 0) && (tris || F == 0), "pedp_mesh_create: null arrays");
+// Everything derived from the posed float32 vertices: triangle records, pair records,
+// cluster and super-cluster spheres.  Enqueued on the context's stream.
+static hipError_t mesh_build_records(pedp_ctx_t c, pedp_mesh_s *m, const float *d_verts, const uint32_t *d_tris) {
+    int grid = (int)((m->F_padded + 255) / 256);
+    hipLaunchKernelGGL(tri_setup_kernel, dim3(grid), dim3(256), 0, c->stream, d_verts, d_tris, m->F, m->F_padded, m->tri);
+    hipLaunchKernelGGL(pair_general_kernel, dim3(grid), dim3(256), 0, c->stream, m->tri, m->F_padded, m->tri2);
+    hipLaunchKernelGGL(cluster_sphere_kernel, dim3((unsigned)((m->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
+                       m->tri, m->F, m->n_clusters, (float4 *)m->spheres);
+    hipLaunchKernelGGL(supercluster_sphere_kernel, dim3((unsigned)((m->n_super + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float4 *)m->spheres, m->n_clusters, m->n_super, (float4 *)m->super_spheres);
+    return hipGetLastError();
+}
+
+static int mesh_alloc(pedp_ctx_t c, int64_t V, const uint32_t *tris, int64_t F, const char *who, pedp_mesh_s **out) {
+    PEDP_REQUIRE(V >= 0 && F >= 0 && F < (int64_t)0x7FFFFF00, "%s: sizes out of range", who);
     for (int64_t i = 0; i < 3 * F; ++i)
-        PEDP_REQUIRE((int64_t)tris[i] < V, "pedp_mesh_create: triangle %lld references vertex %u >= V=%lld",
+        PEDP_REQUIRE((int64_t)tris[i] < V, "%s: triangle %lld references vertex %u >= V=%lld", who,
                      (long long)(i / 3), tris[i], (long long)V);
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     pedp_mesh_s *m = new (std::nothrow) pedp_mesh_s();
-    if (!m) { pedp_set_error("pedp_mesh_create: out of host memory"); return PEDP_ERR_ALLOC; }
+    if (!m) { pedp_set_error("%s: out of host memory", who); return PEDP_ERR_ALLOC; }
     m->ctx = c;
     m->V = V;
     m->F = F;
     m->F_padded = ((F + 63) / 64) * 64;
     if (m->F_padded == 0) m->F_padded = 64;
-    float *d_verts = nullptr;
-    uint32_t *d_tris = nullptr;
+    m->n_clusters = m->F_padded / CL_TRIS;
+    m->n_super = (m->n_clusters + 63) / 64;
     hipError_t e = hipMalloc((void **)&m->tri, sizeof(float) * PEDP_TRI_STRIDE * (size_t)m->F_padded);
     if (e == hipSuccess) e = hipMalloc((void **)&m->tri2, sizeof(float) * PAIR_GEN * (size_t)(m->F_padded / 2));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_verts, sizeof(float) * 3 * (size_t)(V ? V : 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_tris, sizeof(uint32_t) * 3 * (size_t)(F ? F : 1));
-    if (e == hipSuccess && V) e = hipMemcpyAsync(d_verts, verts, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && F) e = hipMemcpyAsync(d_tris, tris, sizeof(uint32_t) * 3 * (size_t)F, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        int grid = (int)((m->F_padded + 255) / 256);
-        hipLaunchKernelGGL(tri_setup_kernel, dim3(grid), dim3(256), 0, c->stream, d_verts, d_tris, F,
-                           m->F_padded, m->tri);
-        hipLaunchKernelGGL(pair_general_kernel, dim3(grid), dim3(256), 0, c->stream, m->tri, m->F_padded, m->tri2);
-        e = hipGetLastError();
-    }
-    m->n_clusters = m->F_padded / CL_TRIS;
     if (e == hipSuccess) e = hipMalloc((void **)&m->spheres, sizeof(float4) * (size_t)m->n_clusters);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(cluster_sphere_kernel, dim3((unsigned)((m->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
-                           m->tri, F, m->n_clusters, (float4 *)m->spheres);
-        e = hipGetLastError();
-    }
-    m->n_super = (m->n_clusters + 63) / 64;
     if (e == hipSuccess) e = hipMalloc((void **)&m->super_spheres, sizeof(float4) * (size_t)m->n_super);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(supercluster_sphere_kernel, dim3((unsigned)((m->n_super + 255) / 256)), dim3(256), 0, c->stream,
-                           (const float4 *)m->spheres, m->n_clusters, m->n_super, (float4 *)m->super_spheres);
-        e = hipGetLastError();
+    if (e == hipSuccess) e = hipMalloc((void **)&m->verts32, sizeof(float) * 3 * (size_t)(V ? V : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->idx, sizeof(uint32_t) * 3 * (size_t)(F ? F : 1));
+    if (e == hipSuccess && F) e = hipMemcpyAsync(m->idx, tris, sizeof(uint32_t) * 3 * (size_t)F, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        pedp_set_error("%s: %s", who, hipGetErrorString(e));
+        pedp_mesh_destroy(m);
+        return PEDP_ERR_HIP;
     }
+    *out = m;
+    return PEDP_OK;
+}
+
+int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t *tris, int64_t F,
+                     pedp_mesh_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_mesh_create: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE((verts || V == 0) && (tris || F == 0), "pedp_mesh_create: null arrays");
+    pedp_mesh_s *m = nullptr;
+    int rc = mesh_alloc(c, V, tris, F, "pedp_mesh_create", &m);
+    if (rc) return rc;
+    hipError_t e = hipSuccess;
+    if (V) e = hipMemcpyAsync(m->verts32, verts, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = mesh_build_records(c, m, m->verts32, m->idx);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (d_verts) (void)hipFree(d_verts);
-    if (d_tris) (void)hipFree(d_tris);
+    // a fixed mesh needs neither the vertices nor the indices again
+    (void)hipFree(m->verts32);
+    (void)hipFree(m->idx);
+    m->verts32 = nullptr;
+    m->idx = nullptr;
     if (e != hipSuccess) {
         pedp_set_error("pedp_mesh_create: %s", hipGetErrorString(e));
         pedp_mesh_destroy(m);
@@ -856,13 +894,54 @@ int pedp_mesh_create(pedp_ctx_t c, const float *verts, int64_t V, const uint32_t
     return PEDP_OK;
 }
 
+int pedp_mesh_create_posable(pedp_ctx_t c, const double *verts, int64_t V, const uint32_t *tris, int64_t F,
+                             pedp_mesh_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_mesh_create_posable: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE((verts || V == 0) && (tris || F == 0), "pedp_mesh_create_posable: null arrays");
+    pedp_mesh_s *m = nullptr;
+    int rc = mesh_alloc(c, V, tris, F, "pedp_mesh_create_posable", &m);
+    if (rc) return rc;
+    hipError_t e = hipMalloc((void **)&m->verts64, sizeof(double) * 3 * (size_t)(V ? V : 1));
+    if (e == hipSuccess && V) e = hipMemcpyAsync(m->verts64, verts, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the caller's arrays are free again
+    if (e != hipSuccess) {
+        pedp_set_error("pedp_mesh_create_posable: %s", hipGetErrorString(e));
+        pedp_mesh_destroy(m);
+        return PEDP_ERR_HIP;
+    }
+    *out = m;
+    return pedp_mesh_set_pose(m, nullptr);
+}
+
+int pedp_mesh_set_pose(pedp_mesh_t m, const double T[16]) {
+    PEDP_REQUIRE(m, "pedp_mesh_set_pose: null mesh");
+    PEDP_REQUIRE(m->verts64, "pedp_mesh_set_pose: mesh was not created with pedp_mesh_create_posable");
+    pedp_ctx_t c = m->ctx;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    Pose16 P;
+    for (int k = 0; k < 16; ++k) P.m[k] = T ? T[k] : ((k % 5) == 0 ? 1.0 : 0.0);
+    if (m->V)
+        hipLaunchKernelGGL(pose_verts_kernel, dim3((unsigned)((m->V + 255) / 256)), dim3(256), 0, c->stream, m->verts64,
+                           m->V, P, T ? 0 : 1, m->verts32);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(mesh_build_records(c, m, m->verts32, m->idx));
+    return PEDP_OK;
+}
+
 void pedp_mesh_destroy(pedp_mesh_t m) {
     if (!m) return;
-    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->ctx) {
+        (void)hipSetDevice(m->ctx->device);
+        if (m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+    }
     if (m->tri) (void)hipFree(m->tri);
     if (m->tri2) (void)hipFree(m->tri2);
     if (m->spheres) (void)hipFree(m->spheres);
     if (m->super_spheres) (void)hipFree(m->super_spheres);
+    if (m->verts64) (void)hipFree(m->verts64);
+    if (m->verts32) (void)hipFree(m->verts32);
+    if (m->idx) (void)hipFree(m->idx);
     delete m;
 }
 

@@ -149,14 +149,49 @@ def ray_tracing(data_dir, target_mesh, heatmap, color_intrinsics, heatmap_thresh
     rays start at the colour camera's origin, the mesh (given in the depth-camera frame) is
     copied and moved into the colour-camera frame with inv(color_to_depth), and the closest
     hits come back as a jet-coloured cloud -- or red debug rays if nothing was hit.
-    Returns (cloud or LineSet, moved mesh copy)."""
+    Returns (cloud or LineSet, moved mesh copy).
+
+    Pixel selection, ray generation, the sweep and the hit filter run as one device call
+    (pedp_project_heatmap); the step-by-step functions above give the same arrays."""
     origin = np.array([0, 0, 0])
     color_to_depth, _ = load_extrinsics(data_dir)
     mesh_in_color = clone(target_mesh)
     mesh_in_color.transform(np.linalg.inv(color_to_depth))
-    pixels = heatmap_to_points(heatmap, heatmap_threshold)
-    rays, intensities = compute_rays(pixels, color_intrinsics)
-    hits, hit_intensities = intersect_rays_with_mesh(mesh_in_color, rays, origin, intensities)
-    if len(hits) > 0:
-        return create_intersection_pcd(hits, hit_intensities), mesh_in_color
+    dev = _device_mesh(mesh_in_color, _lib.default_context())
+    out = dev.project_heatmap(heatmap, color_intrinsics.intrinsic_matrix, heatmap_threshold, origin)
+    if len(out["points"]) > 0:
+        return create_intersection_pcd(out["points"], out["intensities"]), mesh_in_color
+    rays, _ = compute_rays(heatmap_to_points(heatmap, heatmap_threshold), color_intrinsics)
     return project_debug_rays(rays, origin), mesh_in_color
+
+
+class FrameProjector:
+    """Camera-rate form of run.py:95-119 / :176-200 for a fixed model: the model-frame mesh is
+    uploaded once, every frame only sends a 4x4 pose and the heat map.
+
+        proj = FrameProjector(model_mesh, color_intrinsics, color_to_depth)
+        cloud = proj.project(pose_model_to_depth, heatmap, 0.75)
+
+    The pose chain is the reference's: the mesh is moved to the depth-camera frame by the refined
+    pose (transform_object, pose_estimation.py:406-409) and then into the colour-camera frame by
+    inv(color_to_depth) (defect_projection.py:549-550).  Open3D applies the two transforms one
+    after the other on float64 vertices; here their float64 product is applied once on the device,
+    which moves a vertex by at most a few ulp before the float32 cast."""
+
+    def __init__(self, model_mesh, color_intrinsics, color_to_depth=None, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.K = np.array(color_intrinsics.intrinsic_matrix, dtype=np.float64)
+        self.depth_to_color = np.eye(4) if color_to_depth is None else np.linalg.inv(np.asarray(color_to_depth, np.float64))
+        self.mesh = _lib.Mesh(self.ctx, np.asarray(model_mesh.vertices, np.float64), np.asarray(model_mesh.triangles),
+                              posable=True)
+
+    def project(self, pose, heatmap, heatmap_threshold=0.5, details=None):
+        """pose: model -> depth-camera 4x4.  Returns the jet-coloured hit cloud, or None when
+        no ray hits; `details` (dict) receives pixels / primitive_ids / n_rays."""
+        self.mesh.set_pose(self.depth_to_color @ np.asarray(pose, dtype=np.float64))
+        out = self.mesh.project_heatmap(heatmap, self.K, heatmap_threshold)
+        if details is not None:
+            details.update(out)
+        if len(out["points"]) == 0:
+            return None
+        return create_intersection_pcd(out["points"], out["intensities"])

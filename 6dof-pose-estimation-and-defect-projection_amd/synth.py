@@ -154,6 +154,10 @@ class Frame:
         self.max_correspondence_distance = 10.0
 
     @property
+    def K(self):
+        return np.array([[self.f, 0.0, self.cx], [0.0, self.f, self.cy], [0.0, 0.0, 1.0]])
+
+    @property
     def n_rays(self):
         return len(self.rays6)
 

@@ -86,6 +86,44 @@ int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
  * context's stream); synchronises the stream. */
 int pedp_raycast_last_sweep_ms(pedp_ctx_t ctx, float *ms);
 
+/* ---------------------------------------------------------------- fused defect projection
+ * the per-frame work around cast_rays moved onto the device.
+ *
+ * Posable mesh.  Replaces the per-frame `copy.deepcopy(mesh)` + `mesh.transform(T)` +
+ * `TriangleMesh.from_legacy(mesh)` chain (src/pose_estimation.py:406-409,
+ * src/defect_projection.py:549-550, :245; poses composed in run.py:95-119): the model-frame
+ * float64 vertices stay resident, pedp_mesh_set_pose forms T * (x, y, z, 1) in float64 (fixed
+ * operation order), divides by the fourth component, casts to float32 and rebuilds the triangle
+ * records and culling spheres on the device.  T: row-major 4x4 float64 on the host, NULL =
+ * identity.  set_pose only enqueues work on the context's stream. */
+int pedp_mesh_create_posable(pedp_ctx_t ctx, const double *verts, int64_t V, const uint32_t *tris,
+                             int64_t F, pedp_mesh_t *out);
+int pedp_mesh_set_pose(pedp_mesh_t mesh, const double T[16]);
+
+/* Pinhole intrinsics as read from PinholeCameraIntrinsic.intrinsic_matrix
+ * (src/defect_projection.py:209-212) plus the heat map's size. */
+typedef struct {
+    double fx, fy, cx, cy;
+    int32_t width, height;
+} pedp_pinhole;
+
+/* heatmap_to_points + compute_rays + intersect_rays_with_mesh in one call
+ * (src/defect_projection.py:165-179, :196-223, :225-266):
+ *   select pixels with heatmap > threshold in row-major order (np.where); per pixel
+ *   d = (xn, yn, 1) / sqrt((xn*xn + yn*yn) + 1), xn = (x - cx) / fx, yn = (y - cy) / fy in float64;
+ *   [origin | d] cast to float32 and cast against the mesh (same sweep as pedp_raycast);
+ *   rays with t_hit != inf are kept in order; point = origin + d * t_hit in float64.
+ * heatmap: height x width float64, row-major.  origin: 3 float64 on the host (the reference passes
+ * zeros).  Outputs hold `capacity` rows: points capacity x 3 f64, intensities f64, pixels
+ * capacity x 2 int32 (x, y; nullable), prim_id u32 (nullable).  n_rays / n_hits are host
+ * scalars (the call synchronises the stream).  PEDP_DEVICE: heatmap and the output arrays are
+ * device memory.  If n_hits > capacity nothing is written, n_hits is still reported and the call
+ * returns PEDP_ERR_BAD_ARG; capacity = width * height always suffices. */
+int pedp_project_heatmap(pedp_ctx_t ctx, pedp_mesh_t mesh, const pedp_pinhole *cam, const double *heatmap,
+                         double threshold, const double origin[3], int mem, int64_t capacity,
+                         double *points, double *intensities, int32_t *pixels, uint32_t *prim_id,
+                         int64_t *n_rays, int64_t *n_hits);
+
 /* ---------------------------------------------------------------- ICP
  * Replaces src/pose_estimation.py:519-521 and :654-660:
  *     o3d.pipelines.registration.registration_icp(source, target, max_corr_dist, init,

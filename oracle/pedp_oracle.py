@@ -108,6 +108,40 @@ def transform(T, pts):
     return out
 
 
+def pose_vertices(T, verts):
+    """TriangleMesh.transform (pose_estimation.py:406-409) + from_legacy's float32 cast
+    (defect_projection.py:245): Open3D forms T * (x, y, z, 1) in float64 and divides by the
+    fourth component.  Fixed order ((T0 x + T1 y) + T2 z) + T3, elementwise numpy (no FMA)."""
+    v = np.ascontiguousarray(verts, np.float64).reshape(-1, 3)
+    M = np.asarray(T, np.float64).reshape(4, 4)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    h = [((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3] for r in range(4)]
+    return np.stack([h[0] / h[3], h[1] / h[3], h[2] / h[3]], axis=1).astype(np.float32)
+
+
+def project_heatmap(verts32, tris, heatmap, K, threshold=0.5, origin=(0, 0, 0), bvh=True):
+    """heatmap_to_points + compute_rays + intersect_rays_with_mesh
+    (defect_projection.py:165-179, :196-223, :225-266) on whole arrays: np.where order, float64
+    directions with the norm formed as sqrt((xn*xn + yn*yn) + 1), [o | d] cast to float32 for the
+    sweep, t != inf filter, o + d * t in float64."""
+    h = np.asarray(heatmap, np.float64)
+    K = np.asarray(K, np.float64)
+    ys, xs = np.nonzero(h > threshold)
+    xn = (xs.astype(np.float64) - K[0, 2]) / K[0, 0]
+    yn = (ys.astype(np.float64) - K[1, 2]) / K[1, 1]
+    ln = np.sqrt((xn * xn + yn * yn) + 1.0)
+    d = np.stack([xn / ln, yn / ln, 1.0 / ln], axis=1)
+    o = np.asarray(origin, np.float64).reshape(3)
+    rays6 = np.hstack([np.tile(o, (len(d), 1)), d]).astype(np.float32)
+    hit = raycast(verts32, tris, rays6, bvh=bvh) if len(d) else {"t_hit": np.zeros(0, np.float32),
+                                                                  "primitive_ids": np.zeros(0, np.uint32)}
+    valid = hit["t_hit"] != np.inf
+    pts = o + d[valid] * hit["t_hit"][valid, None].astype(np.float64)
+    return {"points": pts, "intensities": h[ys[valid], xs[valid]],
+            "pixels": np.stack([xs[valid], ys[valid]], axis=1).astype(np.int32),
+            "primitive_ids": hit["primitive_ids"][valid], "n_rays": len(d), "rays6": rays6}
+
+
 def icp(src, tgt, tgt_normals, max_corr_dist, init, estimator=P2PLANE, max_iter=30, rel_fitness=1e-6,
         rel_rmse=1e-6, kdtree=True, nthreads=0, want_trace=True):
     s = np.ascontiguousarray(src, np.float64).reshape(-1, 3)

@@ -1,0 +1,137 @@
+"""GPU parity of the fused defect projection against the oracle's restatement of
+heatmap_to_points + compute_rays + intersect_rays_with_mesh: selected pixels, hit count, pixel
+list and triangle indices bit-exact; hit points within 1e-9 mm (float64 o + d * t).  Posable
+meshes: records rebuilt on the device from the float64 model vertices and a pose give bit-exact
+t_hit / primitive_ids against the oracle on pose_vertices()."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POINT_TOL = 1e-9
+
+
+def _heatmap(h, w, seed, fill=0.3):
+    rng = np.random.default_rng(seed)
+    hm = rng.uniform(0.0, 1.0, size=(h, w))
+    hm[rng.uniform(size=(h, w)) > fill] = 0.0  # sparse blobs like an anomaly map
+    hm[0, 0] = np.nan                          # NaN never passes `>`
+    return hm
+
+
+def _check(out, ref):
+    assert out["n_rays"] == ref["n_rays"]
+    assert np.array_equal(out["pixels"], ref["pixels"])
+    assert np.array_equal(out["primitive_ids"], ref["primitive_ids"])
+    assert np.array_equal(out["intensities"], ref["intensities"])
+    assert out["points"].shape == ref["points"].shape
+    if len(ref["points"]):
+        assert np.abs(out["points"] - ref["points"]).max() < POINT_TOL
+
+
+@pytest.mark.parametrize("config,threshold", [("tiny", 0.5), ("tiny", -1.0), ("parity", 0.75), ("parity", 0.0)])
+def test_project_heatmap_matches_oracle(ctx, oracle, config, threshold):
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame(config)
+    hm = _heatmap(f.height, f.width, 3)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    out = mesh.project_heatmap(hm, f.K, threshold)
+    ref = oracle.project_heatmap(f.verts_posed, f.tris, hm, f.K, threshold)
+    assert len(ref["points"]) > 5
+    _check(out, ref)
+
+
+def test_project_heatmap_edge_cases(ctx, oracle):
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    # nothing selected
+    out = mesh.project_heatmap(np.zeros((f.height, f.width)), f.K, 0.5)
+    assert out["n_rays"] == 0 and len(out["points"]) == 0
+    # selected, but every ray misses (camera looks away: flip the mesh behind the camera)
+    behind = _lib.Mesh(ctx, f.verts_posed * np.array([1, 1, -1], np.float32), f.tris)
+    hm = np.ones((f.height, f.width))
+    out = behind.project_heatmap(hm, f.K, 0.5)
+    assert out["n_rays"] == f.height * f.width and len(out["points"]) == 0
+    # a single hot pixel, a non-zero origin, a 1 x 1 image, an empty image
+    hm = np.zeros((f.height, f.width)); hm[f.height // 2, f.width // 2] = 0.9
+    _check(mesh.project_heatmap(hm, f.K, 0.5), oracle.project_heatmap(f.verts_posed, f.tris, hm, f.K, 0.5))
+    o = (1.5, -2.0, 3.25)
+    hm = _heatmap(f.height, f.width, 9)
+    _check(mesh.project_heatmap(hm, f.K, 0.2, o), oracle.project_heatmap(f.verts_posed, f.tris, hm, f.K, 0.2, o))
+    K1 = np.array([[500.0, 0, 0.0], [0, 500.0, 0.0], [0, 0, 1]])
+    _check(mesh.project_heatmap(np.ones((1, 1)), K1, 0.5), oracle.project_heatmap(f.verts_posed, f.tris, np.ones((1, 1)), K1, 0.5))
+    out = mesh.project_heatmap(np.zeros((0, 0)), f.K, 0.5)
+    assert out["n_rays"] == 0
+    # capacity too small is an error, not a truncation
+    import ctypes as C
+    hm = np.ones((f.height, f.width))
+    cam = _lib.Pinhole(f.K[0, 0], f.K[1, 1], f.K[0, 2], f.K[1, 2], f.width, f.height)
+    pts = np.empty((4, 3)); it = np.empty(4); nr, nh = C.c_int64(), C.c_int64()
+    org = np.zeros(3)
+    rc = _lib.load().pedp_project_heatmap(ctx._h, mesh._h, C.byref(cam), _lib._ptr(hm), 0.5, _lib._ptr(org), _lib.HOST, 4,
+                                          _lib._ptr(pts), _lib._ptr(it), None, None, C.byref(nr), C.byref(nh))
+    assert rc == -1 and nh.value > 4 and b"capacity" in _lib.load().pedp_last_error()
+
+
+def test_posable_mesh_matches_host_transform(ctx, oracle):
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    model = f.model_points
+    posable = _lib.Mesh(ctx, model, f.tris, posable=True)
+    # identity pose = plain float32 cast
+    ref = oracle.raycast(model.astype(np.float32), f.tris, f.rays6, bvh=True)
+    res = posable.cast_rays(f.rays6)
+    assert np.array_equal(res["primitive_ids"], ref["primitive_ids"])
+    assert np.array_equal(res["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
+    rng = np.random.default_rng(11)
+    for k in range(3):
+        T = f.T_gt.copy()
+        T[:3, 3] += rng.normal(0, 4.0, 3)
+        T[:3, :3] = T[:3, :3] @ oracle.rot_xyz(rng.normal(0, 0.05, 3))
+        posable.set_pose(T)
+        v32 = oracle.pose_vertices(T, model)
+        # the BLAS-ordered host transform may differ from the fixed order by float64 ulps only
+        host = (model @ T[:3, :3].T + T[:3, 3])
+        assert np.abs(host - v32).max() < 1e-4
+        ref = oracle.raycast(v32, f.tris, f.rays6, bvh=True)
+        res = posable.cast_rays(f.rays6)
+        assert np.isfinite(ref["t_hit"]).sum() > 50
+        assert np.array_equal(res["primitive_ids"], ref["primitive_ids"])
+        assert np.array_equal(res["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
+    with pytest.raises(_lib.PedpError):
+        _lib.Mesh(ctx, f.verts_posed, f.tris).set_pose(np.eye(4))
+
+
+def test_frame_projector_and_ray_tracing(ctx, oracle, tmp_path):
+    """ray_tracing (reference signature) and the resident-model FrameProjector give the
+    oracle's cloud for the same frame."""
+    import json
+    from pedp_hip import compat, synth
+    from pedp_hip.ray_projection import FrameProjector
+
+    f = synth.Frame("tiny")
+    c2d = np.eye(4); c2d[:3, 3] = (32.0, -1.5, 2.0)
+    c2d[:3, :3] = oracle.rot_xyz([0.01, -0.02, 0.005])
+    (tmp_path / "configs").mkdir()
+    d2c = np.linalg.inv(c2d)
+    (tmp_path / "configs" / "camera_extrinsics.json").write_text(json.dumps({
+        "color_to_depth": {"rotation_matrix": c2d[:3, :3].tolist(), "translation_vector": [c2d[:3, 3].tolist()]},
+        "depth_to_color": {"rotation_matrix": d2c[:3, :3].tolist(), "translation_vector": [d2c[:3, 3].tolist()]}}))
+    hm = _heatmap(f.height, f.width, 21, fill=0.6)
+    intr = compat.PinholeCameraIntrinsic(f.width, f.height, intrinsic_matrix=f.K)
+    model = compat.TriangleMesh(f.model_points, f.tris)
+    posed = compat.transform_object(model, f.T_gt)
+    cloud, moved = compat.ray_tracing(str(tmp_path), posed, hm, intr, 0.6)
+    v32 = np.asarray(moved.vertices, np.float64).astype(np.float32)
+    ref = oracle.project_heatmap(v32, f.tris, hm, f.K, 0.6)
+    assert len(ref["points"]) > 5
+    assert np.abs(np.asarray(cloud.points) - ref["points"]).max() < POINT_TOL
+    det = {}
+    cloud2 = FrameProjector(model, intr, c2d).project(f.T_gt, hm, 0.6, det)
+    ref2 = oracle.project_heatmap(oracle.pose_vertices(np.linalg.inv(c2d) @ f.T_gt, f.model_points), f.tris, hm, f.K, 0.6)
+    _check(det, ref2)
+    assert np.array_equal(np.asarray(cloud2.colors), np.asarray(compat.create_intersection_pcd(ref2["points"], ref2["intensities"]).colors))
