@@ -462,13 +462,13 @@ __global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__
 
 // ---- 3. sweep: one wave per segment ----
 // Triples of segment s: tr_b1 / tr_t1 / tr_b2 [(s * 4 + q) * 128 + slot in block]
-template <int QT>
+template <int QT, int G>
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const IcpState *__restrict__ st, const float *__restrict__ tgtf /* (n_tiles + pad) x 64, sorted */, int n_tiles,
     int n_words, const unsigned long long *__restrict__ mask, const int32_t *__restrict__ seg_blk,
     const int32_t *__restrict__ seg_rank0, const int32_t *__restrict__ seg_n, const float *__restrict__ srcf /* slots x 4 */,
     float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2) {
-    __shared__ unsigned surv[NN_WAVES][NN_LIST_TILES / QT + 8];
+    __shared__ unsigned surv[NN_WAVES][NN_LIST_TILES / QT + 2 * G];
     if (st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int seg = blockIdx.x * NN_WAVES + wv;
@@ -504,8 +504,9 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
             running += __shfl(incl, 63, 64);
         }
     }
-    // one pad unit behind the list for the prefetch of the last trip: rows that can never win
-    if (lane == 0) mine[n_s] = (unsigned)n_tiles;  // first pad unit (|t|^2 = 1e30)
+    // pad units behind the list (rows that can never win): the last group is filled up with
+    // them and the prefetch of the trip after it reads them
+    if (lane < 2 * G) mine[n_s + lane] = (unsigned)n_tiles;  // first pad unit (|t|^2 = 1e30)
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
 
     float b[NN_SB];
@@ -517,26 +518,38 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; vq[sb] = b1[sb]; t1[sb] = n_tiles; }
 
     if (n_s > 0) {
-        // Per unit (QT = 4 MFMA tiles = 64 target rows): the 16 values a lane sees are folded
-        // with two v_min3 per MFMA, and only once per unit the running (best value, unit,
-        // second-best value) is updated: 3 VALU ops per MFMA instead of 6.  The matrix pipe works
-        // on the next tile while the VALU folds this one (software pipeline).
+        // Per unit (QT MFMA tiles = 16 QT target rows): the values a lane sees are folded with
+        // two v_min3 per MFMA, and only once per unit the running (best value, unit, second-best
+        // value) is updated.  The matrix pipe works on the next tile while the VALU folds this one
+        // (software pipeline), and the A operands of a whole group of G units (G QT tiles) are
+        // fetched one group ahead: G QT x NN_SB MFMAs cover the load latency.
+        constexpr int U = G * QT;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        float a[QT];
-        unsigned unit = mine[0];
+        float a[U];
+        unsigned units[G];
 #pragma unroll
-        for (int u = 0; u < QT; ++u) a[u] = tgtf[((size_t)unit * QT + u) * 64 + frag];
+        for (int g = 0; g < G; ++g) {
+            units[g] = mine[g];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) a[g * QT + u] = tgtf[((size_t)units[g] * QT + u) * 64 + frag];
+        }
         f32x4 acc[NN_SB];
 #pragma unroll
         for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
-        for (int k = 0; k < n_s; ++k) {
-            const unsigned unit_next = mine[k + 1];  // a pad unit follows the last real one
-            float an[QT];
+        for (int k = 0; k < n_s; k += G) {
+            float an[U];
+            unsigned units_n[G];
 #pragma unroll
-            for (int u = 0; u < QT; ++u) an[u] = tgtf[((size_t)unit_next * QT + u) * 64 + frag];
+            for (int g = 0; g < G; ++g) {
+                units_n[g] = mine[k + G + g];  // pad units follow the last real one
 #pragma unroll
-            for (int u = 0; u < QT; ++u) {
-                const float a_next = (u + 1 < QT) ? a[u + 1] : an[0];
+                for (int u = 0; u < QT; ++u) an[g * QT + u] = tgtf[((size_t)units_n[g] * QT + u) * 64 + frag];
+            }
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const int u = t % QT;
+                const unsigned unit = units[t / QT];
+                const float a_next = (t + 1 < U) ? a[t + 1] : an[0];
 #pragma unroll
                 for (int sb = 0; sb < NN_SB; ++sb) {
                     f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
@@ -563,8 +576,9 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
                 }
             }
 #pragma unroll
-            for (int u = 0; u < QT; ++u) a[u] = an[u];
-            unit = unit_next;
+            for (int t = 0; t < U; ++t) a[t] = an[t];
+#pragma unroll
+            for (int g = 0; g < G; ++g) units[g] = units_n[g];
         }
     }
     const int q = lane >> 4, j = lane & 15;
@@ -599,43 +613,60 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     const bool live = i >= 0;  // dummies carry -1
     const int blk = kk >> 7, slot = kk & 127;
     const int s0 = blk_segstart[blk], s1 = blk_segstart[blk + 1];
-    float m = __uint_as_float(0x7F800000u), m2 = m;
-    for (int sg = s0; sg < s1; sg += 4) {  // four segments per trip: eight loads in flight
+    // everything the slot needs later is requested now, ahead of the dependent loads below
+    const float e = eps[kk], Si = S[kk];
+    const int64_t ip = live ? i : 0;
+    const double px = P[3 * ip], py = P[3 * ip + 1], pz = P[3 * ip + 2];
+    const float inf = __uint_as_float(0x7F800000u);
+    float m = inf, sm = inf, m2 = inf;  // own best b1, own second-best b1, best b2
+    int mt = 0;                         // unit of the own best
+    for (int sg = s0; sg < s1; sg += 4) {  // four segments per trip: twelve loads in flight
         float v1[4], v2[4];
+        int vt[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int sq = sg + u < s1 ? sg + u : s1 - 1;
-            const size_t o = ((size_t)sq * 4 + gl) * (NN_SB * 16) + slot;
+            const bool in = sg + u < s1;
+            const size_t o = ((size_t)(in ? sg + u : s1 - 1) * 4 + gl) * (NN_SB * 16) + slot;
             v1[u] = tr_b1[o];
             v2[u] = tr_b2[o];
+            vt[u] = tr_t1[o];
+            if (!in) { v1[u] = inf; v2[u] = inf; }
         }
-        m = fminf(fminf(m, fminf(v1[0], v1[1])), fminf(v1[2], v1[3]));
-        m2 = fminf(fminf(m2, fminf(v2[0], v2[1])), fminf(v2[2], v2[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sm = v1[u] < m ? m : fminf(sm, v1[u]);
+            mt = v1[u] < m ? vt[u] : mt;
+            m = fminf(m, v1[u]);
+            m2 = fminf(m2, v2[u]);
+        }
     }
-    m = fminf(m, __shfl_xor(m, 1, 64)); m = fminf(m, __shfl_xor(m, 2, 64));
+    float mg = fminf(m, __shfl_xor(m, 1, 64)); mg = fminf(mg, __shfl_xor(mg, 2, 64));
     m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
-    const float e = eps[kk], Si = S[kk];
-    const bool maybe = m + Si <= r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
-    const float win = m + 2.0f * e;
+    const bool maybe = mg + Si <= r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
+    const float win = mg + 2.0f * e;
     double bd = __longlong_as_double(0x7FF0000000000000ll);
     int bj = 0x7FFFFFFF;
-    if (live && maybe) {
-        const double px = P[3 * (int64_t)i], py = P[3 * (int64_t)i + 1], pz = P[3 * (int64_t)i + 2];
-        for (int sg = s0; sg < s1; ++sg) {
-            const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
-            if (tr_b1[o] <= win) {
-                const int64_t row0 = (int64_t)tr_t1[o] * (16 * QT) + 4 * gl;  // lane group gl: rows 4gl..4gl+3 of each tile
-                for (int u = 0; u < QT; ++u) {
+    auto rescore = [&](int unit) {
+        const int64_t row0 = (int64_t)unit * (16 * QT) + 4 * gl;  // lane group gl: rows 4gl..4gl+3 of each tile
+        for (int u = 0; u < QT; ++u) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t row = row0 + 16 * u + r;
-                        if (row < Nt) {
-                            const int64_t j = tperm[row];
-                            lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
-                        }
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * u + r;
+                if (row < Nt) {
+                    const int64_t j = tperm[row];
+                    lexmin(bd, bj, dist2(px, py, pz, tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2]), (int)j);
                 }
             }
+        }
+    };
+    if (live && maybe) {
+        if (sm <= win) {  // rare: several of this thread's segments have a unit inside the window
+            for (int sg = s0; sg < s1; ++sg) {
+                const size_t o = ((size_t)sg * 4 + gl) * (NN_SB * 16) + slot;
+                if (tr_b1[o] <= win) rescore(tr_t1[o]);
+            }
+        } else if (m <= win) {
+            rescore(mt);
         }
     }
 #pragma unroll
@@ -656,25 +687,30 @@ __global__ __launch_bounds__(256) void nn_select_kernel(
     }
 }
 
-// ---- 5. ambiguous slots: exact float64 search, one wave per slot.  Candidate tiles are the
-// block's surviving tiles (mask) that also come within r of THIS point (lane-parallel sphere
-// test per non-empty mask word); their rows are scanned four tiles at a time (16 lanes each).
+// ---- 5. ambiguous slots: exact float64 search, one workgroup (FB_WAVES waves) per slot.
+// Candidate tiles are the block's surviving tiles (mask) that also come within r of THIS point
+// (lane-parallel sphere test per non-empty mask word); wave w takes the mask words w, w +
+// FB_WAVES, ... so the chain of dependent loads per slot is n_words / FB_WAVES long; the waves'
+// results meet in LDS.  Rows are scanned 64 at a time.
+constexpr int FB_WAVES = 16;
 template <int QT>
-__global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__restrict__ st,
-                                                          const int32_t *__restrict__ fb_list,
-                                                          const int32_t *__restrict__ list,
-                                                          const unsigned long long *__restrict__ mask, int n_words,
-                                                          const float4 *__restrict__ tile_sph, float r_search,
-                                                          const double *__restrict__ tgt,
-                                                          const int32_t *__restrict__ tperm, int64_t Nt,
-                                                          const double *__restrict__ P,
-                                                          int32_t *__restrict__ idx_out,
-                                                          double *__restrict__ d2_out) {
+__global__ __launch_bounds__(FB_WAVES * 64) void nn_fallback_kernel(const IcpState *__restrict__ st,
+                                                                   const int32_t *__restrict__ fb_list,
+                                                                   const int32_t *__restrict__ list,
+                                                                   const unsigned long long *__restrict__ mask, int n_words,
+                                                                   const float4 *__restrict__ tile_sph, float r_search,
+                                                                   const double *__restrict__ tgt,
+                                                                   const int32_t *__restrict__ tperm, int64_t Nt,
+                                                                   const double *__restrict__ P,
+                                                                   int32_t *__restrict__ idx_out,
+                                                                   double *__restrict__ d2_out) {
     if (st->done) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ double red_d[FB_WAVES];
+    __shared__ int red_j[FB_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = st->fb_count;
     const double cx = st->centroid[0], cy = st->centroid[1], cz = st->centroid[2];
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
         const int kk = fb_list[w];
         const int i = list[kk];
         const unsigned long long *mw = mask + (size_t)(kk >> 7) * n_words;
@@ -683,7 +719,7 @@ __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__rest
         const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
         double bd = __longlong_as_double(0x7FF0000000000000ll);
         int bj = 0x7FFFFFFF;
-        for (int wi = 0; wi < n_words; ++wi) {
+        for (int wi = wave; wi < n_words; wi += FB_WAVES) {
             const unsigned long long word = mw[wi];  // wave-uniform
             if (word == 0ull) continue;
             bool keep = false;
@@ -718,7 +754,14 @@ __global__ __launch_bounds__(256) void nn_fallback_kernel(const IcpState *__rest
             int oj = __shfl_xor(bj, off, 64);
             lexmin(bd, bj, od, oj);
         }
-        if (lane == 0) { idx_out[i] = bj; d2_out[i] = bd; }
+        if (lane == 0) { red_d[wave] = bd; red_j[wave] = bj; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 1; q < FB_WAVES; ++q) lexmin(bd, bj, red_d[q], red_j[q]);
+            idx_out[i] = bj;
+            d2_out[i] = bd;
+        }
+        __syncthreads();
     }
 }
 
@@ -817,8 +860,10 @@ __device__ void ident4(double *T) {
 // in oracle/icp.c pedp_oracle_solve6_ldlt.
 __device__ bool solve6_ldlt(const double *Ain, const double *b, double *x) {
     const int n = 6;
-    double A[6][6], tmp[6], y[6];
-    int tr[6];
+    // run by one thread; the pivoting indexes these arrays at run time, so they live in LDS
+    // (private arrays with dynamic indices would go to scratch memory: ~10x the latency)
+    __shared__ double A[6][6], tmp[6], y[6];
+    __shared__ int tr[6];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) A[i][j] = Ain[n * i + j];
     for (int k = 0; k < n; ++k) {
@@ -964,6 +1009,7 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState *__restrict__ s
     // single-GPU runs fold icp_reduce into this launch (partials != null); with an all-reduce
     // hook the packet was reduced (and summed over ranks) before.  Fixed order: 8 slices of 32
     // partials each, then the slices in order -- run-to-run bit-stable.
+    __shared__ double pk[32];
     if (partials) {
         __shared__ double slice[8][32];
         const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -976,10 +1022,14 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState *__restrict__ s
             double t = 0.0;
             for (int q = 0; q < 8; ++q) t += slice[q][threadIdx.x];
             packet[threadIdx.x] = t;
+            pk[threadIdx.x] = t;
         }
-        __syncthreads();
+    } else if (threadIdx.x < PACKET) {
+        pk[threadIdx.x] = packet[threadIdx.x];
     }
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    packet = pk;  // the serial part below reads the packet from LDS
     st->sum_cand += (long long)st->n_blocks * (NN_SB * 16);
     st->sum_fb += st->fb_count;
     st->fb_count = 0;
@@ -1165,20 +1215,21 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
         hipLaunchKernelGGL(nn_segment_kernel, dim3(1), dim3(1024), 0, c->stream, w.st, w.blk_cnt, w.blk_segstart,
                            w.seg_blk, w.seg_rank0, w.seg_n, w.max_segs, SEG_MIN_TILES / w.qt, NN_LIST_TILES / w.qt);
     }
-#define PEDP_NN_STAGE(QTV)                                                                                            \
+#define PEDP_NN_STAGE(QTV, GV)                                                                                          \
     do {                                                                                                              \
-        hipLaunchKernelGGL(nn_sweep_kernel<QTV>, dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,            \
+        hipLaunchKernelGGL((nn_sweep_kernel<QTV, GV>), dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,            \
                            (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0, w.seg_n,         \
                            (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);                                            \
         if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }                       \
         hipLaunchKernelGGL(nn_select_kernel<QTV>, dim3(sel_grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,       \
                            w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx,   \
                            w.d2, w.fb);                                                                               \
-        hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(c->num_cus), dim3(256), 0, c->stream, w.st, w.fb, w.list,     \
+        hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(2 * c->num_cus), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,     \
                            w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);       \
     } while (0)
-    if (w.qt == 4) PEDP_NN_STAGE(4);
-    else PEDP_NN_STAGE(1);
+    static const int g_exp = getenv("PEDP_SWEEP_G") ? atoi(getenv("PEDP_SWEEP_G")) : 0;  // experiment knob
+    if (w.qt == 4) { if (g_exp == 2) PEDP_NN_STAGE(4, 2); else PEDP_NN_STAGE(4, 1); }
+    else { if (g_exp == 8) PEDP_NN_STAGE(1, 8); else if (g_exp == 1) PEDP_NN_STAGE(1, 1); else PEDP_NN_STAGE(1, 4); }
 #undef PEDP_NN_STAGE
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
@@ -1352,6 +1403,7 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     *hp = h;
     PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, x->stream));
     const double r2 = r * r;
+    const double ng = n_global > 0 ? n_global : 1.0;
     for (int pass = 0; pass <= max_iter; ++pass) {
         if (!degenerate) {
             rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, false);
@@ -1370,10 +1422,11 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
                 return PEDP_ERR_COLLECTIVE;
             }
         }
+        // A fused accumulate + solve (last workgroup done runs the solve) was measured slower:
+        // the device-scope release every workgroup needs writes the whole L2 back (43 us vs 12 + 16).
         const double *fold = (!degenerate && !prm->allreduce) ? w.partials : nullptr;
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, x->stream, w.st, w.packet, fold, pass, max_iter,
-                           prm->estimator, n_global > 0 ? n_global : 1.0, prm->relative_fitness,
-                           prm->relative_rmse, want_trace ? w.trace : nullptr);
+                           prm->estimator, ng, prm->relative_fitness, prm->relative_rmse, want_trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
         // Passes after convergence are no-ops on the device but still cost launches; with the
         // early exit enabled, look at the flag every 8th pass (one 4-byte read-back, identical
