@@ -50,6 +50,13 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_erode_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                   C.c_int, C.c_void_p]),
+    "pedp_bilateral_filter_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              C.c_float, C.c_int, C.c_void_p]),
+    "pedp_depth2xyzmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pedp_depth2xyzmap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
+                                          C.c_int, C.c_void_p]),
     "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
@@ -120,13 +127,15 @@ def device_count():
 
 
 class Context:
-    """One GPU + one HIP stream.  `stream` may be a raw hipStream_t (int), e.g.
-    torch.cuda.current_stream().cuda_stream, so torch.distributed collectives order
-    with the library's kernels."""
+    """One GPU + one HIP stream.  `stream` may be a raw hipStream_t (int) of a torch.cuda.Stream
+    (`.cuda_stream`), so torch work and torch.distributed collectives issued on that stream order
+    with the library's kernels.  None / 0 (torch's DEFAULT stream has handle 0) makes the library
+    create its own non-blocking stream, which is not ordered with torch: synchronise explicitly."""
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
         self.device = device
+        self.stream_handle = int(stream) if stream else None  # None: the library created its own stream
         lib = load()
         check(lib.pedp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)),
               "pedp_ctx_create")

@@ -29,6 +29,9 @@ def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
     return [poses[k].copy() for k in keep]
 
 
+from .depth_filters import bilateral_filter_depth, depth2xyzmap, depth2xyzmap_batch, erode_depth  # noqa: E402
+
+
 class _MyCpp:
     """`mycpp = pedp_hip.compat.mycpp` gives estimater.py its `mycpp.cluster_poses`."""
     cluster_poses = staticmethod(cluster_poses)
@@ -41,6 +44,7 @@ __all__ = [
     "preprocess_source", "preprocess_target", "transform_object",
     "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
     "project_debug_rays", "load_extrinsics", "ray_tracing",
+    "erode_depth", "bilateral_filter_depth", "depth2xyzmap", "depth2xyzmap_batch",
     "registration_icp", "TransformationEstimationPointToPlane", "TransformationEstimationPointToPoint",
     "ICPConvergenceCriteria", "get_rotation_matrix_from_xyz",
     "PointCloud", "TriangleMesh", "LineSet", "PinholeCameraIntrinsic", "RegistrationResult",

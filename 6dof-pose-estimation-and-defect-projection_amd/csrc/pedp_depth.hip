@@ -1,0 +1,363 @@
+// Depth pre-filters: the reference's warp-lang kernels and its depth back-projection
+// as HIP for gfx950.
+//   erode_depth_kernel             Utils.py:356-383   (launcher :386-396, callers estimater.py:171, :255)
+//   bilateral_filter_depth_kernel  Utils.py:304-345   (launcher :347-357, callers estimater.py:172, :256)
+//   depth2xyzmap                   Utils.py:401-420   (callers run.py:89, estimater.py:175, :212)
+//   depth2xyzmap_batch             Utils.py:423-442   (caller estimater.py:259)
+// All float32 like the warp kernels (`float` = f32 there); depth2xyzmap forms x, y in float64 and
+// stores float32 (numpy promotes (u - cx) * z / fx to float64, the map is float32).
+//
+// Stencils: one workgroup = 64 x 16 output pixels, staged with their halo in LDS; a thread owns a
+// 1 x 4 column strip and walks the window column by column (u outer, v inner: the reference's
+// loop order, which fixes the float32 summation order of the bilateral filter), keeping each
+// window column in registers for its four outputs.  Compulsory traffic is 8 B per pixel (4 in,
+// 4 out): the erode kernel is HBM-bound, the bilateral kernel is bound by its 25 exp per pixel.
+#include "pedp_internal.h"
+
+namespace {
+
+constexpr int TILE_W = 64, TILE_H = 16, STRIP = 4;
+
+struct StencilArgs {
+    int H, W, radius;
+    float zfar;
+    float a, b;  // erode: depth_diff_thres, ratio_thres; bilateral: sigmaD, sigmaR
+};
+
+__device__ __forceinline__ bool depth_valid(float d, float zfar) { return d >= 0.001f && d < zfar; }
+
+// erode: out = 0 if more than ratio_thres of the window is invalid or differs from the centre by
+// more than depth_diff_thres, else the centre value unchanged (also when the centre itself is
+// invalid: the reference's first assignment is overwritten by the second, Utils.py:363-383).
+__device__ __forceinline__ float erode_finish(float d_ori, float bad, float total, float ratio) {
+    return (bad / total > ratio) ? 0.0f : d_ori;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ depth, float *__restrict__ out, StencilArgs p) {
+    constexpr int TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
+    __shared__ float tile[TH][TW];
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW, gy = y0 + ty - R, gx = x0 + tx - R;
+        tile[ty][tx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? depth[(size_t)gy * p.W + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, ys = y0 + ly * STRIP;
+    if (x >= p.W) return;
+    float d_ori[STRIP], bad[STRIP], total[STRIP];
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j) { d_ori[j] = tile[ly * STRIP + j + R][lx + R]; bad[j] = 0.f; total[j] = 0.f; }
+#pragma unroll
+    for (int du = -R; du <= R; ++du) {
+        const int u = x + du;
+        if (u < 0 || u >= p.W) continue;
+        float col[STRIP + 2 * R];
+#pragma unroll
+        for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+#pragma unroll
+            for (int dv = -R; dv <= R; ++dv) {
+                const int v = ys + j + dv;
+                if (v < 0 || v >= p.H) continue;
+                const float cur = col[j + dv + R];
+                total[j] += 1.0f;
+                if (cur < 0.001f || cur >= p.zfar || fabsf(cur - d_ori[j]) > p.a) bad[j] += 1.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j)
+        if (ys + j < p.H) out[(size_t)(ys + j) * p.W + x] = erode_finish(d_ori[j], bad[j], total[j], p.b);
+}
+
+// any radius: one thread per pixel straight from global memory (the caches carry the reuse)
+__global__ __launch_bounds__(256) void erode_generic_kernel(const float *__restrict__ depth, float *__restrict__ out,
+                                                            StencilArgs p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const float d_ori = depth[(size_t)y * p.W + x];
+    float bad = 0.f, total = 0.f;
+    for (int u = x - p.radius; u <= x + p.radius; ++u) {
+        if (u < 0 || u >= p.W) continue;
+        for (int v = y - p.radius; v <= y + p.radius; ++v) {
+            if (v < 0 || v >= p.H) continue;
+            const float cur = depth[(size_t)v * p.W + u];
+            total += 1.0f;
+            if (cur < 0.001f || cur >= p.zfar || fabsf(cur - d_ori) > p.a) bad += 1.0f;
+        }
+    }
+    out[(size_t)y * p.W + x] = erode_finish(d_ori, bad, total, p.b);
+}
+
+// bilateral weight of one neighbour (Utils.py:341): every operation float32, no contraction
+__device__ __forceinline__ float bilateral_weight(int du, int dv, float centre, float cur, float two_sd2, float two_sr2) {
+    const float a = __fdiv_rn(-(float)(du * du + dv * dv), two_sd2);
+    const float dc = __fsub_rn(centre, cur);
+    const float b = __fdiv_rn(__fmul_rn(dc, dc), two_sr2);
+    return expf(__fsub_rn(a, b));
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict__ depth, float *__restrict__ out,
+                                                        StencilArgs p) {
+    constexpr int TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
+    __shared__ float tile[TH][TW];
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW, gy = y0 + ty - R, gx = x0 + tx - R;
+        tile[ty][tx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? depth[(size_t)gy * p.W + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, ys = y0 + ly * STRIP;
+    if (x >= p.W) return;
+    const float two_sd2 = __fmul_rn(__fmul_rn(2.0f, p.a), p.a), two_sr2 = __fmul_rn(__fmul_rn(2.0f, p.b), p.b);
+    float mean[STRIP];
+    int nv[STRIP];
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j) { mean[j] = 0.f; nv[j] = 0; }
+#pragma unroll
+    for (int du = -R; du <= R; ++du) {
+        const int u = x + du;
+        if (u < 0 || u >= p.W) continue;
+        float col[STRIP + 2 * R];
+#pragma unroll
+        for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+#pragma unroll
+            for (int dv = -R; dv <= R; ++dv) {
+                const int v = ys + j + dv;
+                if (v < 0 || v >= p.H) continue;
+                const float cur = col[j + dv + R];
+                if (depth_valid(cur, p.zfar)) { ++nv[j]; mean[j] = __fadd_rn(mean[j], cur); }
+            }
+        }
+    }
+    float sw[STRIP], sum[STRIP], centre[STRIP];
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j) {
+        mean[j] = nv[j] ? __fdiv_rn(mean[j], (float)nv[j]) : 0.f;
+        sw[j] = 0.f; sum[j] = 0.f;
+        centre[j] = tile[ly * STRIP + j + R][lx + R];
+    }
+#pragma unroll
+    for (int du = -R; du <= R; ++du) {
+        const int u = x + du;
+        if (u < 0 || u >= p.W) continue;
+        float col[STRIP + 2 * R];
+#pragma unroll
+        for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+#pragma unroll
+            for (int dv = -R; dv <= R; ++dv) {
+                const int v = ys + j + dv;
+                if (v < 0 || v >= p.H) continue;
+                const float cur = col[j + dv + R];
+                if (nv[j] && depth_valid(cur, p.zfar) && fabsf(__fsub_rn(cur, mean[j])) < 0.01f) {
+                    const float w = bilateral_weight(du, dv, centre[j], cur, two_sd2, two_sr2);
+                    sw[j] = __fadd_rn(sw[j], w);
+                    sum[j] = __fadd_rn(sum[j], __fmul_rn(w, cur));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j)
+        if (ys + j < p.H) out[(size_t)(ys + j) * p.W + x] = (sw[j] > 0.f && nv[j] > 0) ? __fdiv_rn(sum[j], sw[j]) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void bilateral_generic_kernel(const float *__restrict__ depth, float *__restrict__ out,
+                                                                StencilArgs p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const float two_sd2 = __fmul_rn(__fmul_rn(2.0f, p.a), p.a), two_sr2 = __fmul_rn(__fmul_rn(2.0f, p.b), p.b);
+    float mean = 0.f;
+    int nv = 0;
+    for (int u = x - p.radius; u <= x + p.radius; ++u) {
+        if (u < 0 || u >= p.W) continue;
+        for (int v = y - p.radius; v <= y + p.radius; ++v) {
+            if (v < 0 || v >= p.H) continue;
+            const float cur = depth[(size_t)v * p.W + u];
+            if (depth_valid(cur, p.zfar)) { ++nv; mean = __fadd_rn(mean, cur); }
+        }
+    }
+    float res = 0.0f;
+    if (nv) {
+        mean = __fdiv_rn(mean, (float)nv);
+        const float centre = depth[(size_t)y * p.W + x];
+        float sw = 0.f, sum = 0.f;
+        for (int u = x - p.radius; u <= x + p.radius; ++u) {
+            if (u < 0 || u >= p.W) continue;
+            for (int v = y - p.radius; v <= y + p.radius; ++v) {
+                if (v < 0 || v >= p.H) continue;
+                const float cur = depth[(size_t)v * p.W + u];
+                if (depth_valid(cur, p.zfar) && fabsf(__fsub_rn(cur, mean)) < 0.01f) {
+                    const float w = bilateral_weight(u - x, y - v, centre, cur, two_sd2, two_sr2);
+                    sw = __fadd_rn(sw, w);
+                    sum = __fadd_rn(sum, __fmul_rn(w, cur));
+                }
+            }
+        }
+        if (sw > 0.f) res = __fdiv_rn(sum, sw);
+    }
+    out[(size_t)y * p.W + x] = res;
+}
+
+// depth2xyzmap: x = (u - cx) * z / fx in float64, stored as float32; depth < 0.001 -> (0, 0, 0)
+__global__ __launch_bounds__(256) void xyzmap_kernel(const float *__restrict__ depth, int H, int W, double fx, double fy,
+                                                     double cx, double cy, float *__restrict__ xyz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+    const float z = depth[i];
+    float X = 0.f, Y = 0.f, Z = 0.f;
+    if (!(z < 0.001f)) {
+        X = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)u, cx), (double)z), fx);
+        Y = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)v, cy), (double)z), fy);
+        Z = z;
+    }
+    xyz[3 * i] = X; xyz[3 * i + 1] = Y; xyz[3 * i + 2] = Z;
+}
+
+// depth2xyzmap_batch: float32 throughout, per-image intrinsics, invalid = z < 0.001 or z > zfar
+__global__ __launch_bounds__(256) void xyzmap_batch_kernel(const float *__restrict__ depth, int64_t HW, int W,
+                                                           const float *__restrict__ Ks /* B x 9 */, float zfar,
+                                                           float *__restrict__ xyz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const int b = blockIdx.y;
+    const float *K = Ks + 9 * b;
+    const int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
+    const float z = depth[(size_t)b * HW + i];
+    float X = 0.f, Y = 0.f, Z = 0.f;
+    if (!((z < 0.001f) || (z > zfar))) {
+        X = __fdiv_rn(__fmul_rn(__fsub_rn((float)u, K[2]), z), K[0]);
+        Y = __fdiv_rn(__fmul_rn(__fsub_rn((float)v, K[5]), z), K[4]);
+        Z = z;
+    }
+    float *o = xyz + 3 * ((size_t)b * HW + i);
+    o[0] = X; o[1] = Y; o[2] = Z;
+}
+
+int stage_in(pedp_ctx_t c, const float *src, size_t n_in, size_t n_out, int mem, const float **d_in, float **d_out,
+             float *out) {
+    *d_in = src;
+    *d_out = out;
+    if (mem == PEDP_HOST) {
+        int st = c->ray_in.reserve(sizeof(float) * n_in);
+        if (st) return st;
+        st = c->ray_out.reserve(sizeof(float) * n_out);
+        if (st) return st;
+        PEDP_HIP_CHECK(hipMemcpyAsync(c->ray_in.ptr, src, sizeof(float) * n_in, hipMemcpyHostToDevice, c->stream));
+        *d_in = (const float *)c->ray_in.ptr;
+        *d_out = (float *)c->ray_out.ptr;
+    }
+    return PEDP_OK;
+}
+
+int stage_out(pedp_ctx_t c, float *out, const float *d_out, size_t n_out, int mem) {
+    PEDP_HIP_CHECK(hipGetLastError());
+    if (mem == PEDP_HOST) {
+        PEDP_HIP_CHECK(hipMemcpyAsync(out, d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return PEDP_OK;
+}
+
+int check_image(pedp_ctx_t c, const void *in, const void *out, int H, int W, int mem, const char *who) {
+    PEDP_REQUIRE(c, "%s: null context", who);
+    PEDP_REQUIRE(H >= 0 && W >= 0 && (int64_t)H * W < (int64_t)1 << 31, "%s: image size out of range", who);
+    PEDP_REQUIRE(mem == PEDP_HOST || mem == PEDP_DEVICE, "%s: bad mem flag %d", who, mem);
+    PEDP_REQUIRE((in && out) || (int64_t)H * W == 0, "%s: null arrays", who);
+    return PEDP_OK;
+}
+
+template <int MODE>  // 0 erode, 1 bilateral
+int run_stencil(pedp_ctx_t c, const float *depth, int H, int W, StencilArgs p, int mem, float *out, const char *who) {
+    int rc = check_image(c, depth, out, H, W, mem, who);
+    if (rc) return rc;
+    PEDP_REQUIRE(p.radius >= 0 && p.radius <= 64, "%s: radius out of range", who);
+    const size_t n = (size_t)H * W;
+    if (n == 0) return PEDP_OK;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const float *d_in;
+    float *d_out;
+    rc = stage_in(c, depth, n, n, mem, &d_in, &d_out, out);
+    if (rc) return rc;
+    const dim3 tiles((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H), rows((W + 63) / 64, (H + 3) / 4);
+#define PEDP_STENCIL(RV)                                                                                      \
+    if (MODE == 0) hipLaunchKernelGGL(erode_kernel<RV>, tiles, dim3(256), 0, c->stream, d_in, d_out, p);      \
+    else hipLaunchKernelGGL(bilateral_kernel<RV>, tiles, dim3(256), 0, c->stream, d_in, d_out, p)
+    switch (p.radius) {
+        case 1: PEDP_STENCIL(1); break;
+        case 2: PEDP_STENCIL(2); break;
+        case 3: PEDP_STENCIL(3); break;
+        case 4: PEDP_STENCIL(4); break;
+        default:
+            if (MODE == 0) hipLaunchKernelGGL(erode_generic_kernel, rows, dim3(256), 0, c->stream, d_in, d_out, p);
+            else hipLaunchKernelGGL(bilateral_generic_kernel, rows, dim3(256), 0, c->stream, d_in, d_out, p);
+    }
+#undef PEDP_STENCIL
+    return stage_out(c, out, d_out, n, mem);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pedp_erode_depth(pedp_ctx_t c, const float *depth, int H, int W, int radius, float depth_diff_thres,
+                     float ratio_thres, float zfar, int mem, float *out) {
+    StencilArgs p{H, W, radius, zfar, depth_diff_thres, ratio_thres};
+    return run_stencil<0>(c, depth, H, W, p, mem, out, "pedp_erode_depth");
+}
+
+int pedp_bilateral_filter_depth(pedp_ctx_t c, const float *depth, int H, int W, int radius, float zfar, float sigmaD,
+                                float sigmaR, int mem, float *out) {
+    StencilArgs p{H, W, radius, zfar, sigmaD, sigmaR};
+    return run_stencil<1>(c, depth, H, W, p, mem, out, "pedp_bilateral_filter_depth");
+}
+
+int pedp_depth2xyzmap(pedp_ctx_t c, const float *depth, int H, int W, const double K[9], int mem, float *xyz) {
+    int rc = check_image(c, depth, xyz, H, W, mem, "pedp_depth2xyzmap");
+    if (rc) return rc;
+    PEDP_REQUIRE(K, "pedp_depth2xyzmap: null intrinsics");
+    const size_t n = (size_t)H * W;
+    if (n == 0) return PEDP_OK;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const float *d_in;
+    float *d_out;
+    rc = stage_in(c, depth, n, 3 * n, mem, &d_in, &d_out, xyz);
+    if (rc) return rc;
+    hipLaunchKernelGGL(xyzmap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, H, W, K[0], K[4],
+                       K[2], K[5], d_out);
+    return stage_out(c, xyz, d_out, 3 * n, mem);
+}
+
+int pedp_depth2xyzmap_batch(pedp_ctx_t c, const float *depths, int B, int H, int W, const float *Ks, float zfar,
+                            int mem, float *xyz) {
+    int rc = check_image(c, depths, xyz, H, W, mem, "pedp_depth2xyzmap_batch");
+    if (rc) return rc;
+    PEDP_REQUIRE(B >= 0 && B < 65536 && (int64_t)B * H * W < (int64_t)1 << 33, "pedp_depth2xyzmap_batch: batch out of range");
+    const size_t hw = (size_t)H * W, n = hw * (size_t)B;
+    if (n == 0) return PEDP_OK;
+    PEDP_REQUIRE(Ks, "pedp_depth2xyzmap_batch: null intrinsics");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const float *d_in;
+    float *d_out;
+    rc = stage_in(c, depths, n, 3 * n, mem, &d_in, &d_out, xyz);
+    if (rc) return rc;
+    // intrinsics: B x 9 float32 on the host in both modes (a few bytes per image)
+    int st = c->proj.reserve(sizeof(float) * 9 * (size_t)B);
+    if (st) return st;
+    PEDP_HIP_CHECK(hipMemcpyAsync(c->proj.ptr, Ks, sizeof(float) * 9 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(xyzmap_batch_kernel, dim3((unsigned)((hw + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, d_in,
+                       (int64_t)hw, W, (const float *)c->proj.ptr, zfar, d_out);
+    return stage_out(c, xyz, d_out, 3 * n, mem);
+}
+
+}  // extern "C"

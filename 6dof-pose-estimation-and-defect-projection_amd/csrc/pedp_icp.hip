@@ -58,7 +58,7 @@ constexpr int NN_TU = 4;    // rows are padded to multiples of 16 * NN_TU (= the
 // fold-and-compare epilogue and of the exact re-scoring.  QT = 1 inside a registration with a
 // finite radius (finest culling), QT = 4 for dense sweeps (3 instead of 6 VALU ops per MFMA).
 constexpr int NN_LIST_TILES = 2048; // most MFMA tiles one sweep wave walks (its unit list lives in LDS)
-constexpr int SEG_MIN_TILES = 32;   // MFMA tiles per sweep segment at least
+constexpr int SEG_MIN_TILES = 64;   // MFMA tiles per sweep segment at least
 constexpr int CULL_WORDS = 8;       // 64-unit mask words one cull wave fills
 constexpr int SORT_BITS = 5;          // spatial sort: 32^3 Hilbert-ordered cells over the cloud's bounding box
 constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
@@ -1227,9 +1227,8 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
         hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(2 * c->num_cus), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,     \
                            w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);       \
     } while (0)
-    static const int g_exp = getenv("PEDP_SWEEP_G") ? atoi(getenv("PEDP_SWEEP_G")) : 0;  // experiment knob
-    if (w.qt == 4) { if (g_exp == 2) PEDP_NN_STAGE(4, 2); else PEDP_NN_STAGE(4, 1); }
-    else { if (g_exp == 8) PEDP_NN_STAGE(1, 8); else if (g_exp == 1) PEDP_NN_STAGE(1, 1); else PEDP_NN_STAGE(1, 4); }
+    if (w.qt == 4) PEDP_NN_STAGE(4, 2);
+    else PEDP_NN_STAGE(1, 4);
 #undef PEDP_NN_STAGE
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;

@@ -52,15 +52,24 @@ class _DevicePacket:
 
 
 class HipBackend:
-    """Product backend: libpedp_hip.so on this rank's GPU, on torch's current stream so the
-    collectives torch.distributed enqueues are ordered with the library's kernels."""
+    """Product backend: libpedp_hip.so on this rank's GPU.  The library's kernels and the
+    collectives of torch.distributed share ONE explicit HIP stream (a torch.cuda.Stream the
+    context is bound to): a collective enqueued inside `ordered()` waits for the kernels before
+    it and holds back the kernels after it, with no host synchronisation.  (torch's default
+    stream has handle 0, which the C ABI reads as "create your own non-blocking stream" -- work
+    on such a stream is NOT ordered with torch's.)"""
 
     def __init__(self, device=None):
         import torch
 
         self.torch = torch
         self.device = torch.cuda.current_device() if device is None else device
-        self.ctx = _lib.Context(self.device, stream=torch.cuda.current_stream(self.device).cuda_stream)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx = _lib.Context(self.device, stream=self.stream.cuda_stream)
+
+    def ordered(self):
+        """Context manager: torch work issued inside runs on the library's stream."""
+        return self.torch.cuda.stream(self.stream)
 
     # ---- rays
     def make_mesh(self, vertices_f32, triangles):
@@ -75,7 +84,8 @@ class HipBackend:
         rec = np.empty((len(t_hit), 2), np.uint32)
         rec[:, 0] = t_hit.view(np.uint32)
         rec[:, 1] = ids
-        return self.torch.from_numpy(rec.view(np.int32)).to(f"cuda:{self.device}")
+        with self.ordered():
+            return self.torch.from_numpy(rec.view(np.int32)).to(f"cuda:{self.device}")
 
     # ---- ICP
     def make_cloud(self, points, normals=None):
@@ -91,10 +101,18 @@ class HipBackend:
         return self.torch.as_tensor(_DevicePacket(ptr, n), device=f"cuda:{self.device}")
 
 
-def sharded_cast_rays(backend, vertices_f32, triangles, rays6, group=None, gather=True):
+def _ordered(backend):
+    """The backend's stream scope (HIP) or nothing (the CPU stand-ins of the gloo tests)."""
+    import contextlib
+
+    return backend.ordered() if hasattr(backend, "ordered") else contextlib.nullcontext()
+
+
+def sharded_cast_rays(backend, vertices_f32, triangles, rays6, group=None, gather=True, always_collective=False):
     """Cast `rays6` (the SAME full array on every rank) with rows sharded over the ranks and
     all-gather the hit records.  Returns (t_hit, primitive_ids) for all rays (or only this
-    rank's block when gather=False)."""
+    rank's block when gather=False).  always_collective runs the all-gather even on one rank
+    (exercises the stream ordering with RCCL on a single GPU)."""
     import torch
     import torch.distributed as dist
 
@@ -104,17 +122,18 @@ def sharded_cast_rays(backend, vertices_f32, triangles, rays6, group=None, gathe
     lo, hi = shard_bounds(n, rank, world)
     mesh = backend.make_mesh(vertices_f32, triangles)
     t_loc, id_loc = backend.cast(mesh, rays6[lo:hi])
-    if world == 1 or not gather:
+    if (world == 1 and not always_collective) or not gather:
         return t_loc, id_loc
     # equal-size blocks for all_gather_into_tensor: pad to the largest shard
     width = shard_bounds(n, 0, world)[1]
-    rec = backend.hit_records_tensor(t_loc, id_loc)
-    if rec.shape[0] < width:
-        pad = torch.zeros((width - rec.shape[0], 2), dtype=rec.dtype, device=rec.device)
-        rec = torch.cat([rec, pad])
-    out = torch.empty((world * width, 2), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
-    out = out.cpu().numpy().view(np.uint32).reshape(world, width, 2)
+    with _ordered(backend):
+        rec = backend.hit_records_tensor(t_loc, id_loc)
+        if rec.shape[0] < width:
+            pad = torch.zeros((width - rec.shape[0], 2), dtype=rec.dtype, device=rec.device)
+            rec = torch.cat([rec, pad])
+        out = torch.empty((world * width, 2), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+        out = out.cpu().numpy().view(np.uint32).reshape(world, width, 2)
     t_all = np.empty(n, np.float32)
     id_all = np.empty(n, np.uint32)
     for r in range(world):
@@ -126,7 +145,7 @@ def sharded_cast_rays(backend, vertices_f32, triangles, rays6, group=None, gathe
 
 def sharded_registration_icp(backend, source_points, target_points, target_normals, radius, init,
                              estimator=_lib.POINT_TO_PLANE, max_iteration=30, rel_fitness=1e-6, rel_rmse=1e-6,
-                             group=None):
+                             group=None, always_collective=False):
     """registration_icp with the scene sharded over the ranks (every rank passes the SAME
     full arrays and takes its block).  All ranks return the identical result dict."""
     import torch.distributed as dist
@@ -139,8 +158,10 @@ def sharded_registration_icp(backend, source_points, target_points, target_norma
     tgt = backend.make_cloud(target_points, target_normals)
 
     def allreduce(ptr, count, stream):
-        t = backend.packet_tensor(ptr, count)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        # called between the reduce and the solve kernel of a pass, which are on `stream`
+        with _ordered(backend):
+            t = backend.packet_tensor(ptr, count)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
-    hook = allreduce if world > 1 else None
+    hook = allreduce if (world > 1 or always_collective) else None
     return backend.icp(src, tgt, radius, init, estimator, max_iteration, rel_fitness, rel_rmse, hook, n)

@@ -138,6 +138,26 @@ def scene_from_depth(t_hit, dirs, noise_sigma=0.5, back_plane=600.0, seed=0):
     return np.ascontiguousarray(pts)
 
 
+def depth_image(height, width, seed=0, nan=True):
+    """Sensor-like depth in metres (the unit of the reference's depth filters, zfar = 100,
+    thresholds 1 mm): a slanted wavy surface with a step edge, 1 mm noise, holes (0), sub-
+    threshold values, readings beyond zfar and, optionally, a few NaN."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    d = 0.6 + 0.0008 * x + 0.0004 * y + 0.01 * np.sin(x / 7.0) * np.cos(y / 5.0)
+    d[:, width // 2:] += 0.15                                   # step edge
+    d += rng.normal(0, 0.001, d.shape)
+    u = rng.uniform(size=d.shape)
+    d[u < 0.05] = 0.0                                           # holes
+    d[(u >= 0.05) & (u < 0.06)] = 0.0005                        # below the validity threshold
+    d[(u >= 0.06) & (u < 0.07)] = 150.0                         # beyond zfar
+    blob = (x - width * 0.3) ** 2 + (y - height * 0.6) ** 2 < (min(height, width) * 0.12) ** 2
+    d[blob] = 0.0                                               # a larger hole
+    if nan:
+        d[(u >= 0.07) & (u < 0.072)] = np.nan
+    return d.astype(np.float32)
+
+
 class Frame:
     """Everything one benchmark / parity frame needs, built lazily around a ray caster."""
 

@@ -81,7 +81,10 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    ctx = _lib.Context(local, stream=torch.cuda.current_stream(dev).cuda_stream)
+    # One explicit HIP stream for the library's kernels AND the collectives (torch's default
+    # stream has handle 0 = "library creates its own stream", which NCCL would not order with).
+    stream = torch.cuda.Stream(device=dev)
+    ctx = _lib.Context(local, stream=stream.cuda_stream)
 
     frame = synth.Frame(args.config)
     n_rays, n_tris = frame.n_rays, frame.n_tris
@@ -112,8 +115,9 @@ def main():
         b = time.perf_counter()
         cast()
         if world > 1:
-            dist.all_gather_into_tensor(gathered_t, t_hit)
-            dist.all_gather_into_tensor(gathered_i, prim)
+            with torch.cuda.stream(stream):  # ordered behind the sweep on the same stream
+                dist.all_gather_into_tensor(gathered_t, t_hit)
+                dist.all_gather_into_tensor(gathered_i, prim)
         if record:
             icp_ms.append(1e3 * (b - a))           # pedp_icp returns after its stream sync
             sweep_ms.append(_lib.raycast_last_sweep_ms(ctx))  # HIP events around the sweep kernel
@@ -214,7 +218,7 @@ def main():
                                             "triangle stream per launch; the records are L2-resident, real HBM traffic "
                                             "is about the compulsory 15 MB"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(frame, depth)
         print(json.dumps(out), flush=True)
     if world > 1:

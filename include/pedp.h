@@ -124,6 +124,30 @@ int pedp_project_heatmap(pedp_ctx_t ctx, pedp_mesh_t mesh, const pedp_pinhole *c
                          double *points, double *intensities, int32_t *pixels, uint32_t *prim_id,
                          int64_t *n_rays, int64_t *n_hits);
 
+/* ---------------------------------------------------------------- depth pre-filters
+ * the reference's warp-lang kernels (CUDA-only JIT) and its depth back-projection.
+ * Images are H x W float32, row-major; PEDP_HOST copies in and out and returns after completion,
+ * PEDP_DEVICE only enqueues on the context's stream.  Defaults of the reference in brackets.
+ *
+ * erode_depth (Utils.py:356-396; estimater.py:171, :255): a pixel becomes 0 when more than
+ * ratio_thres [0.8] of its (2 radius + 1)^2 window [radius 2] is invalid (< 0.001 or >= zfar
+ * [100]) or differs from the centre by more than depth_diff_thres [0.001]; else it is kept. */
+int pedp_erode_depth(pedp_ctx_t ctx, const float *depth, int H, int W, int radius, float depth_diff_thres,
+                     float ratio_thres, float zfar, int mem, float *out);
+/* bilateral_filter_depth (Utils.py:304-357; estimater.py:172, :256): mean of the valid window
+ * pixels, then a Gaussian (sigmaD [2] in pixels, sigmaR [100000] in depth) weighted average over
+ * the valid pixels within 0.01 of that mean; float32, window walked column by column. */
+int pedp_bilateral_filter_depth(pedp_ctx_t ctx, const float *depth, int H, int W, int radius, float zfar,
+                                float sigmaD, float sigmaR, int mem, float *out);
+/* depth2xyzmap (Utils.py:401-420; run.py:89, estimater.py:175, :212), uvs=None form: xyz is
+ * H x W x 3 float32, ((u - cx) z / fx, (v - cy) z / fy, z) formed in float64; depth < 0.001 -> 0.
+ * K: row-major 3 x 3 float64 on the host. */
+int pedp_depth2xyzmap(pedp_ctx_t ctx, const float *depth, int H, int W, const double K[9], int mem, float *xyz);
+/* depth2xyzmap_batch (Utils.py:423-442; estimater.py:259): B images, Ks = B x 9 float32 on the
+ * host, float32 arithmetic, invalid = depth < 0.001 or depth > zfar. */
+int pedp_depth2xyzmap_batch(pedp_ctx_t ctx, const float *depths, int B, int H, int W, const float *Ks, float zfar,
+                            int mem, float *xyz);
+
 /* ---------------------------------------------------------------- ICP
  * Replaces src/pose_estimation.py:519-521 and :654-660:
  *     o3d.pipelines.registration.registration_icp(source, target, max_corr_dist, init,

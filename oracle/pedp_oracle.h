@@ -86,6 +86,14 @@ void pedp_oracle_vec6_to_T(const double x[6], double T[16]);
 void pedp_oracle_kabsch(const double *S, const double *Tg, int64_t K, double T[16]);
 void pedp_oracle_rot_xyz(const double abc[3], double R[9]); /* Rx(a)Ry(b)Rz(c) */
 
+/* depth pre-filters (depth.c): Utils.py:304-442 */
+void pedp_oracle_erode_depth(const float *depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
+                             float zfar, float *out, int nthreads);
+void pedp_oracle_bilateral_depth(const float *depth, int H, int W, int radius, float zfar, float sigmaD, float sigmaR,
+                                 float *out, int nthreads);
+void pedp_oracle_depth2xyzmap(const float *depth, int H, int W, const double *K, float *xyz);
+void pedp_oracle_depth2xyzmap_batch(const float *depths, int B, int H, int W, const float *Ks, float zfar, float *xyz);
+
 /* ---- cluster_poses (float32; mycpp/src/app/pybind_api.cpp:24-68) ---- */
 int pedp_oracle_cluster_poses(float angle_diff_deg, float dist_diff, const float *poses,
                               int n, const float *syms, int s, int32_t *keep_idx,

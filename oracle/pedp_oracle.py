@@ -142,6 +142,40 @@ def project_heatmap(verts32, tris, heatmap, K, threshold=0.5, origin=(0, 0, 0), 
             "primitive_ids": hit["primitive_ids"][valid], "n_rays": len(d), "rays6": rays6}
 
 
+def erode_depth(depth, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100, nthreads=0):
+    d = np.ascontiguousarray(depth, np.float32)
+    out = np.zeros_like(d)
+    lib().pedp_oracle_erode_depth(_p(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(radius),
+                                  C.c_float(depth_diff_thres), C.c_float(ratio_thres), C.c_float(zfar), _p(out),
+                                  C.c_int(nthreads or os.cpu_count()))
+    return out
+
+
+def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, nthreads=0):
+    d = np.ascontiguousarray(depth, np.float32)
+    out = np.zeros_like(d)
+    lib().pedp_oracle_bilateral_depth(_p(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(radius), C.c_float(zfar),
+                                      C.c_float(sigmaD), C.c_float(sigmaR), _p(out), C.c_int(nthreads or os.cpu_count()))
+    return out
+
+
+def depth2xyzmap(depth, K):
+    d = np.ascontiguousarray(depth, np.float32)
+    Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+    out = np.zeros(d.shape + (3,), np.float32)
+    lib().pedp_oracle_depth2xyzmap(_p(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), _p(Kd), _p(out))
+    return out
+
+
+def depth2xyzmap_batch(depths, Ks, zfar):
+    d = np.ascontiguousarray(depths, np.float32)
+    Kf = np.ascontiguousarray(Ks, np.float32).reshape(len(d), 9)
+    out = np.zeros(d.shape + (3,), np.float32)
+    lib().pedp_oracle_depth2xyzmap_batch(_p(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(d.shape[2]), _p(Kf),
+                                         C.c_float(zfar), _p(out))
+    return out
+
+
 def icp(src, tgt, tgt_normals, max_corr_dist, init, estimator=P2PLANE, max_iter=30, rel_fitness=1e-6,
         rel_rmse=1e-6, kdtree=True, nthreads=0, want_trace=True):
     s = np.ascontiguousarray(src, np.float64).reshape(-1, 3)

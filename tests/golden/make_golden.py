@@ -113,7 +113,22 @@ def main():
                         rmse=np.array([t[2] for t in trace]), T=np.array([t[3] for t in trace]),
                         best_T=res.transformation, best_fitness=res.fitness, best_rmse=res.inlier_rmse,
                         rng_after=np.random.uniform())
+    g7()
     print("golden fixtures written to", HERE)
+
+
+def g7():
+    """G7: depth pre-filters on a 48 x 64 sensor-like image (default parameters and one
+    non-default set), back-projection single and batched."""
+    d = synth.depth_image(48, 64, seed=7)
+    K = np.array([[60.0, 0, 31.5], [0, 61.0, 23.5], [0, 0, 1]])
+    d2 = synth.depth_image(48, 64, seed=8, nan=False)
+    Ks = np.stack([K, K * np.array([[1.1], [0.9], [1.0]])]).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g7_depth_filters.npz"), depth=d, K=K, depths=np.stack([d, d2]), Ks=Ks,
+                        erode=oracle.erode_depth(d), erode_r3=oracle.erode_depth(d, 3, 0.002, 0.5, 1.0),
+                        bilateral=oracle.bilateral_filter_depth(d),
+                        bilateral_r1=oracle.bilateral_filter_depth(d, 1, 1.0, 1.5, 0.02),
+                        xyz=oracle.depth2xyzmap(d, K), xyz_batch=oracle.depth2xyzmap_batch(np.stack([d, d2]), Ks, 0.9))
 
 
 if __name__ == "__main__":

@@ -154,9 +154,9 @@ def test_dist_hip_backend_single_rank(oracle):
     seen = []
 
     def fake_allreduce(ptr, n, stream):
-        pkt = be.packet_tensor(ptr, n)
-        torch.cuda.current_stream().synchronize()
-        seen.append(float(pkt[28].item()))      # correspondence count of this pass
+        with be.ordered():                      # the library's stream: item() waits for the reduce kernel
+            pkt = be.packet_tensor(ptr, n)
+            seen.append(float(pkt[28].item()))  # correspondence count of this pass
 
     from pedp_hip import _lib
     r2 = _lib.icp(be.ctx, be.make_cloud(scene), be.make_cloud(f.model_points, f.normals), 10.0, f.icp_init(),
@@ -164,6 +164,36 @@ def test_dist_hip_backend_single_rank(oracle):
                   n_source_global=len(scene))
     assert len(seen) == 6 and seen[-1] == round(ro["fitness"] * len(scene))
     assert np.abs(r2["T"] - ro["T"]).max() < 1e-5
+
+
+def test_dist_hip_backend_rccl_single_rank_group(oracle):
+    """The real collectives on one GPU: a world-size-1 RCCL group with always_collective=True
+    sends the hit records through all_gather_into_tensor and every ICP pass through all_reduce,
+    on the stream the library's kernels run on (ordering without host synchronisation)."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from pedp_hip import dist as pdist
+
+    f = _frame()
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+        created = True
+    try:
+        be = pdist.HipBackend(0)
+        ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+        for _ in range(3):  # repeated: an unordered collective would read a half-written buffer sooner or later
+            t, ids = pdist.sharded_cast_rays(be, f.verts_posed, f.tris, f.rays6, always_collective=True)
+            assert np.array_equal(ids, ref["primitive_ids"]) and np.array_equal(t.view(np.uint32), ref["t_hit"].view(np.uint32))
+        scene = f.scene(ref["t_hit"])
+        ro = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=8, rel_fitness=-1, rel_rmse=-1)
+        for _ in range(3):
+            res = pdist.sharded_registration_icp(be, scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iteration=8,
+                                                 rel_fitness=-1, rel_rmse=-1, always_collective=True)
+            assert res["fitness"] == ro["fitness"] and np.abs(res["T"] - ro["T"]).max() < 1e-5
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_icp_with_shuffled_subsampled_target(oracle):

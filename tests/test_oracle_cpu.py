@@ -280,3 +280,90 @@ def test_g6_improve_result_rng_order(oracle):
     assert np.abs(np.array([t[3] for t in trace]) - g["T"]).max() < 1e-12
     assert res.fitness == float(g["best_fitness"]) and abs(np.random.uniform() - float(g["rng_after"])) == 0
     assert param["refine_registration"]["distance_threshold"] == 8.0             # caller's dict untouched (deepcopy)
+
+
+# ------------------------------------------------------------------ depth pre-filters (G7)
+def _py_erode(depth, radius, thr, ratio, zfar):
+    """The warp kernel's loop nest (Utils.py:356-383) in plain Python on float32 scalars."""
+    f = np.float32
+    H, W = depth.shape
+    out = np.zeros_like(depth)
+    for h in range(H):
+        for w in range(W):
+            d_ori = depth[h, w]
+            bad, total = f(0), f(0)
+            for u in range(w - radius, w + radius + 1):
+                if u < 0 or u >= W:
+                    continue
+                for v in range(h - radius, h + radius + 1):
+                    if v < 0 or v >= H:
+                        continue
+                    cur = depth[v, u]
+                    total += f(1)
+                    if cur < f(0.001) or cur >= f(zfar) or abs(f(cur - d_ori)) > f(thr):
+                        bad += f(1)
+            out[h, w] = f(0) if f(bad / total) > f(ratio) else d_ori
+    return out
+
+
+def _py_bilateral(depth, radius, zfar, sD, sR):
+    """Utils.py:304-345 in plain Python, float32 step by step."""
+    f = np.float32
+    H, W = depth.shape
+    out = np.zeros_like(depth)
+    for h in range(H):
+        for w in range(W):
+            mean, nv = f(0), 0
+            win = [(u, v) for u in range(w - radius, w + radius + 1) if 0 <= u < W
+                   for v in range(h - radius, h + radius + 1) if 0 <= v < H]
+            for u, v in win:
+                cur = depth[v, u]
+                if cur >= f(0.001) and cur < f(zfar):
+                    nv += 1
+                    mean = f(mean + cur)
+            if nv == 0:
+                continue
+            mean = f(mean / f(nv))
+            c = depth[h, w]
+            sw, sm = f(0), f(0)
+            for u, v in win:
+                cur = depth[v, u]
+                if cur >= f(0.001) and cur < f(zfar) and abs(f(cur - mean)) < f(0.01):
+                    a = f(-f((u - w) ** 2 + (h - v) ** 2) / f(f(f(2) * f(sD)) * f(sD)))
+                    b = f(f(f(c - cur) * f(c - cur)) / f(f(f(2) * f(sR)) * f(sR)))
+                    wgt = f(np.exp(f(a - b)))
+                    sw = f(sw + wgt)
+                    sm = f(sm + f(wgt * cur))
+            if sw > 0:
+                out[h, w] = f(sm / sw)
+    return out
+
+
+def test_depth_filters_golden_and_python_restatement(oracle):
+    from pedp_hip import synth
+
+    g = np.load(os.path.join(GOLD, "g7_depth_filters.npz"))
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)  # noqa: E731
+    assert same(oracle.erode_depth(g["depth"]), g["erode"])
+    assert same(oracle.erode_depth(g["depth"], 3, 0.002, 0.5, 1.0), g["erode_r3"])
+    assert same(oracle.bilateral_filter_depth(g["depth"]), g["bilateral"])
+    assert same(oracle.bilateral_filter_depth(g["depth"], 1, 1.0, 1.5, 0.02), g["bilateral_r1"])
+    assert same(oracle.depth2xyzmap(g["depth"], g["K"]), g["xyz"])
+    assert same(oracle.depth2xyzmap_batch(g["depths"], g["Ks"], 0.9), g["xyz_batch"])
+    # an independent statement of the same loops on a small image
+    d = synth.depth_image(14, 19, seed=5)
+    with np.errstate(invalid="ignore"):
+        assert same(oracle.erode_depth(d, 2), _py_erode(d, 2, 0.001, 0.8, 100))
+        assert same(oracle.erode_depth(d, 1, 0.003, 0.4, 0.9), _py_erode(d, 1, 0.003, 0.4, 0.9))
+        pb = _py_bilateral(d, 2, 100, 2, 100000)
+    ob = oracle.bilateral_filter_depth(d, 2)
+    assert np.array_equal(np.isnan(ob), np.isnan(pb))
+    m = ~np.isnan(ob)
+    assert np.all(np.abs(ob[m] - pb[m]) <= 2e-6 * np.abs(pb[m]))  # numpy's float32 exp vs libm expf
+    # numpy statement of depth2xyzmap (Utils.py:401-420)
+    K = g["K"]
+    dd = np.nan_to_num(d)
+    vs, us = np.meshgrid(np.arange(14), np.arange(19), indexing="ij")
+    pts = np.stack(((us - K[0, 2]) * dd / K[0, 0], (vs - K[1, 2]) * dd / K[1, 1], dd), -1).astype(np.float32)
+    pts[dd < 0.001] = 0
+    assert same(oracle.depth2xyzmap(dd, K), pts)
