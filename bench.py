@@ -196,6 +196,7 @@ def main():
             "roofline": {"kernel": "nn_sweep_kernel", "bound": "mfma", "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
                          "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"), "kernel_ms": nn,
+                         "mfma_util_pmc": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
                          "note": f"{FLOP_PER_PAIR} flop x {len(scene)} scene x {len(frame.model_points)} model points "
                                  "(all pairs, one correspondence pass) / HIP-event duration of the sweep kernel; "
                                  "inside a step the same kernel runs on the bounding-box survivors only "

@@ -1,28 +1,63 @@
-"""Turns the rocprofv3 --pmc CSVs under profiles/ into profiles/r01_traffic.json (bytes per
-launch for the roofline kernels).  gfx950 correction (MI355X_MICROARCH.md s.HBM): FETCH_SIZE
-counts 64 B per 128-B request for wide coalesced streams, so vector-streaming reads are
-doubled; scalar-load dominated kernels are left as measured (uncalibrated width) and flagged."""
-import collections, csv, json, os, sys
+"""Turns the rocprofv3 --pmc CSVs under profiles/ (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv,
+optional r01_pmc_sq.csv) into profiles/r01_traffic.json: HBM-side bytes per launch for the kernels
+bench.py and DESIGN.md quote.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
+counts 64 B per 128-B request for wide coalesced streams, so kernels whose reads are vector streams
+are doubled; kernels whose reads are scalar loads (s_load_dwordx16 of triangle records) are left
+as measured (width uncalibrated) and flagged.  WRITE_SIZE is taken as is."""
+import collections, csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+
+
 def load(name):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(P, name))):
-        d[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return d
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
-f, w = load("r01_pmc_fetch_size.csv"), load("r01_pmc_write_size.csv")
-def pick(d, key):
+
+
+f, w, sq = load("r01_pmc_fetch_size.csv"), load("r01_pmc_write_size.csv"), load("r01_pmc_sq.csv")
+
+
+def pick(d, key, counter):
     for k, v in d.items():
-        if key in k:
-            return sum(v) / len(v)
+        if key in k and counter in v:
+            return sum(v[counter]) / len(v[counter])
     return None
+
+
+KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector streams)
+    ("nn_sweep_kernel<4", "nn_sweep_kernel", True),
+    ("nn_sweep_kernel<1", "nn_sweep_kernel_culled", True),
+    ("ray_sweep_rpl_kernel<true>", "ray_sweep_rpl_kernel", False),
+    ("ray_sweep_seg_kernel", "ray_sweep_seg_kernel", False),
+    ("ray_cull_mask_kernel", "ray_cull_mask_kernel", True),
+    ("erode_kernel<2>", "erode_kernel", True),
+    ("xyzmap_kernel", "xyzmap_kernel", True),
+)
 out = {}
-for key, name, double in (("nn_sweep_kernel", "nn_sweep_kernel", True), ("ray_sweep_rpl_kernel<true>", "ray_sweep_rpl_kernel", False),
-                          ("ray_sweep_cull_kernel", "ray_sweep_cull_kernel", False)):
-    fe, wr = pick(f, key), pick(w, key)
-    out[name] = {"fetch_bytes_raw": fe, "fetch_bytes_corrected": fe * (2 if double else 1), "write_bytes": wr,
-                 "hbm_bytes_per_launch": fe * (2 if double else 1) + wr,
-                 "note": "FETCH_SIZE doubled (16-B/lane coalesced streams)" if double else
-                         "FETCH_SIZE as measured: reads are scalar loads (s_load_dwordx16), width uncalibrated on gfx950"}
+for key, name, stream in KERNELS:
+    fe, wr = pick(f, key, "FETCH_SIZE"), pick(w, key, "WRITE_SIZE")
+    if fe is None or wr is None:
+        continue
+    fe, wr = fe * 1024.0, wr * 1024.0  # the counters are in KiB
+    rec = {"fetch_bytes_raw": fe, "fetch_bytes_corrected": fe * (2 if stream else 1), "write_bytes": wr,
+           "hbm_bytes_per_launch": fe * (2 if stream else 1) + wr,
+           "note": "FETCH_SIZE doubled (coalesced vector streams, gfx950 tallies 128-B requests at 64 B)" if stream else
+                   "FETCH_SIZE as measured: reads are scalar loads (s_load_dwordx16), width uncalibrated on gfx950"}
+    for c in ("SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_ACTIVE_INST_VALU",
+              "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+        v = pick(sq, key, c)
+        if v is not None:
+            rec[c] = v
+    if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") and rec.get("GRBM_GUI_ACTIVE"):
+        # rocprofv3's MfmaUtil: busy cycles summed over the 1024 SIMDs / (kernel cycles x 1024);
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+        rec["mfma_util"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        rec["mfma_flop"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
+    out[name] = rec
 json.dump(out, open(os.path.join(P, "r01_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
