@@ -34,14 +34,19 @@
 //
 // Variant 3 (default when all rays share one origin), ray per lane WITH conservative
 // culling -- still every triangle is accounted for, most of them by a bound instead of a
-// test.  Triangles are taken in clusters of 16 consecutive records with a bounding sphere
-// (mesh build); per call every cluster gets its cone from the shared origin (unit axis v,
-// cos/sin of the half-angle psi); rays are binned by direction (octahedral map, 256 x 256
-// cells in Hilbert-curve order, counting sort) so a wave holds 64 rays of one small solid angle, whose cone
-// (axis a, half-angle theta) is reduced in-kernel from the actual rays.  A ray of the wave can
-// only hit a triangle of the cluster if angle(a, v) <= theta + psi, so clusters with
-// v.a < cos(theta + psi) are skipped; the test runs lane-parallel (lane l tests cluster
-// base + l, one ballot per 64 clusters) and the survivors are swept exactly like variant 1.
+// test.  Triangles are taken in clusters of 16 consecutive records with a bounding sphere and
+// every 64 clusters in a super-cluster sphere (mesh build); per call every (super-)cluster gets
+// its cone from the shared origin (unit axis v, cos/sin of the half-angle psi); rays are binned
+// by direction (octahedral map, 256 x 256 cells in Hilbert-curve order, counting sort) so a
+// packet of 64 consecutive rays covers one small solid angle, whose cone (axis a, half-angle
+// theta) is reduced from the actual rays.  A ray of the packet can only hit a triangle of a
+// cluster if angle(a, v) <= theta + psi, so clusters with v.a < cos(theta + psi) are dropped:
+//   ray_cull_mask_kernel   one wave per packet, super-cluster cones first, then lane l tests
+//                          cluster 64 w + l of every surviving word: the ballot IS the mask word
+//   ray_segment_kernel     cuts every packet's survivor list into segments of equal length
+//                          (device-side scan), so each sweep wave has the same work
+//   ray_sweep_seg_kernel   one wave per segment: mask ranks -> LDS cluster list -> the loop body
+//                          of variant 1 on those clusters
 // Culling is conservative (margins below), so results stay bit-identical to the oracle.
 //
 // Variant 2, triangle per lane: few rays against a big mesh.  Lanes own consecutive
