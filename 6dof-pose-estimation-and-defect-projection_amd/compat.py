@@ -9,7 +9,7 @@ import numpy as np
 from . import _lib
 from .geometry import (LineSet, PinholeCameraIntrinsic, PointCloud, RegistrationResult,  # noqa: F401
                        TriangleMesh)
-from .icp_refine import (improve_result, predict_z_axis_adjustment, preprocess_source,  # noqa: F401
+from .icp_refine import (determine_pose, improve_result, predict_z_axis_adjustment, preprocess_source,  # noqa: F401
                          preprocess_target, refine_pose_with_icp, refine_registration, transform_object)
 from .ray_projection import (compute_rays, create_intersection_pcd, heatmap_to_points,  # noqa: F401
                              intersect_rays_with_mesh, load_extrinsics, project_debug_rays, ray_tracing)
@@ -40,7 +40,7 @@ class _MyCpp:
 mycpp = _MyCpp()
 
 __all__ = [
-    "refine_registration", "improve_result", "predict_z_axis_adjustment", "refine_pose_with_icp",
+    "refine_registration", "improve_result", "predict_z_axis_adjustment", "refine_pose_with_icp", "determine_pose",
     "preprocess_source", "preprocess_target", "transform_object",
     "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
     "project_debug_rays", "load_extrinsics", "ray_tracing",

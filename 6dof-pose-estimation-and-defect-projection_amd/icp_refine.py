@@ -180,3 +180,14 @@ def refine_pose_with_icp(source, target, background, initial_fp_transformation, 
                  f"Fitness: {best.fitness:.4f}\n:: Final Transformation Matrix:\n{model_in_scene}")
     target_transformed = transform_object(target, model_in_scene)
     return target_transformed, best, z_adjustment, target_processed
+
+
+def determine_pose(source, target, background, initial_fp_transformation, parameters, icp=False):
+    """pose_estimation.py:686-747.  With icp=False (the only form run.py's callers use) this is
+    the same chain as refine_pose_with_icp: preprocess, z search, in-place z adjustment,
+    improve_result.  icp=True starts from run_icp's FPFH + RANSAC global registration
+    (pose_estimation.py:411-503), which is outside the hot path and not provided."""
+    if icp:
+        raise NotImplementedError("determine_pose(icp=True): global registration (run_icp, FPFH + RANSAC) is not part "
+                                  "of this build; pass the FoundationPose estimate with icp=False")
+    return refine_pose_with_icp(source, target, background, initial_fp_transformation, parameters)
