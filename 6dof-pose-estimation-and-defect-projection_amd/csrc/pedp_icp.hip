@@ -560,8 +560,9 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
 #else
-                    if (u == 0) vq[sb] = fminf(fminf(cur[0], cur[1]), fminf(cur[2], cur[3]));
-                    else vq[sb] = fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), fminf(cur[2], cur[3]));
+                    // two v_min3 per MFMA (linear nesting is what the compiler turns into v_min3)
+                    if (u == 0) vq[sb] = fminf(fminf(fminf(cur[0], cur[1]), cur[2]), cur[3]);
+                    else vq[sb] = fminf(fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), cur[2]), cur[3]);
                     if (u == QT - 1) {
                         const float v = vq[sb];
                         t1[sb] = v < b1[sb] ? (int)unit : t1[sb];
