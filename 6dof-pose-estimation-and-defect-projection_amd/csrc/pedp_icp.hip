@@ -274,17 +274,6 @@ __device__ __forceinline__ void pack_store(const PackPoint &p, int slot, float4 
     S[slot] = p.sx * p.sx + p.sy * p.sy + p.sz * p.sz;
     list[slot] = p.i;
 }
-__device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
 __global__ __launch_bounds__(256) void icp_transform_pack_kernel(
     IcpState *__restrict__ st, int mode, const double *__restrict__ src, double *__restrict__ P,
     const int32_t *__restrict__ perm, int64_t N, float4 *__restrict__ B, float *__restrict__ eps, float *__restrict__ S,

@@ -1,3 +1,4 @@
+"""Timing of one 20-iteration registration at bench size and of pedp_icp_batched (32 poses): python tools/icp_only.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

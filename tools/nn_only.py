@@ -1,3 +1,4 @@
+"""Timing of the dense all-pairs NN sweep (pedp_nn) at bench size: python tools/nn_only.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""Timing of the culled ray stage: python tools/ray_only.py [config]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
