@@ -82,3 +82,44 @@ def test_bench_1m_config_rays(ctx, oracle):
     got = mesh.cast_rays(f.rays6)
     _same(got, ref)
     assert np.isfinite(ref["t_hit"]).sum() > 50_000
+
+
+def test_batched_256_pose_refine(ctx, oracle, frame100k):
+    """BASELINE config 3: 256 start poses share one scene and one model (FoundationPose's
+    render-and-compare sizing, estimater.py:104-122).  pedp_icp_batched runs them on concurrent
+    streams; every pose must equal the one-by-one call bit for bit, a sample of them the oracle."""
+    import time
+    from pedp_hip import _lib, synth
+
+    f = frame100k
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(256)])
+    t0 = time.perf_counter()
+    T, fit, rmse = _lib.icp_batched(ctx, src, tgt, 10.0, inits, max_iteration=6)
+    dt = time.perf_counter() - t0
+    print(f"256-pose batch, 6 iterations each: {1e3 * dt:.1f} ms")
+    assert T.shape == (256, 4, 4) and np.all(np.isfinite(T)) and np.all((fit > 0) & (fit <= 1))
+    for b in (0, 1, 77, 128, 255):
+        one = _lib.icp(ctx, src, tgt, 10.0, inits[b], max_iteration=6, relative_fitness=-1, relative_rmse=-1)
+        assert np.array_equal(T[b], one["T"]) and fit[b] == one["fitness"] and rmse[b] == one["inlier_rmse"]
+    for b in (3, 200):
+        ref = oracle.icp(scene, f.model_points, f.normals, 10.0, inits[b], max_iter=6, rel_fitness=-1, rel_rmse=-1)
+        assert fit[b] == ref["fitness"] and np.abs(T[b] - ref["T"]).max() < 1e-5
+
+
+def test_bench_1m_config_icp(ctx, oracle):
+    """The 1M-triangle configuration's clouds through ICP: 921,600 scene points against the
+    500,000 model vertices, two iterations against the KD-tree oracle."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("bench_1m")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    assert len(scene) == 921_600 and len(f.model_points) == 500_000
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    res = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=2, relative_fitness=-1, relative_rmse=-1, want_corr=True)
+    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=2, rel_fitness=-1, rel_rmse=-1)
+    assert np.array_equal(res["corr"], ref["corr"])
+    assert res["fitness"] == ref["fitness"] and np.abs(res["T"] - ref["T"]).max() < 1e-5
