@@ -83,6 +83,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
         if (c->sub[k]) pedp_ctx_destroy(c->sub[k]);
         c->sub[k] = nullptr;
     }
+    if (c->icp_graph) (void)hipGraphExecDestroy(c->icp_graph);
     c->ray_keys.release();
     c->ray_in.release();
     c->ray_out.release();

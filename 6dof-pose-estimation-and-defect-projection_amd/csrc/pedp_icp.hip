@@ -1364,32 +1364,45 @@ int icp_prepare(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, double r
     return ensure_spatial_perm(c, source, roi);
 }
 
-int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
-                const pedp_icp_params *prm, const double init[16], bool want_trace, bool early_stop, IcpJob &job) {
+// workspace of one registration on executor x (may grow the executor's scratch buffer)
+int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm, IcpJob &job) {
     PEDP_HIP_CHECK(hipSetDevice(x->device));
-    const int64_t Ns = source->N, Nt = target->N;
-    const int max_iter = prm->max_iteration;
-    const double r = prm->max_correspondence_distance;
-    const double n_global = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
-    job.max_iter = max_iter;
-    job.Ns = Ns;
-    job.Nt = Nt;
-    job.qt = icp_unit_size(target, r);
+    job.max_iter = prm->max_iteration;
+    job.Ns = source->N;
+    job.Nt = target->N;
+    job.qt = icp_unit_size(target, prm->max_correspondence_distance);
     IcpWorkspace &w = job.w;
-    int rc = carve_workspace(x, Ns, Nt, max_iter, job.qt, w);
+    int rc = carve_workspace(x, job.Ns, job.Nt, job.max_iter, job.qt, w);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
     w.tile_sph = (const float4 *)(job.qt == 4 ? target->tile_sph4 : target->tile_sph);
     w.tgt_perm = (const int32_t *)target->perm;
     w.src_perm = (const int32_t *)source->perm;
+    return PEDP_OK;
+}
 
+// start state of a registration in the executor's pinned block (uploaded by the first node of
+// icp_enqueue; the same block receives the final state)
+void icp_fill_state(pedp_ctx_t x, const TargetPrep &tp, const double init[16]) {
     IcpState h{};
     for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
+    *(IcpState *)x->pinned = h;
+}
+
+// every pass of one registration on x's stream; nothing here allocates or synchronises unless
+// early_stop is set, so the sequence can be captured into a graph
+int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
+                const pedp_icp_params *prm, bool want_trace, bool early_stop, const IcpJob &job) {
+    const int64_t Ns = source->N, Nt = target->N;
+    const int max_iter = prm->max_iteration;
+    const double r = prm->max_correspondence_distance;
+    const double n_global = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
+    const IcpWorkspace &w = job.w;
+    int rc;
     // Open3D: max_correspondence_distance <= 0 or an empty cloud gives an empty result
     const bool degenerate = (r <= 0.0 || Ns == 0 || Nt == 0);
     IcpState *hp = (IcpState *)x->pinned;
-    *hp = h;
     PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, x->stream));
     const double r2 = r * r;
     const double ng = n_global > 0 ? n_global : 1.0;
@@ -1452,6 +1465,44 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
     return PEDP_OK;
 }
 
+// Batched registrations are bound by the host's launch rate (a pass is 8 small kernels), so a
+// sub-context captures the whole pass sequence once into a hipGraph and replays it per start
+// pose: the graph's nodes read the start state from the executor's pinned block and everything
+// else from device memory.  Anything the captured launches depend on is in the key.
+int icp_launch_replayed(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
+                        const pedp_icp_params *prm, const double init[16], IcpJob &job) {
+    int rc = icp_job_setup(x, source, target, prm, job);
+    if (rc) return rc;
+    icp_fill_state(x, tp, init);
+    pedp_icp_graph_key key;
+    key.src = source; key.tgt = target; key.ws = x->icp_ws.ptr;
+    key.Ns = job.Ns; key.Nt = job.Nt; key.max_iter = job.max_iter; key.qt = job.qt; key.estimator = prm->estimator;
+    key.r = prm->max_correspondence_distance;
+    const pedp_icp_graph_key &have = x->icp_graph_key;
+    const bool same = x->icp_graph && have.src == key.src && have.tgt == key.tgt && have.ws == key.ws && have.Ns == key.Ns &&
+                      have.Nt == key.Nt && have.max_iter == key.max_iter && have.qt == key.qt &&
+                      have.estimator == key.estimator && have.r == key.r;
+    if (!same) {
+        if (x->icp_graph) { (void)hipGraphExecDestroy(x->icp_graph); x->icp_graph = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(x->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rc = icp_enqueue(x, source, target, tp, prm, false, false, job);
+            const hipError_t e = hipStreamEndCapture(x->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e == hipSuccess && graph && hipGraphInstantiate(&x->icp_graph, graph, nullptr, nullptr, 0) == hipSuccess)
+                x->icp_graph_key = key;
+            else
+                x->icp_graph = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+        if (!x->icp_graph)  // capture unavailable: plain launches, same work
+            return icp_enqueue(x, source, target, tp, prm, false, false, job);
+    }
+    PEDP_HIP_CHECK(hipGraphLaunch(x->icp_graph, x->stream));
+    return PEDP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1467,7 +1518,10 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     rc = icp_prepare(c, source, target, prm->max_correspondence_distance, init, 1, tp);
     if (rc) return rc;
     IcpJob job;
-    rc = icp_enqueue(c, source, target, tp, prm, init, trace != nullptr, true, job);
+    rc = icp_job_setup(c, source, target, prm, job);
+    if (rc) return rc;
+    icp_fill_state(c, tp, init);
+    rc = icp_enqueue(c, source, target, tp, prm, trace != nullptr, true, job);
     if (rc) return rc;
     return icp_collect(c, job, T_out, fitness, inlier_rmse, n_iter_done, corr, trace);
 }
@@ -1503,7 +1557,7 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
     for (int b0 = 0; b0 < B; b0 += K) {
         const int n = (B - b0 < K) ? B - b0 : K;
         for (int k = 0; k < n; ++k) {
-            rc = icp_enqueue(c->sub[k], source, target, tp, &p, inits + 16 * (b0 + k), false, false, jobs[k]);
+            rc = icp_launch_replayed(c->sub[k], source, target, tp, &p, inits + 16 * (b0 + k), jobs[k]);
             if (rc) return rc;
         }
         for (int k = 0; k < n; ++k) {

@@ -37,6 +37,15 @@ struct pedp_scratch {
 
 #define PEDP_MAX_SUB 8
 
+// What a captured registration graph depends on besides device-memory contents: if any of it
+// changes, the graph is captured again.
+struct pedp_icp_graph_key {
+    const void *src = nullptr, *tgt = nullptr, *ws = nullptr;
+    int64_t Ns = 0, Nt = 0;
+    int max_iter = 0, qt = 0, estimator = 0;
+    double r = 0.0;
+};
+
 struct pedp_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -58,6 +67,8 @@ struct pedp_ctx_s {
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
+    hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
+    pedp_icp_graph_key icp_graph_key;
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
 };

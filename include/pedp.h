@@ -184,7 +184,9 @@ int pedp_icp(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
              double *trace);
 
 /* Batched refine (FoundationPose hypothesis sizing, estimater.py:104-122): B start
- * poses share one source and one target; no early exit across the batch. */
+ * poses share one source and one target; no early exit across the batch.  Up to 8 registrations
+ * are in flight on internal streams (each replaying one captured hipGraph per pose); the call
+ * returns when all are complete.  Results equal B separate pedp_icp calls bit for bit. */
 int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
                      const pedp_icp_params *params, const double *inits /* B x 16 */, int B,
                      double *T_out /* B x 16 */, double *fitness /* B */,
