@@ -11,8 +11,9 @@ from .geometry import (LineSet, PinholeCameraIntrinsic, PointCloud, Registration
                        TriangleMesh)
 from .icp_refine import (determine_pose, improve_result, predict_z_axis_adjustment, preprocess_source,  # noqa: F401
                          preprocess_target, refine_pose_with_icp, refine_registration, transform_object)
-from .ray_projection import (compute_rays, create_intersection_pcd, heatmap_to_points,  # noqa: F401
-                             intersect_rays_with_mesh, load_extrinsics, project_debug_rays, ray_tracing)
+from .ray_projection import (align_to_surface, calc_coordinates, compute_rays, create_intersection_pcd,  # noqa: F401
+                             heatmap_to_point3d, heatmap_to_points, intersect_rays_with_mesh, load_extrinsics,
+                             pcd_from_point3d, project_debug_rays, ray_tracing)
 from .registration import (ICPConvergenceCriteria, TransformationEstimationPointToPlane,  # noqa: F401
                            TransformationEstimationPointToPoint, get_rotation_matrix_from_xyz,
                            registration_icp)
@@ -44,6 +45,7 @@ __all__ = [
     "preprocess_source", "preprocess_target", "transform_object",
     "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
     "project_debug_rays", "load_extrinsics", "ray_tracing",
+    "heatmap_to_point3d", "pcd_from_point3d", "calc_coordinates", "align_to_surface",
     "erode_depth", "bilateral_filter_depth", "depth2xyzmap", "depth2xyzmap_batch",
     "registration_icp", "TransformationEstimationPointToPlane", "TransformationEstimationPointToPoint",
     "ICPConvergenceCriteria", "get_rotation_matrix_from_xyz",

@@ -195,3 +195,68 @@ class FrameProjector:
         if len(out["points"]) == 0:
             return None
         return create_intersection_pcd(out["points"], out["intensities"])
+
+
+# ---------------------------------------------------------------- depth-based projection
+# The reference's alternative to ray casting (defect_projection.py:359-460): back-project the hot
+# pixels through the depth image and snap them onto the model cloud.  The snap is one exact
+# nearest-neighbour pass of the ICP stage (pedp_nn).
+
+def heatmap_to_point3d(heatmap, depth_image, intrinsic, threshold=0.1):
+    """Rows [x, y, z, intensity] of the pixels whose max-normalised heat exceeds `threshold` and
+    whose depth is positive, row-major like the reference's double loop (:359-397):
+    x = (u - cx) * depth / fx, y = (v - cy) * depth / fy, z = 0.98 * depth."""
+    heat = np.asarray(heatmap)
+    depth = np.asarray(depth_image)
+    K = np.asarray(intrinsic.intrinsic_matrix, dtype=np.float64)
+    h = min(heat.shape[0], depth.shape[0])
+    w = min(heat.shape[1], depth.shape[1])
+    inten = heat[:h, :w] / np.max(heat)
+    d = depth[:h, :w]
+    vs, us = np.nonzero((inten > threshold) & (d > 0))
+    dz = d[vs, us]
+    x3d = (us - K[0, 2]) * dz / K[0, 0]
+    y3d = (vs - K[1, 2]) * dz / K[1, 1]
+    if len(vs) == 0:
+        return np.array([])
+    return np.stack([x3d, y3d, dz * 0.98, inten[vs, us]], axis=1)
+
+
+def pcd_from_point3d(points_3D):
+    if len(points_3D) == 0:
+        raise ValueError("No valid 3D points found.")
+    return PointCloud(np.array(points_3D)[:, :3])
+
+
+def calc_coordinates(depth_image, points, intrinsic):
+    """3-D coordinates of the given (x, y) pixels from the depth image; zero depth is skipped
+    (:462-494)."""
+    K = np.asarray(intrinsic.intrinsic_matrix, dtype=np.float64)
+    out = []
+    for x, y in points:
+        depth = depth_image[y, x]
+        if depth == 0:
+            logging.info(f"Depth is zero at coordinates x = {x}, y = {y}. Skipping this point.")
+            continue
+        out.append([(x - K[0, 2]) * depth / K[0, 0], (y - K[1, 2]) * depth / K[1, 1], depth])
+    return np.array(out, dtype=np.float64)
+
+
+def align_to_surface(defect_points, target_pcd, offset=0.1, ctx=None):
+    """Snap every defect point [x, y, z, ...] to its nearest model point and lift it by `offset`
+    along that point's normal (:413-460).  Returns (offset_points, aligned_points).  The
+    reference estimates normals when the model has none; that belongs to the preprocessing row
+    that is not built, so a model without normals is an error here."""
+    from .geometry import normals_of, points_of
+
+    pts = np.asarray(defect_points, dtype=np.float64).reshape(len(defect_points), -1)
+    if len(pts) == 0:
+        return np.array([]), np.array([])
+    model, normals = points_of(target_pcd), normals_of(target_pcd)
+    if normals is None:
+        raise RuntimeError("align_to_surface: the target cloud carries no normals; normal estimation "
+                           "(defect_projection.py:428-433) is not part of this build")
+    ctx = ctx or _lib.default_context()
+    idx, _ = _lib.nn(ctx, _lib.Cloud(ctx, pts[:, :3]), _lib.Cloud(ctx, model))
+    aligned = model[idx]
+    return aligned + normals[idx] * offset, aligned

@@ -291,3 +291,38 @@ def test_load_extrinsics_and_shard_bounds(tmp_path):
             b = [shard_bounds(n, r, w) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_depth_based_projection_host_functions():
+    """heatmap_to_point3d / calc_coordinates against the reference's literal loops
+    (defect_projection.py:359-397, :462-494) on a small uint16 depth image."""
+    from pedp_hip.compat import PinholeCameraIntrinsic, calc_coordinates, heatmap_to_point3d, pcd_from_point3d
+
+    rng = np.random.default_rng(4)
+    heat = rng.uniform(0, 2.0, (9, 12))
+    depth = rng.integers(0, 900, (8, 14)).astype(np.uint16)     # other size than the heat map, zeros inside
+    depth[2, 3] = 0
+    intr = PinholeCameraIntrinsic(12, 9, 50.0, 51.0, 5.5, 4.0)
+    K = intr.intrinsic_matrix
+    expect = []
+    mx = np.max(heat)
+    for y in range(9):
+        for x in range(12):
+            if y >= 8 or x >= 14:
+                continue
+            inten = heat[y, x] / mx
+            if inten > 0.3:
+                d = depth[y, x]
+                if d > 0:
+                    expect.append([(x - K[0, 2]) * d / K[0, 0], (y - K[1, 2]) * d / K[1, 1], d * 0.98, inten])
+    got = heatmap_to_point3d(heat, depth, intr, 0.3)
+    assert got.shape == (len(expect), 4) and np.array_equal(got, np.array(expect))
+    assert heatmap_to_point3d(heat, depth, intr, 5.0).size == 0
+    assert len(pcd_from_point3d(got).points) == len(expect)
+    with pytest.raises(ValueError):
+        pcd_from_point3d([])
+    pix = [(3, 2), (1, 1), (11, 7)]
+    c = calc_coordinates(depth, pix, intr)
+    ref = [[(x - K[0, 2]) * depth[y, x] / K[0, 0], (y - K[1, 2]) * depth[y, x] / K[1, 1], depth[y, x]]
+           for x, y in pix if depth[y, x] != 0]
+    assert np.array_equal(c, np.array(ref, dtype=np.float64)) and len(c) == 2

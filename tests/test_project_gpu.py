@@ -135,3 +135,23 @@ def test_frame_projector_and_ray_tracing(ctx, oracle, tmp_path):
     ref2 = oracle.project_heatmap(oracle.pose_vertices(np.linalg.inv(c2d) @ f.T_gt, f.model_points), f.tris, hm, f.K, 0.6)
     _check(det, ref2)
     assert np.array_equal(np.asarray(cloud2.colors), np.asarray(compat.create_intersection_pcd(ref2["points"], ref2["intensities"]).colors))
+
+
+def test_align_to_surface_matches_oracle_nn(ctx, oracle):
+    """align_to_surface (defect_projection.py:413-460): nearest model point by the exact NN pass,
+    offset along its normal; indices equal the oracle's KD-tree search."""
+    from pedp_hip import compat, synth
+
+    f = synth.Frame("parity")
+    rng = np.random.default_rng(2)
+    pick = rng.integers(0, len(f.model_points), 700)
+    defects = np.hstack([f.model_points[pick] + rng.normal(0, 1.5, (700, 3)), rng.uniform(0, 1, (700, 1))])
+    model = compat.PointCloud(f.model_points, normals=f.normals)
+    off, aligned = compat.align_to_surface(defects, model, offset=0.25)
+    idx, _ = oracle.nn(defects[:, :3], f.model_points, kdtree=True)
+    assert np.array_equal(aligned, f.model_points[idx])
+    assert np.array_equal(off, f.model_points[idx] + f.normals[idx] * 0.25)
+    e_off, e_al = compat.align_to_surface(np.zeros((0, 4)), model)
+    assert e_off.size == 0 and e_al.size == 0
+    with pytest.raises(RuntimeError, match="normals"):
+        compat.align_to_surface(defects, compat.PointCloud(f.model_points))
