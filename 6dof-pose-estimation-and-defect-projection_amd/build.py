@@ -24,6 +24,7 @@ SOURCES = {
     "pedp_icp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "pedp_project.hip": [],
     "pedp_depth.hip": [],
+    "pedp_cloudops.hip": [],
     "pedp_cluster.cpp": [],
 }
 HEADERS = ["pedp_internal.h", os.path.join("..", "..", "include", "pedp.h")]

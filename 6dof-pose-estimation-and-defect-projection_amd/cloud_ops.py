@@ -1,0 +1,84 @@
+"""Point-cloud operations behind the PointCloud holder's Open3D-style methods:
+voxel_down_sample, segment_plane, cluster_dbscan, remove_statistical_outlier as used by
+preprocess_source (src/pose_estimation.py:186-268).  The per-point / per-iteration work runs in
+libpedp_hip.so; what is left on the host is O(N) bookkeeping in the oracle's order."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_SEED = 0
+
+
+def set_ransac_seed(seed):
+    """Seed of segment_plane's sampler (Open3D: o3d.utility.random.seed).  The global numpy RNG is
+    never touched, so improve_result's random stream stays the reference's."""
+    global _SEED
+    _SEED = int(seed)
+
+
+def _pts(points):
+    return np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+
+
+def voxel_down_sample(points, voxel_size, normals=None, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _pts(points)
+    n = None if normals is None or len(normals) == 0 else _pts(normals)
+    out, outn = np.empty_like(p), (np.empty_like(p) if n is not None else None)
+    m = C.c_int64()
+    _lib.check(_lib.load().pedp_voxel_down_sample(ctx._h, _lib._ptr(p), _lib._ptr(n), len(p), float(voxel_size), _lib._ptr(out),
+                                                  _lib._ptr(outn), len(p), C.byref(m)), "pedp_voxel_down_sample")
+    return out[:m.value].copy(), (None if outn is None else outn[:m.value].copy())
+
+
+def cluster_dbscan(points, eps, min_points, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _pts(points)
+    labels = np.empty(len(p), np.int32)
+    _lib.check(_lib.load().pedp_cluster_dbscan(ctx._h, _lib._ptr(p), len(p), float(eps), int(min_points), _lib._ptr(labels)),
+               "pedp_cluster_dbscan")
+    return labels
+
+
+def knn_mean_distance(points, k, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _pts(points)
+    avg = np.empty(len(p), np.float64)
+    _lib.check(_lib.load().pedp_knn_mean_distance(ctx._h, _lib._ptr(p), len(p), int(k), _lib._ptr(avg)), "pedp_knn_mean_distance")
+    return avg
+
+
+def statistical_outlier_indices(avg, std_ratio):
+    """Open3D's global step on the per-point mean distances: mean over the valid ones, Bessel-
+    corrected deviation, keep 0 < avg < mean + ratio * std; sums in index order (cumsum)."""
+    avg = np.asarray(avg, dtype=np.float64)
+    valid = int(np.count_nonzero(avg >= 0))
+    if valid == 0:
+        return np.zeros(0, np.int64)
+    pos = avg > 0
+    mean = (np.cumsum(np.where(pos, avg, 0.0))[-1] if len(avg) else 0.0) / valid
+    dev = np.where(pos, (avg - mean) * (avg - mean), 0.0)
+    sq = np.cumsum(dev)[-1] if len(avg) else 0.0
+    std = np.sqrt(sq / (valid - 1)) if valid > 1 else float("nan")
+    return np.nonzero(pos & (avg < mean + std_ratio * std))[0]
+
+
+def remove_statistical_outlier(points, nb_neighbors, std_ratio, ctx=None):
+    """Indices kept by PointCloud.remove_statistical_outlier."""
+    return statistical_outlier_indices(knn_mean_distance(points, nb_neighbors, ctx), std_ratio)
+
+
+def segment_plane(points, distance_threshold, ransac_n=3, num_iterations=100, seed=None, ctx=None):
+    if ransac_n != 3:
+        raise NotImplementedError("segment_plane: ransac_n = 3 is the only form the reference uses")
+    ctx = ctx or _lib.default_context()
+    p = _pts(points)
+    plane = np.zeros(4)
+    inl = np.empty(len(p), np.int32)
+    n = C.c_int64()
+    _lib.check(_lib.load().pedp_segment_plane(ctx._h, _lib._ptr(p), len(p), float(distance_threshold), int(num_iterations),
+                                              C.c_uint64(_SEED if seed is None else int(seed)), _lib._ptr(plane), _lib._ptr(inl),
+                                              C.byref(n)), "pedp_segment_plane")
+    return plane, inl[:n.value].copy()

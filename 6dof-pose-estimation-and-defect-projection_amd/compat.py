@@ -9,8 +9,11 @@ import numpy as np
 from . import _lib
 from .geometry import (LineSet, PinholeCameraIntrinsic, PointCloud, RegistrationResult,  # noqa: F401
                        TriangleMesh)
-from .icp_refine import (determine_pose, improve_result, predict_z_axis_adjustment, preprocess_source,  # noqa: F401
-                         preprocess_target, refine_pose_with_icp, refine_registration, transform_object)
+from .icp_refine import (background_removal, determine_pose, filter_largest_cluster,  # noqa: F401
+                         flip_plane_normal_if_needed, improve_result, perform_plane_segmentation,
+                         predict_z_axis_adjustment, preprocess_source, preprocess_target, refine_pose_with_icp,
+                         refine_registration, remove_plane, remove_points_below_plane, remove_statistical_outliers,
+                         transform_object)
 from .ray_projection import (align_to_surface, calc_coordinates, compute_rays, create_intersection_pcd,  # noqa: F401
                              heatmap_to_point3d, heatmap_to_points, intersect_rays_with_mesh, load_extrinsics,
                              pcd_from_point3d, project_debug_rays, ray_tracing)
@@ -43,6 +46,8 @@ mycpp = _MyCpp()
 __all__ = [
     "refine_registration", "improve_result", "predict_z_axis_adjustment", "refine_pose_with_icp", "determine_pose",
     "preprocess_source", "preprocess_target", "transform_object",
+    "perform_plane_segmentation", "flip_plane_normal_if_needed", "remove_plane", "remove_points_below_plane",
+    "background_removal", "filter_largest_cluster", "remove_statistical_outliers",
     "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
     "project_debug_rays", "load_extrinsics", "ray_tracing",
     "heatmap_to_point3d", "pcd_from_point3d", "calc_coordinates", "align_to_surface",

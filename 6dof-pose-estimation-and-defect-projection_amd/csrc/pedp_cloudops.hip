@@ -1,0 +1,534 @@
+// Point-cloud operations of preprocess_source for gfx950: the Open3D calls the
+// reference chains in src/pose_estimation.py:186-268, restated from the published open3d==0.18.0
+// algorithms (oracle/cloudops.c is the CPU statement the tests compare with).
+//
+//   pedp_voxel_down_sample      pcd.voxel_down_sample(voxel_size)                   :204-205
+//   pedp_cluster_dbscan         pcd.cluster_dbscan(eps, min_points)                 :284
+//   pedp_knn_mean_distance      per-point part of pcd.remove_statistical_outlier    :308-312
+//   pedp_segment_plane          pcd.segment_plane(threshold, 3, num_iterations)     :323-329
+//
+// Everything with an order-dependent result is made order-free or given the oracle's order:
+//   * voxel averages: points are sorted by voxel key with a STABLE radix sort (rocPRIM), so a
+//     voxel's members are summed in point order like Open3D's sequential accumulation;
+//   * DBSCAN: clusters are the connected components of the core points (lock-free union-find,
+//     smaller index wins, so the representative is the component's smallest core index whatever the
+//     execution order); cluster ids rank the representatives -- Open3D's discovery order -- and a
+//     border point takes the smallest id among its core neighbours -- the first cluster that
+//     reaches it in Open3D's breadth-first sweep;
+//   * k nearest neighbours: each thread keeps its k smallest squared distances sorted, so the mean
+//     is summed in ascending order;
+//   * plane RANSAC: one workgroup per iteration counts the inliers of its sampled plane; choosing
+//     the best iteration, the final inliers and the refit are O(N) and done by the host in the
+//     oracle's order.
+// Neighbourhood queries (DBSCAN) walk a uniform grid with cell >= eps built by a sort on the cell id.
+#include "pedp_internal.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <class T> T *take(size_t n) {
+        T *p = (T *)(base + off);
+        off = a256(off + sizeof(T) * n);
+        return p;
+    }
+};
+
+__device__ __forceinline__ double dist2(const double *a, const double *b) {
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;  // -ffp-contract=off: no FMA, the oracle's rounding
+}
+
+// ------------------------------------------------------------------ voxel grid
+__global__ void voxel_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz, double voxel,
+                                 unsigned long long *__restrict__ key, int *__restrict__ val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned long long cx = (unsigned long long)(long long)floor((pts[3 * i] - lox) / voxel);
+    const unsigned long long cy = (unsigned long long)(long long)floor((pts[3 * i + 1] - loy) / voxel);
+    const unsigned long long cz = (unsigned long long)(long long)floor((pts[3 * i + 2] - loz) / voxel);
+    key[i] = ((cx & 0x1FFFFFull) << 42) | ((cy & 0x1FFFFFull) << 21) | (cz & 0x1FFFFFull);
+    val[i] = (int)i;
+}
+
+__global__ void voxel_average_kernel(const double *__restrict__ pts, const double *__restrict__ nrm,
+                                     const int *__restrict__ sorted_idx, const unsigned *__restrict__ counts,
+                                     const unsigned *__restrict__ offsets, const unsigned *__restrict__ n_runs,
+                                     double *__restrict__ out_pts, double *__restrict__ out_nrm) {
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= *n_runs) return;
+    const unsigned a = offsets[v], n = counts[v];
+    double s0 = 0, s1 = 0, s2 = 0, n0 = 0, n1 = 0, n2 = 0;
+    for (unsigned j = 0; j < n; ++j) {  // members in point order (stable sort)
+        const int64_t i = sorted_idx[a + j];
+        s0 += pts[3 * i]; s1 += pts[3 * i + 1]; s2 += pts[3 * i + 2];
+        if (nrm) { n0 += nrm[3 * i]; n1 += nrm[3 * i + 1]; n2 += nrm[3 * i + 2]; }
+    }
+    const double c = (double)n;
+    out_pts[3 * (size_t)v] = s0 / c; out_pts[3 * (size_t)v + 1] = s1 / c; out_pts[3 * (size_t)v + 2] = s2 / c;
+    if (nrm) { out_nrm[3 * (size_t)v] = n0 / c; out_nrm[3 * (size_t)v + 1] = n1 / c; out_nrm[3 * (size_t)v + 2] = n2 / c; }
+}
+
+// ------------------------------------------------------------------ uniform grid
+struct Grid {
+    double lo[3], cell;
+    int dim[3];
+};
+
+__device__ __forceinline__ int grid_axis(double p, double lo, double cell, int dim) {
+    int c = (int)floor((p - lo) / cell);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ void grid_cell_kernel(const double *__restrict__ pts, int64_t N, Grid g, unsigned *__restrict__ cell,
+                                 int *__restrict__ val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int cx = grid_axis(pts[3 * i], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(pts[3 * i + 1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(pts[3 * i + 2], g.lo[2], g.cell, g.dim[2]);
+    cell[i] = (unsigned)(cx + g.dim[0] * (cy + g.dim[1] * cz));
+    val[i] = (int)i;
+}
+
+// sorted by cell: where each cell's run starts and ends, and the points gathered in that order
+__global__ void grid_ranges_kernel(const unsigned *__restrict__ cell_sorted, const int *__restrict__ idx_sorted,
+                                   const double *__restrict__ pts, int64_t N, int *__restrict__ cell_start,
+                                   int *__restrict__ cell_end, double *__restrict__ sp) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const unsigned c = cell_sorted[j];
+    if (j == 0 || cell_sorted[j - 1] != c) cell_start[c] = (int)j;
+    if (j == N - 1 || cell_sorted[j + 1] != c) cell_end[c] = (int)j + 1;
+    const int64_t i = idx_sorted[j];
+    sp[3 * j] = pts[3 * i]; sp[3 * j + 1] = pts[3 * i + 1]; sp[3 * j + 2] = pts[3 * i + 2];
+}
+
+// calls f(q) for every sorted position q whose point lies in one of the 27 cells around p
+template <class F>
+__device__ __forceinline__ void for_neighbours(const Grid &g, const double *p, const int *__restrict__ cell_start,
+                                               const int *__restrict__ cell_end, F f) {
+    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dim[2] - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1); ++y)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1); ++x) {
+                const int c = x + g.dim[0] * (y + g.dim[1] * z);
+                for (int q = cell_start[c]; q < cell_end[c]; ++q) f(q);
+            }
+}
+
+// ------------------------------------------------------------------ DBSCAN
+__global__ void dbscan_core_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
+                                   const int *__restrict__ cell_end, double e2, int min_points,
+                                   const int *__restrict__ idx_sorted, int *__restrict__ core /* by original index */,
+                                   int *__restrict__ parent) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    int cnt = 0;
+    for_neighbours(g, p, cell_start, cell_end, [&](int q) { cnt += dist2(p, sp + 3 * (size_t)q) < e2; });
+    const int i = idx_sorted[j];
+    core[i] = cnt >= min_points;
+    parent[i] = i;
+}
+
+__device__ __forceinline__ int uf_find(int *parent, int a) {
+    int r = a;
+    while (true) {
+        const int p = ((volatile int *)parent)[r];
+        if (p == r) return r;
+        r = p;
+    }
+}
+
+__global__ void dbscan_union_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
+                                    const int *__restrict__ cell_end, double e2, const int *__restrict__ idx_sorted,
+                                    const int *__restrict__ core, int *__restrict__ parent) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int i = idx_sorted[j];
+    if (!core[i]) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    for_neighbours(g, p, cell_start, cell_end, [&](int q) {
+        const int iq = idx_sorted[q];
+        if (iq >= i || !core[iq] || !(dist2(p, sp + 3 * (size_t)q) < e2)) return;
+        int a = i, b = iq;  // union: the larger root is hooked under the smaller one
+        while (true) {
+            a = uf_find(parent, a);
+            b = uf_find(parent, b);
+            if (a == b) break;
+            if (a < b) { const int t = a; a = b; b = t; }
+            if (atomicCAS(&parent[a], a, b) == a) break;
+        }
+    });
+}
+
+// roots of core components in index order -> flags for the rank scan
+__global__ void dbscan_root_kernel(int64_t N, const int *__restrict__ core, int *__restrict__ parent, int *__restrict__ root,
+                                   unsigned *__restrict__ is_rep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int r = -1;
+    if (core[i]) r = uf_find(parent, (int)i);
+    root[i] = r;
+    is_rep[i] = (r == (int)i) ? 1u : 0u;
+}
+
+__global__ void dbscan_label_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
+                                    const int *__restrict__ cell_end, double e2, const int *__restrict__ idx_sorted,
+                                    const int *__restrict__ root, const unsigned *__restrict__ rank /* exclusive scan of is_rep */,
+                                    int32_t *__restrict__ labels) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int i = idx_sorted[j];
+    if (root[i] >= 0) { labels[i] = (int32_t)rank[root[i]]; return; }
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    int best = 0x7FFFFFFF;
+    for_neighbours(g, p, cell_start, cell_end, [&](int q) {
+        const int rq = root[idx_sorted[q]];
+        if (rq >= 0 && dist2(p, sp + 3 * (size_t)q) < e2) best = min(best, (int)rank[rq]);
+    });
+    labels[i] = best == 0x7FFFFFFF ? -1 : best;
+}
+
+// ------------------------------------------------------------------ k nearest neighbours (mean distance)
+// One thread per query, all threads of a wave walk the same candidate (scalar loads, broadcast);
+// each thread keeps its k smallest squared distances sorted ascending in LDS.
+constexpr int KNN_THREADS = 64;
+__global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(const double *__restrict__ pts, int64_t N, int k,
+                                                               double *__restrict__ avg) {
+    extern __shared__ double top[];  // [k][KNN_THREADS]: element r of thread t at top[r * KNN_THREADS + t]
+    const int t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * KNN_THREADS + t;
+    const bool live = i < N;
+    const int64_t ii = live ? i : 0;
+    const double p[3] = {pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2]};
+    const int m = (int)(N < k ? N : k);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    for (int r = 0; r < m; ++r) top[r * KNN_THREADS + t] = inf;
+    double worst = inf;
+    for (int64_t q = 0; q < N; ++q) {
+        const double d = dist2(p, pts + 3 * q);
+        if (d < worst) {  // insert, keeping ascending order
+            int r = m - 1;
+            while (r > 0 && top[(r - 1) * KNN_THREADS + t] > d) {
+                top[r * KNN_THREADS + t] = top[(r - 1) * KNN_THREADS + t];
+                --r;
+            }
+            top[r * KNN_THREADS + t] = d;
+            worst = top[(m - 1) * KNN_THREADS + t];
+        }
+    }
+    if (!live) return;
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) s += sqrt(top[r * KNN_THREADS + t]);
+    avg[i] = m > 0 ? s / (double)m : -1.0;
+}
+
+// ------------------------------------------------------------------ plane RANSAC
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline void sample3(unsigned long long seed, long long t, long long N, long long out[3]) {
+    unsigned long long s = splitmix64(seed ^ splitmix64((unsigned long long)t));
+    int n = 0;
+    while (n < 3) {
+        s = splitmix64(s);
+        const long long c = (long long)(s % (unsigned long long)N);
+        bool dup = false;
+        for (int q = 0; q < n; ++q) dup |= (out[q] == c);
+        if (!dup) out[n++] = c;
+    }
+}
+__host__ __device__ inline bool triangle_plane(const double *p0, const double *p1, const double *p2, double pl[4]) {
+    const double a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    const double n = sqrt((x * x + y * y) + z * z);
+    if (!(n > 0.0)) return false;
+    pl[0] = x / n; pl[1] = y / n; pl[2] = z / n;
+    pl[3] = -((pl[0] * p0[0] + pl[1] * p0[1]) + pl[2] * p0[2]);
+    return true;
+}
+__host__ __device__ inline double plane_dist(const double pl[4], const double *p) {
+    return fabs(((pl[0] * p[0] + pl[1] * p[1]) + pl[2] * p[2]) + pl[3]);
+}
+
+__global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ pts, long long N, double threshold,
+                                                           unsigned long long seed, int *__restrict__ counts) {
+    __shared__ int red[4];
+    __shared__ double pl_s[4];
+    __shared__ int ok_s;
+    const int t = blockIdx.x;
+    if (threadIdx.x == 0) {
+        long long s[3];
+        double pl[4];
+        sample3(seed, t, N, s);
+        ok_s = triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], pl);
+        for (int k = 0; k < 4; ++k) pl_s[k] = ok_s ? pl[k] : 0.0;
+    }
+    __syncthreads();
+    if (!ok_s) { if (threadIdx.x == 0) counts[t] = -1; return; }
+    const double pl[4] = {pl_s[0], pl_s[1], pl_s[2], pl_s[3]};
+    int cnt = 0;
+    for (long long i = threadIdx.x; i < N; i += 256) cnt += plane_dist(pl, pts + 3 * i) < threshold;
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[t] = red[0] + red[1] + red[2] + red[3];
+}
+
+// host: GetPlaneFromPoints, oracle/cloudops.c pedp_oracle_plane_from_points
+void plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (n < 3) return;
+    double c[3] = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) c[k] += pts[3 * (int64_t)idx[i] + k];
+    for (int k = 0; k < 3; ++k) c[k] /= (double)n;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = pts + 3 * (int64_t)idx[i];
+        const double rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+    double a, b, cc;
+    if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }
+    else if (det_y >= det_z) { a = xz * yz - xy * zz; b = det_y; cc = xy * xz - yz * xx; }
+    else { a = xy * yz - xz * yy; b = xy * xz - yz * xx; cc = det_z; }
+    const double nrm = std::sqrt((a * a + b * b) + cc * cc);
+    if (!(nrm > 0.0)) return;
+    pl[0] = a / nrm; pl[1] = b / nrm; pl[2] = cc / nrm;
+    pl[3] = -((pl[0] * c[0] + pl[1] * c[1]) + pl[2] * c[2]);
+}
+
+int check_cloud(pedp_ctx_t c, const double *pts, int64_t N, const char *who) {
+    PEDP_REQUIRE(c, "%s: null context", who);
+    PEDP_REQUIRE(N >= 0 && N < (int64_t)1 << 31, "%s: N out of range", who);
+    PEDP_REQUIRE(pts || N == 0, "%s: null points", who);
+    return PEDP_OK;
+}
+
+void bounds(const double *pts, int64_t N, double lo[3], double hi[3]) {
+    for (int k = 0; k < 3; ++k) lo[k] = hi[k] = pts[k];
+    for (int64_t i = 1; i < N; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double v = pts[3 * i + k];
+            if (v < lo[k]) lo[k] = v;
+            if (v > hi[k]) hi[k] = v;
+        }
+}
+
+#define PEDP_ROCPRIM(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pedp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return PEDP_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
+                           double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out) {
+    int rc = check_cloud(c, pts, N, "pedp_voxel_down_sample");
+    if (rc) return rc;
+    PEDP_REQUIRE(n_out, "pedp_voxel_down_sample: null count");
+    *n_out = 0;
+    PEDP_REQUIRE(voxel_size > 0.0, "pedp_voxel_down_sample: voxel_size <= 0");  // Open3D raises too
+    if (N == 0) return PEDP_OK;
+    double lo[3], hi[3];
+    bounds(pts, N, lo, hi);
+    for (int k = 0; k < 3; ++k) {
+        PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
+        lo[k] = lo[k] - voxel_size * 0.5;
+        PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
+    }
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                           (int *)nullptr, (int *)nullptr, n, 0, 63, c->stream));
+    PEDP_ROCPRIM(rocprim::run_length_encode(nullptr, tmp_rle, (unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
+                                            (unsigned *)nullptr, (unsigned *)nullptr, c->stream));
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
+                                         rocprim::plus<unsigned>(), c->stream));
+    size_t tmp = tmp_sort > tmp_rle ? tmp_sort : tmp_rle;
+    if (tmp_scan > tmp) tmp = tmp_scan;
+    const size_t need = a256(sizeof(double) * 3 * N) * 4 + a256(sizeof(unsigned long long) * N) * 3 + a256(sizeof(int) * N) * 2 +
+                        a256(sizeof(unsigned) * N) * 2 + 256 + a256(tmp) + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N), *d_nrm = cv.take<double>(3 * (size_t)N);
+    double *d_out = cv.take<double>(3 * (size_t)N), *d_outn = cv.take<double>(3 * (size_t)N);
+    unsigned long long *key = cv.take<unsigned long long>(N), *key_s = cv.take<unsigned long long>(N),
+                       *uniq = cv.take<unsigned long long>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
+    unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
+    void *d_tmp = cv.take<char>(tmp);
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    if (normals) PEDP_HIP_CHECK(hipMemcpyAsync(d_nrm, normals, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
+    PEDP_ROCPRIM(rocprim::run_length_encode(d_tmp, tmp_rle, key_s, n, uniq, counts, n_runs, c->stream));
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, counts, offsets, 0u, n, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(voxel_average_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, normals ? d_nrm : nullptr, val_s, counts,
+                       offsets, n_runs, d_out, d_outn);
+    PEDP_HIP_CHECK(hipGetLastError());
+    unsigned *h_runs = (unsigned *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_runs, n_runs, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t m = *h_runs;
+    *n_out = m;
+    PEDP_REQUIRE(m <= capacity, "pedp_voxel_down_sample: %lld voxels exceed the output capacity %lld", (long long)m,
+                 (long long)capacity);
+    PEDP_REQUIRE(out_pts && (out_normals || !normals), "pedp_voxel_down_sample: null output arrays");
+    PEDP_HIP_CHECK(hipMemcpyAsync(out_pts, d_out, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (normals) PEDP_HIP_CHECK(hipMemcpyAsync(out_normals, d_outn, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, int min_points, int32_t *labels) {
+    int rc = check_cloud(c, pts, N, "pedp_cluster_dbscan");
+    if (rc) return rc;
+    PEDP_REQUIRE(eps > 0.0 && std::isfinite(eps), "pedp_cluster_dbscan: eps must be positive and finite");
+    if (N == 0) return PEDP_OK;
+    PEDP_REQUIRE(labels, "pedp_cluster_dbscan: null labels");
+    double lo[3], hi[3];
+    bounds(pts, N, lo, hi);
+    Grid g;
+    g.cell = eps * (1.0 + 1e-9);  // >= eps with margin: neighbours within eps are never two cells apart
+    while (true) {
+        double cells = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_cluster_dbscan: non-finite coordinates");
+            g.lo[k] = lo[k];
+            const double d = std::floor((hi[k] - lo[k]) / g.cell) + 1.0;
+            g.dim[k] = d < 1.0 ? 1 : (d > 1e9 ? 1000000000 : (int)d);
+            cells *= (double)g.dim[k];
+        }
+        if (cells <= 16777216.0) break;
+        g.cell *= 2.0;  // a coarser grid is still a valid (slower) neighbourhood index
+    }
+    const int64_t n_cells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0, tmp_scan = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                           (int *)nullptr, n, 0, 32, c->stream));
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
+                                         rocprim::plus<unsigned>(), c->stream));
+    const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    const size_t need = a256(sizeof(double) * 3 * N) * 2 + a256(sizeof(unsigned) * N) * 4 + a256(sizeof(int) * N) * 6 +
+                        a256(sizeof(int) * n_cells) * 2 + a256(tmp) + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N);
+    unsigned *cell = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N), *is_rep = cv.take<unsigned>(N), *rank = cv.take<unsigned>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N), *core = cv.take<int>(N), *parent = cv.take<int>(N), *root = cv.take<int>(N);
+    int32_t *d_labels = cv.take<int32_t>(N);
+    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
+    void *d_tmp = cv.take<char>(tmp);
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    const double e2 = eps * eps;
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell, cell_s, val, val_s, n, 0, 32, c->stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
+    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, min_points,
+                       val_s, core, parent);
+    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, core,
+                       parent);
+    hipLaunchKernelGGL(dbscan_root_kernel, dim3(grid), dim3(256), 0, c->stream, N, core, parent, root, is_rep);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, is_rep, rank, 0u, n, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, root,
+                       rank, d_labels);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(labels, d_labels, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, double *avg) {
+    int rc = check_cloud(c, pts, N, "pedp_knn_mean_distance");
+    if (rc) return rc;
+    PEDP_REQUIRE(k >= 1 && k <= 300, "pedp_knn_mean_distance: k must be in 1..300");  // k x 64 doubles of LDS per workgroup
+    if (N == 0) return PEDP_OK;
+    PEDP_REQUIRE(avg, "pedp_knn_mean_distance: null output");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    int st = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(double) * N) + 512);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N), *d_avg = cv.take<double>(N);
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
+    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream,
+                       d_pts, N, k, d_avg);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_segment_plane(pedp_ctx_t c, const double *pts, int64_t N, double distance_threshold, int num_iterations,
+                       uint64_t seed, double plane[4], int32_t *inliers, int64_t *n_inliers) {
+    int rc = check_cloud(c, pts, N, "pedp_segment_plane");
+    if (rc) return rc;
+    PEDP_REQUIRE(plane && n_inliers, "pedp_segment_plane: null outputs");
+    PEDP_REQUIRE(num_iterations >= 0 && num_iterations <= 10000000, "pedp_segment_plane: num_iterations out of range");
+    plane[0] = plane[1] = plane[2] = plane[3] = 0.0;
+    *n_inliers = 0;
+    if (N < 3 || num_iterations == 0) return PEDP_OK;
+    PEDP_REQUIRE(inliers, "pedp_segment_plane: null inlier array");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    int st = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(int) * (size_t)num_iterations) + 512);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N);
+    int *d_cnt = cv.take<int>(num_iterations);
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)num_iterations), dim3(256), 0, c->stream, d_pts, (long long)N,
+                       distance_threshold, (unsigned long long)seed, d_cnt);
+    PEDP_HIP_CHECK(hipGetLastError());
+    std::vector<int> counts((size_t)num_iterations);
+    PEDP_HIP_CHECK(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int) * (size_t)num_iterations, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int best_t = -1, best_cnt = -1;
+    for (int t = 0; t < num_iterations; ++t)
+        if (counts[t] > best_cnt) { best_cnt = counts[t]; best_t = t; }  // most inliers, earliest iteration on ties
+    if (best_t < 0) return PEDP_OK;
+    long long s[3];
+    double best[4];
+    sample3(seed, best_t, N, s);
+    triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], best);
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; ++i)
+        if (plane_dist(best, pts + 3 * i) < distance_threshold) inliers[n++] = (int32_t)i;
+    plane_from_points(pts, inliers, n, plane);
+    *n_inliers = n;
+    return PEDP_OK;
+}
+
+}  // extern "C"

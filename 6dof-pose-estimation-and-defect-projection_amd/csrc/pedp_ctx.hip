@@ -90,6 +90,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_aux.release();
     c->icp_ws.release();
     c->proj.release();
+    c->ops.release();
     c->proj_out.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

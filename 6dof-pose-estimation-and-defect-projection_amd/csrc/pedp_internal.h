@@ -64,6 +64,7 @@ struct pedp_ctx_s {
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;
     // ICP
     pedp_scratch icp_ws;
+    pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations

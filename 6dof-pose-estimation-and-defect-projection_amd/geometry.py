@@ -55,6 +55,41 @@ class PointCloud:
     def __deepcopy__(self, memo):
         return PointCloud(np.array(self.points), np.array(self.normals), np.array(self.colors))
 
+    # ---- the Open3D methods preprocess_source calls (src/pose_estimation.py:186-268); GPU work in
+    # pedp_hip.cloud_ops.  Colours are not carried through voxel_down_sample (nothing downstream
+    # reads them).
+    def select_by_index(self, indices, invert=False):
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        if invert:
+            mask = np.ones(len(self.points), bool)
+            mask[idx] = False
+            idx = np.nonzero(mask)[0]
+        return PointCloud(np.asarray(self.points)[idx], self.normals[idx] if self.has_normals() else None,
+                          self.colors[idx] if self.has_colors() else None)
+
+    def voxel_down_sample(self, voxel_size):
+        from . import cloud_ops
+
+        pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)
+        return PointCloud(pts, nrm)
+
+    def segment_plane(self, distance_threshold, ransac_n, num_iterations, probability=0.99999999):
+        from . import cloud_ops
+
+        plane, inliers = cloud_ops.segment_plane(self.points, distance_threshold, ransac_n, num_iterations)
+        return plane, [int(i) for i in inliers]
+
+    def cluster_dbscan(self, eps, min_points, print_progress=False):
+        from . import cloud_ops
+
+        return cloud_ops.cluster_dbscan(self.points, eps, min_points)
+
+    def remove_statistical_outlier(self, nb_neighbors, std_ratio, print_progress=False):
+        from . import cloud_ops
+
+        keep = cloud_ops.remove_statistical_outlier(self.points, nb_neighbors, std_ratio)
+        return self.select_by_index(keep), [int(i) for i in keep]
+
 
 class TriangleMesh:
     def __init__(self, vertices=None, triangles=None):

@@ -57,14 +57,103 @@ def preprocess_target(pcd, param):
     return out, None
 
 
+def perform_plane_segmentation(pcd, param):
+    """pose_estimation.py:323-329."""
+    return pcd.segment_plane(distance_threshold=param["distance_threshold"], ransac_n=3,
+                             num_iterations=param["num_iterations"])
+
+
+def flip_plane_normal_if_needed(plane_model, average_normal):
+    """pose_estimation.py:342-359: orient the plane like the cloud's average normal."""
+    a, b, c, d = plane_model
+    plane_normal = np.array([a, b, c], dtype=np.float64)
+    plane_normal /= np.linalg.norm(plane_normal)
+    if np.dot(plane_normal, average_normal) < 0:
+        plane_normal = -plane_normal
+        plane_model = [-a, -b, -c, -d]
+        logging.info(":: Plane normal was flipped to match the majority of normals.")
+    return plane_model, plane_normal
+
+
+def remove_plane(pcd, inliers):
+    return pcd.select_by_index(inliers, invert=True)
+
+
+def remove_points_below_plane(pcd, plane_model):
+    """Keep the points with signed distance <= 0 (pose_estimation.py:366-378); like the reference the
+    result carries points only."""
+    a, b, c, d = plane_model
+    points = points_of(pcd)
+    distances = (a * points[:, 0] + b * points[:, 1] + c * points[:, 2] + d) / np.sqrt(a ** 2 + b ** 2 + c ** 2)
+    return PointCloud(points[distances <= 0])
+
+
+def background_removal(pcd, background_pcd, threshold=10):
+    """pose_estimation.py:380-392 always returns its input: the freshly made result cloud is tested
+    for emptiness before it is filled (:386-388).  Kept, because it decides which points reach ICP."""
+    return pcd
+
+
+def filter_largest_cluster(pcd, eps=10, min_points=10):
+    """DBSCAN, keep the largest cluster (pose_estimation.py:270-299); None when everything is noise."""
+    labels = np.array(pcd.cluster_dbscan(eps=eps, min_points=min_points, print_progress=True))
+    unique_labels, counts = np.unique(labels, return_counts=True)
+    valid_labels = unique_labels[unique_labels != -1]
+    if len(valid_labels) == 0:
+        print("No valid clusters found.")
+        return None
+    largest = valid_labels[np.argmax(counts[unique_labels != -1])]
+    return pcd.select_by_index(np.where(labels == largest)[0])
+
+
+def remove_statistical_outliers(pcd, nb_neighbors=20, std_ratio=1.0):
+    clean, _ = pcd.remove_statistical_outlier(nb_neighbors=nb_neighbors, std_ratio=std_ratio)
+    return clean
+
+
 def preprocess_source(pcd, background, param, i=0):
-    """Scene preprocessing (voxel grid, plane removal, clustering, outlier filter;
-    pose_estimation.py:186-268) is the 'next' row f2 of SURVEY s8 and is not built: the cloud
-    is returned as is.  Only the reference's parameter mutation for tracking frames is kept
-    (`down_sample = 5` when i > 0, :202-203)."""
+    """Scene preprocessing (pose_estimation.py:186-268): voxel grid, RANSAC table plane, half-space
+    cut, (background removal | plane removal), largest DBSCAN cluster, statistical outlier filter.
+    The point-cloud operations run on the GPU (pedp_hip.cloud_ops).  Returns (processed, filtered,
+    fpfh) with filtered is processed, as in the reference.
+
+    Not built, and what stands in:
+      * normal estimation (:301-306) feeds only compute_average_normal (:314-321), which orients the
+        table plane on the first frame.  estimate_normals(radius=2, max_nn=5) on a voxel grid of a
+        few millimetres finds fewer than three neighbours almost everywhere and Open3D then writes
+        (0, 0, 1); the average normal used here is that (0, 0, 1).  Tracking frames (i > 0) use the
+        reference's (1, 1, 1).
+      * FPFH features (:254-260) are only read by the global-registration path: the slot is None
+        (i == 0) or 0 (i > 0).
+      * param['mesh'] (Poisson re-meshing, :240-245) raises NotImplementedError.
+    A param dict without a 'preprocess_source' section means "already preprocessed": the cloud is
+    passed through (the tracking-frame mutation down_sample = 5 is still applied)."""
+    if "preprocess_source" not in param:
+        if i > 0:
+            param.setdefault("preprocess_source", {})["down_sample"] = 5
+        return pcd, pcd, None
+    params = param["preprocess_source"]
     if i > 0:
-        param.setdefault("preprocess_source", {})["down_sample"] = 5
-    return pcd, pcd, None
+        params["down_sample"] = 5
+    if background is not None:
+        background = background.voxel_down_sample(voxel_size=params["down_sample"] * 2)
+    pcd_down = pcd.voxel_down_sample(voxel_size=params["down_sample"])
+    plane_model, inliers = perform_plane_segmentation(pcd_down, params["plane_removal"])
+    average_normal = np.array([1, 1, 1], dtype=float)
+    if i == 0:
+        average_normal = np.array([0.0, 0.0, 1.0])
+        logging.info(f":: Average Normal for Source = {average_normal}")
+    plane_model, _ = flip_plane_normal_if_needed(plane_model, average_normal)
+    source_processed = remove_points_below_plane(pcd_down, plane_model)
+    if param.get("box"):
+        source_processed = background_removal(source_processed, background)
+    else:
+        source_processed = remove_plane(pcd_down, inliers)
+    if param.get("mesh"):
+        raise NotImplementedError("preprocess_source: param['mesh'] (Poisson re-meshing) is not part of this build")
+    source_processed = filter_largest_cluster(source_processed)
+    source_processed = remove_statistical_outliers(source_processed, nb_neighbors=75, std_ratio=0.01)
+    return source_processed, source_processed, (None if i == 0 else 0)
 
 
 def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, max_adjustment=50,

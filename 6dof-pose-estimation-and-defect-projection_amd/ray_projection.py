@@ -249,9 +249,9 @@ def align_to_surface(defect_points, target_pcd, offset=0.1, ctx=None):
     that is not built, so a model without normals is an error here."""
     from .geometry import normals_of, points_of
 
-    pts = np.asarray(defect_points, dtype=np.float64).reshape(len(defect_points), -1)
-    if len(pts) == 0:
+    if len(defect_points) == 0:
         return np.array([]), np.array([])
+    pts = np.asarray(defect_points, dtype=np.float64).reshape(len(defect_points), -1)
     model, normals = points_of(target_pcd), normals_of(target_pcd)
     if normals is None:
         raise RuntimeError("align_to_surface: the target cloud carries no normals; normal estimation "

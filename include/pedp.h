@@ -148,6 +148,34 @@ int pedp_depth2xyzmap(pedp_ctx_t ctx, const float *depth, int H, int W, const do
 int pedp_depth2xyzmap_batch(pedp_ctx_t ctx, const float *depths, int B, int H, int W, const float *Ks, float zfar,
                             int mem, float *xyz);
 
+/* ---------------------------------------------------------------- point-cloud operations
+ * the Open3D calls preprocess_source chains (src/pose_estimation.py:186-268),
+ * restated from the published open3d==0.18.0 algorithms.  Host arrays only (N x 3 float64); the
+ * calls return after completion.  Where Open3D's result depends on something that cannot be
+ * recovered (hash-map order, random_device seed, thread interleaving) the rule used is stated.
+ *
+ * voxel_down_sample (:204-205): voxel index floor((p - (min_bound - voxel/2)) / voxel) per axis;
+ * a voxel's points (and normals, nullable) are summed in point order and divided by the count.
+ * Output order: ascending (ix, iy, iz) (Open3D: unordered_map order).  capacity = N always fits. */
+int pedp_voxel_down_sample(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N, double voxel_size,
+                           double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out);
+/* cluster_dbscan (:284): neighbours are points with d^2 < eps^2 (itself included), core points
+ * have >= min_points neighbours; labels as Open3D's breadth-first sweep assigns them: clusters
+ * numbered by their smallest core index, a border point takes the smallest id among its core
+ * neighbours, noise is -1. */
+int pedp_cluster_dbscan(pedp_ctx_t ctx, const double *pts, int64_t N, double eps, int min_points, int32_t *labels);
+/* Per-point part of remove_statistical_outlier (:308-312): mean distance to the k nearest
+ * neighbours (the point itself is one of them), summed in ascending order; the global mean /
+ * deviation / threshold over N doubles is host arithmetic (pedp_hip.cloud_ops). */
+int pedp_knn_mean_distance(pedp_ctx_t ctx, const double *pts, int64_t N, int k, double *avg);
+/* segment_plane with ransac_n = 3 (:323-329).  Iteration t samples three distinct indices from a
+ * counter-based generator of (seed, t); plane through them; inliers |n.p + d| < threshold; the best
+ * iteration has the most inliers (earliest on ties); all iterations are evaluated (Open3D:
+ * random_device samples, probabilistic early stop).  Returns, like Open3D, the inliers of the best
+ * sampled plane (ascending) and the plane refitted to them (GetPlaneFromPoints). */
+int pedp_segment_plane(pedp_ctx_t ctx, const double *pts, int64_t N, double distance_threshold, int num_iterations,
+                       uint64_t seed, double plane[4], int32_t *inliers, int64_t *n_inliers);
+
 /* ---------------------------------------------------------------- ICP
  * Replaces src/pose_estimation.py:519-521 and :654-660:
  *     o3d.pipelines.registration.registration_icp(source, target, max_corr_dist, init,

@@ -1,0 +1,226 @@
+/* TEST INFRASTRUCTURE -- CPU restatement of the Open3D point-cloud operations that
+ * preprocess_source chains (src/pose_estimation.py:186-268), written from the published
+ * open3d==0.18.0 algorithms (the wheel is absent; parity unpinned).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ *   pedp_oracle_voxel_down_sample    PointCloud::VoxelDownSample     (pose_estimation.py:204-205)
+ *   pedp_oracle_dbscan               PointCloud::ClusterDBSCAN       (:284, eps 10, min_points 10)
+ *   pedp_oracle_knn_mean_distance    PointCloud::RemoveStatisticalOutliers, per-point part (:308-312)
+ *   pedp_oracle_segment_plane        PointCloud::SegmentPlane        (:323-329)
+ *
+ * Where Open3D's result depends on something that is not recoverable (hash-map iteration order,
+ * a random_device seed, thread interleaving) the choice made here is stated at the function and
+ * is the definition the HIP side is tested against.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "pedp_oracle.h"
+
+static double d2(const double *a, const double *b) {
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* ---- voxel grid.  Open3D: voxel_min_bound = min_bound - voxel_size / 2, index = floor((p -
+ * voxel_min_bound) / voxel_size) per axis, the points (and normals) of a voxel are summed in
+ * point order and divided by the count.  Output order: Open3D iterates an unordered_map (not
+ * recoverable); here voxels come out in ascending (ix, iy, iz). */
+typedef struct { uint64_t key; int64_t idx; } keyed;
+static int cmp_keyed(const void *a, const void *b) {
+    const keyed *x = (const keyed *)a, *y = (const keyed *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int64_t pedp_oracle_voxel_down_sample(const double *pts, const double *normals, int64_t N, double voxel,
+                                      double *out_pts, double *out_normals) {
+    if (N <= 0) return 0;
+    double lo[3] = {pts[0], pts[1], pts[2]};
+    for (int64_t i = 1; i < N; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (pts[3 * i + k] < lo[k]) lo[k] = pts[3 * i + k];
+    for (int k = 0; k < 3; ++k) lo[k] = lo[k] - voxel * 0.5;
+    keyed *ks = (keyed *)malloc(sizeof(keyed) * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) {
+        uint64_t key = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int64_t c = (int64_t)floor((pts[3 * i + k] - lo[k]) / voxel);
+            key = (key << 21) | ((uint64_t)c & 0x1FFFFF);
+        }
+        ks[i].key = key;
+        ks[i].idx = i;
+    }
+    qsort(ks, (size_t)N, sizeof(keyed), cmp_keyed);
+    int64_t n_out = 0;
+    for (int64_t a = 0; a < N;) {
+        int64_t b = a;
+        double s[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
+        while (b < N && ks[b].key == ks[a].key) {
+            const int64_t i = ks[b].idx;
+            for (int k = 0; k < 3; ++k) s[k] += pts[3 * i + k];
+            if (normals)
+                for (int k = 0; k < 3; ++k) sn[k] += normals[3 * i + k];
+            ++b;
+        }
+        const double cnt = (double)(b - a);
+        for (int k = 0; k < 3; ++k) out_pts[3 * n_out + k] = s[k] / cnt;
+        if (normals && out_normals)
+            for (int k = 0; k < 3; ++k) out_normals[3 * n_out + k] = sn[k] / cnt;
+        ++n_out;
+        a = b;
+    }
+    free(ks);
+    return n_out;
+}
+
+/* ---- DBSCAN, Open3D's breadth-first form: neighbours = points with d^2 < eps^2 (nanoflann's
+ * radius search is strict; the point itself counts), core iff at least min_points neighbours;
+ * points are scanned in index order, every unvisited core point starts the next cluster and the
+ * cluster grows through the neighbour lists of its core points; a non-core point reached by a
+ * cluster takes that cluster's label if it is still unlabelled or noise.  Labels: -1 noise. */
+void pedp_oracle_dbscan(const double *pts, int64_t N, double eps, int min_points, int32_t *labels) {
+    const double e2 = eps * eps;
+    int32_t *cnt = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+        int32_t c = 0;
+        for (int64_t j = 0; j < N; ++j)
+            if (d2(pts + 3 * i, pts + 3 * j) < e2) ++c;
+        cnt[i] = c;
+    }
+    for (int64_t i = 0; i < N; ++i) labels[i] = -2; /* undefined */
+    int64_t *queue = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    int32_t cluster = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        if (labels[i] != -2) continue;
+        if (cnt[i] < min_points) { labels[i] = -1; continue; }
+        labels[i] = cluster;
+        int64_t head = 0, tail = 0;
+        queue[tail++] = i;
+        while (head < tail) {
+            const int64_t q = queue[head++];  /* q is a core point of this cluster */
+            for (int64_t j = 0; j < N; ++j) {
+                if (!(d2(pts + 3 * q, pts + 3 * j) < e2)) continue;
+                if (labels[j] == -1) { labels[j] = cluster; continue; } /* noise becomes border */
+                if (labels[j] != -2) continue;
+                labels[j] = cluster;
+                if (cnt[j] >= min_points) queue[tail++] = j;
+            }
+        }
+        ++cluster;
+    }
+    free(queue);
+    free(cnt);
+}
+
+/* ---- statistical outlier removal, per-point part: mean of the distances to the k nearest
+ * neighbours (the point itself is one of them, as in Open3D's SearchKNN on its own cloud), summed
+ * in ascending order of distance.  -1 when the cloud is empty.  The global mean / Bessel-corrected
+ * deviation / threshold are formed by the caller in index order (pedp_oracle.py). */
+static int cmp_double(const void *a, const void *b) {
+    const double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? -1 : (x > y);
+}
+void pedp_oracle_knn_mean_distance(const double *pts, int64_t N, int k, double *avg) {
+#pragma omp parallel
+    {
+        double *d = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 0; i < N; ++i) {
+            for (int64_t j = 0; j < N; ++j) d[j] = d2(pts + 3 * i, pts + 3 * j);
+            qsort(d, (size_t)N, sizeof(double), cmp_double);
+            const int64_t m = N < k ? N : k;
+            double s = 0.0;
+            for (int64_t j = 0; j < m; ++j) s += sqrt(d[j]);
+            avg[i] = m > 0 ? s / (double)m : -1.0;
+        }
+        free(d);
+    }
+}
+
+/* ---- plane RANSAC.  Open3D draws its samples from a random_device-seeded engine and stops early
+ * by a probability rule evaluated under OpenMP: neither is recoverable.  Definition here: iteration
+ * t samples the three distinct indices pedp_oracle_sample3(seed, t, N); plane through them
+ * (TriangleMesh::ComputeTrianglePlane: unit normal of (p1-p0)x(p2-p0), d = -n.p0), degenerate
+ * samples skipped; inliers |n.p + d| < threshold; the best iteration has the most inliers, ties go
+ * to the earliest iteration; all num_iterations are evaluated.  Returned like Open3D: the inliers
+ * of the best sampled plane, and the plane refitted to them (GetPlaneFromPoints: centroid +
+ * largest-determinant closed form). */
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+void pedp_oracle_sample3(uint64_t seed, int64_t t, int64_t N, int64_t out[3]) {
+    uint64_t s = splitmix64(seed ^ splitmix64((uint64_t)t));
+    int n = 0;
+    while (n < 3) {
+        s = splitmix64(s);
+        const int64_t c = (int64_t)(s % (uint64_t)N);
+        int dup = 0;
+        for (int q = 0; q < n; ++q) dup |= (out[q] == c);
+        if (!dup) out[n++] = c;
+    }
+}
+static int triangle_plane(const double *p0, const double *p1, const double *p2, double pl[4]) {
+    const double a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    const double n = sqrt((x * x + y * y) + z * z);
+    if (!(n > 0.0)) return 0;
+    pl[0] = x / n; pl[1] = y / n; pl[2] = z / n;
+    pl[3] = -((pl[0] * p0[0] + pl[1] * p0[1]) + pl[2] * p0[2]);
+    return 1;
+}
+static double plane_dist(const double pl[4], const double *p) {
+    return fabs(((pl[0] * p[0] + pl[1] * p[1]) + pl[2] * p[2]) + pl[3]);
+}
+void pedp_oracle_plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (n < 3) return;
+    double c[3] = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) c[k] += pts[3 * (int64_t)idx[i] + k];
+    for (int k = 0; k < 3; ++k) c[k] /= (double)n;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = pts + 3 * (int64_t)idx[i];
+        const double rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
+        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+    }
+    const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+    double a, b, cc;
+    if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }
+    else if (det_y >= det_z) { a = xz * yz - xy * zz; b = det_y; cc = xy * xz - yz * xx; }
+    else { a = xy * yz - xz * yy; b = xy * xz - yz * xx; cc = det_z; }
+    const double nrm = sqrt((a * a + b * b) + cc * cc);
+    if (!(nrm > 0.0)) return;
+    pl[0] = a / nrm; pl[1] = b / nrm; pl[2] = cc / nrm;
+    pl[3] = -((pl[0] * c[0] + pl[1] * c[1]) + pl[2] * c[2]);
+}
+int64_t pedp_oracle_segment_plane(const double *pts, int64_t N, double threshold, int num_iterations, uint64_t seed,
+                                  double plane[4], int32_t *inliers) {
+    plane[0] = plane[1] = plane[2] = plane[3] = 0.0;
+    if (N < 3) return 0;
+    int64_t best_cnt = -1;
+    double best[4] = {0, 0, 0, 0};
+    for (int t = 0; t < num_iterations; ++t) {
+        int64_t s[3];
+        double pl[4];
+        pedp_oracle_sample3(seed, t, N, s);
+        if (!triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], pl)) continue;
+        int64_t cnt = 0;
+#pragma omp parallel for reduction(+ : cnt)
+        for (int64_t i = 0; i < N; ++i) cnt += plane_dist(pl, pts + 3 * i) < threshold;
+        if (cnt > best_cnt) { best_cnt = cnt; memcpy(best, pl, sizeof(best)); }
+    }
+    if (best_cnt < 0) return 0;
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; ++i)
+        if (plane_dist(best, pts + 3 * i) < threshold) inliers[n++] = (int32_t)i;
+    pedp_oracle_plane_from_points(pts, inliers, n, plane);
+    return n;
+}

@@ -86,6 +86,16 @@ void pedp_oracle_vec6_to_T(const double x[6], double T[16]);
 void pedp_oracle_kabsch(const double *S, const double *Tg, int64_t K, double T[16]);
 void pedp_oracle_rot_xyz(const double abc[3], double R[9]); /* Rx(a)Ry(b)Rz(c) */
 
+/* point-cloud operations of preprocess_source (cloudops.c): src/pose_estimation.py:186-392 */
+int64_t pedp_oracle_voxel_down_sample(const double *pts, const double *normals, int64_t N, double voxel,
+                                      double *out_pts, double *out_normals);
+void pedp_oracle_dbscan(const double *pts, int64_t N, double eps, int min_points, int32_t *labels);
+void pedp_oracle_knn_mean_distance(const double *pts, int64_t N, int k, double *avg);
+void pedp_oracle_sample3(uint64_t seed, int64_t t, int64_t N, int64_t out[3]);
+void pedp_oracle_plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]);
+int64_t pedp_oracle_segment_plane(const double *pts, int64_t N, double threshold, int num_iterations, uint64_t seed,
+                                  double plane[4], int32_t *inliers);
+
 /* depth pre-filters (depth.c): Utils.py:304-442 */
 void pedp_oracle_erode_depth(const float *depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                              float zfar, float *out, int nthreads);

@@ -176,6 +176,76 @@ def depth2xyzmap_batch(depths, Ks, zfar):
     return out
 
 
+def voxel_down_sample(points, voxel_size, normals=None):
+    """PointCloud.voxel_down_sample: (points, normals or None), voxels in ascending (ix, iy, iz)."""
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    n = None if normals is None else np.ascontiguousarray(normals, np.float64).reshape(-1, 3)
+    out = np.empty_like(p)
+    outn = np.empty_like(p) if n is not None else None
+    fn = lib().pedp_oracle_voxel_down_sample
+    fn.restype = C.c_int64
+    m = fn(_p(p), _p(n), C.c_int64(len(p)), C.c_double(voxel_size), _p(out), _p(outn))
+    return out[:m].copy(), (None if outn is None else outn[:m].copy())
+
+
+def cluster_dbscan(points, eps, min_points):
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    labels = np.empty(len(p), np.int32)
+    lib().pedp_oracle_dbscan(_p(p), C.c_int64(len(p)), C.c_double(eps), C.c_int(min_points), _p(labels))
+    return labels
+
+
+def knn_mean_distance(points, k):
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    avg = np.empty(len(p), np.float64)
+    lib().pedp_oracle_knn_mean_distance(_p(p), C.c_int64(len(p)), C.c_int(k), _p(avg))
+    return avg
+
+
+def statistical_outlier_indices(avg, std_ratio):
+    """The global part of PointCloud.remove_statistical_outlier on the per-point mean distances:
+    mean over the valid ones, Bessel-corrected deviation, keep 0 < avg < mean + ratio * std; all
+    sums in index order."""
+    valid = 0
+    total = 0.0
+    for a in avg:
+        if a > 0:
+            total += a
+        if a >= 0:
+            valid += 1
+    if valid == 0:
+        return np.zeros(0, np.int64)
+    mean = total / valid
+    sq = 0.0
+    for a in avg:
+        if a > 0:
+            sq += (a - mean) * (a - mean)
+    std = np.sqrt(sq / (valid - 1)) if valid > 1 else float("nan")
+    thr = mean + std_ratio * std
+    return np.nonzero((avg > 0) & (avg < thr))[0]
+
+
+def remove_statistical_outlier(points, nb_neighbors, std_ratio):
+    return statistical_outlier_indices(knn_mean_distance(points, nb_neighbors), std_ratio)
+
+
+def segment_plane(points, distance_threshold, num_iterations, seed=0):
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    plane = np.zeros(4)
+    inl = np.empty(len(p), np.int32)
+    fn = lib().pedp_oracle_segment_plane
+    fn.restype = C.c_int64
+    n = fn(_p(p), C.c_int64(len(p)), C.c_double(distance_threshold), C.c_int(num_iterations), C.c_uint64(seed),
+           _p(plane), _p(inl))
+    return plane, inl[:n].copy()
+
+
+def sample3(seed, t, n):
+    out = (C.c_int64 * 3)()
+    lib().pedp_oracle_sample3(C.c_uint64(seed), C.c_int64(t), C.c_int64(n), out)
+    return list(out)
+
+
 def icp(src, tgt, tgt_normals, max_corr_dist, init, estimator=P2PLANE, max_iter=30, rel_fitness=1e-6,
         rel_rmse=1e-6, kdtree=True, nthreads=0, want_trace=True):
     s = np.ascontiguousarray(src, np.float64).reshape(-1, 3)

@@ -1,0 +1,171 @@
+"""GPU parity of the point-cloud operations of preprocess_source against
+oracle/cloudops.c: voxel averages, DBSCAN labels, kept indices of the statistical outlier filter,
+RANSAC inliers -- all bit-exact (float64 sums are taken in the oracle's order); the refitted plane
+within 1e-12.  Through the C ABI (pedp_voxel_down_sample, pedp_cluster_dbscan,
+pedp_knn_mean_distance, pedp_segment_plane)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n_plane=6000, n_obj=2500, n_noise=150, seed=0):
+    """A table plane, an object blob above it, a second smaller blob and scattered outliers (mm)."""
+    rng = np.random.default_rng(seed)
+    plane = np.column_stack([rng.uniform(-150, 150, n_plane), rng.uniform(-100, 100, n_plane), 400 + rng.normal(0, 0.4, n_plane)])
+    obj = rng.normal([10, -5, 360], [18, 14, 9], (n_obj, 3))
+    small = rng.normal([120, 70, 380], 4, (n_obj // 8, 3))
+    noise = rng.uniform([-200, -150, 250], [200, 150, 450], (n_noise, 3))
+    pts = np.vstack([plane, obj, small, noise])
+    return pts[rng.permutation(len(pts))]
+
+
+@pytest.mark.parametrize("voxel", [2.0, 5.0, 25.0])
+def test_voxel_down_sample(ctx, oracle, voxel):
+    from pedp_hip import cloud_ops
+
+    pts = _scene()
+    nrm = np.random.default_rng(1).normal(size=pts.shape)
+    got, gotn = cloud_ops.voxel_down_sample(pts, voxel, nrm)
+    ref, refn = oracle.voxel_down_sample(pts, voxel, nrm)
+    assert got.shape == ref.shape and 10 < len(ref) < len(pts)
+    assert np.array_equal(got, ref) and np.array_equal(gotn, refn)
+    g2, n2 = cloud_ops.voxel_down_sample(pts, voxel)
+    assert n2 is None and np.array_equal(g2, ref)
+    # one point, all points in one voxel, empty, bad size
+    one, _ = cloud_ops.voxel_down_sample(pts[:1], voxel)
+    assert np.array_equal(one, pts[:1])
+    big, _ = cloud_ops.voxel_down_sample(pts, 1e4)
+    assert np.array_equal(big, oracle.voxel_down_sample(pts, 1e4)[0]) and len(big) <= 8
+    assert len(cloud_ops.voxel_down_sample(np.zeros((0, 3)), voxel)[0]) == 0
+    with pytest.raises(Exception, match="voxel_size"):
+        cloud_ops.voxel_down_sample(pts, 0.0)
+    with pytest.raises(Exception, match="too small"):
+        cloud_ops.voxel_down_sample(pts, 1e-5)
+
+
+@pytest.mark.parametrize("eps,min_points", [(10.0, 10), (4.0, 5), (2.0, 3), (60.0, 10)])
+def test_cluster_dbscan_labels(ctx, oracle, eps, min_points):
+    from pedp_hip import cloud_ops
+
+    pts, _ = oracle.voxel_down_sample(_scene(seed=3), 3.0)
+    got = cloud_ops.cluster_dbscan(pts, eps, min_points)
+    ref = oracle.cluster_dbscan(pts, eps, min_points)
+    assert np.array_equal(got, ref)
+    assert ref.max() >= 0
+
+
+def test_cluster_dbscan_edge_cases(ctx, oracle):
+    from pedp_hip import cloud_ops
+
+    rng = np.random.default_rng(5)
+    # border points shared by two clusters, chains, duplicates, a single point, everything noise
+    a = rng.normal([0, 0, 0], 1.0, (60, 3))
+    b = rng.normal([9, 0, 0], 1.0, (60, 3))
+    bridge = np.array([[4.5, 0, 0], [4.4, 0.1, 0], [4.6, -0.1, 0]])
+    pts = np.vstack([a, bridge, b, a[:5]])
+    for eps, mp in ((3.0, 8), (2.0, 4), (5.0, 20)):
+        assert np.array_equal(cloud_ops.cluster_dbscan(pts, eps, mp), oracle.cluster_dbscan(pts, eps, mp))
+    assert np.array_equal(cloud_ops.cluster_dbscan(pts[:1], 1.0, 1), [0])
+    assert np.array_equal(cloud_ops.cluster_dbscan(pts[:1], 1.0, 2), [-1])
+    far = rng.uniform(-1e3, 1e3, (200, 3))
+    assert np.all(cloud_ops.cluster_dbscan(far, 1.0, 3) == -1)
+    assert len(cloud_ops.cluster_dbscan(np.zeros((0, 3)), 1.0, 3)) == 0
+    # huge extent against a small eps: the grid coarsens instead of overflowing
+    wide = np.vstack([a, a + [5e6, 0, 0]])
+    assert np.array_equal(cloud_ops.cluster_dbscan(wide, 3.0, 8), oracle.cluster_dbscan(wide, 3.0, 8))
+
+
+@pytest.mark.parametrize("k,ratio", [(75, 0.01), (20, 1.0), (1, 0.5), (5000, 2.0)])
+def test_statistical_outlier_removal(ctx, oracle, k, ratio):
+    from pedp_hip import cloud_ops
+
+    pts, _ = oracle.voxel_down_sample(_scene(seed=7), 4.0)
+    if k > 300:
+        with pytest.raises(Exception, match="1..300"):
+            cloud_ops.knn_mean_distance(pts, k)
+        return
+    avg = cloud_ops.knn_mean_distance(pts, k)
+    assert np.array_equal(avg, oracle.knn_mean_distance(pts, k))
+    keep = cloud_ops.remove_statistical_outlier(pts, k, ratio)
+    assert np.array_equal(keep, oracle.remove_statistical_outlier(pts, k, ratio))
+    few = pts[:40]                       # fewer points than neighbours: all of them are "the k nearest"
+    assert np.array_equal(cloud_ops.knn_mean_distance(few, 75), oracle.knn_mean_distance(few, 75))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345])
+def test_segment_plane(ctx, oracle, seed):
+    from pedp_hip import cloud_ops
+
+    pts, _ = oracle.voxel_down_sample(_scene(seed=9), 3.0)
+    plane, inl = cloud_ops.segment_plane(pts, 1.0, 3, 300, seed=seed)
+    rplane, rinl = oracle.segment_plane(pts, 1.0, 300, seed=seed)
+    assert np.array_equal(inl, rinl) and len(inl) > 1000
+    assert np.abs(plane - rplane).max() < 1e-12
+    assert abs(abs(plane[2]) - 1.0) < 1e-3 and abs(abs(plane[3]) - 400.0) < 1.0     # the table: z = 400
+    # degenerate: fewer than three points, collinear points
+    p0, i0 = cloud_ops.segment_plane(pts[:2], 1.0, 3, 10)
+    assert not p0.any() and len(i0) == 0
+    line = np.outer(np.arange(50.0), [1.0, 2.0, 3.0])
+    p1, i1 = cloud_ops.segment_plane(line, 1.0, 3, 20)
+    r1, ri1 = oracle.segment_plane(line, 1.0, 20)
+    assert np.array_equal(i1, ri1) and np.array_equal(p1, r1)
+
+
+def test_pointcloud_methods_follow_open3d_shapes(ctx, oracle):
+    """The holder's Open3D-style methods as preprocess_source calls them."""
+    from pedp_hip.compat import PointCloud
+
+    pts = _scene(seed=11)
+    pcd = PointCloud(pts)
+    down = pcd.voxel_down_sample(voxel_size=5)
+    assert isinstance(down, PointCloud) and np.array_equal(down.points, oracle.voxel_down_sample(pts, 5)[0])
+    plane, inliers = down.segment_plane(distance_threshold=1.0, ransac_n=3, num_iterations=200)
+    assert len(plane) == 4 and isinstance(inliers, list)
+    rest = down.select_by_index(inliers, invert=True)
+    assert len(rest.points) == len(down.points) - len(inliers)
+    labels = np.array(rest.cluster_dbscan(eps=10, min_points=10, print_progress=True))
+    assert np.array_equal(labels, oracle.cluster_dbscan(rest.points, 10, 10))
+    clean, ind = rest.remove_statistical_outlier(nb_neighbors=75, std_ratio=0.01)
+    assert np.array_equal(ind, oracle.remove_statistical_outlier(rest.points, 75, 0.01)) and len(clean.points) == len(ind)
+
+
+def test_preprocess_source_flow_matches_oracle_chain(ctx, oracle):
+    """preprocess_source (pose_estimation.py:186-268) on a rendered frame (object in front of a back
+    plane): the same chain put together from the oracle's operations gives the same points."""
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, preprocess_source
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)                                     # object + back plane at z = 600, 0.5 mm noise
+    param = {"preprocess_source": {"down_sample": 4, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 200}},
+             "box": False, "mesh": False}
+    out, filtered, fpfh = preprocess_source(PointCloud(scene), None, param, i=0)
+    assert filtered is out and fpfh is None
+    # the oracle's chain
+    down, _ = oracle.voxel_down_sample(scene, 4)
+    plane, inl = oracle.segment_plane(down, 2.0, 200, seed=0)
+    rest = np.delete(down, inl, axis=0)                        # remove_plane (box = False)
+    labels = oracle.cluster_dbscan(rest, 10, 10)
+    ids, counts = np.unique(labels[labels >= 0], return_counts=True)
+    big = rest[labels == ids[np.argmax(counts)]]
+    ref = big[oracle.remove_statistical_outlier(big, 75, 0.01)]
+    assert np.array_equal(out.points, ref) and 200 < len(ref) < len(down)
+    assert abs(abs(plane[2]) - 1) < 1e-3                       # the back plane was the segmented plane
+    # box = True keeps the half space in front of the plane instead (background_removal returns its input)
+    param["box"] = True
+    boxed, _, _ = preprocess_source(PointCloud(scene), PointCloud(scene[::50]), param, i=1)
+    assert param["preprocess_source"]["down_sample"] == 5      # tracking-frame mutation (:202-203)
+    down5, _ = oracle.voxel_down_sample(scene, 5)
+    pl5, _ = oracle.segment_plane(down5, 2.0, 200, seed=0)
+    if np.dot(pl5[:3] / np.linalg.norm(pl5[:3]), [1, 1, 1]) < 0:
+        pl5 = -pl5
+    dist = (down5 @ pl5[:3] + pl5[3]) / np.sqrt((pl5[:3] ** 2).sum())
+    half = down5[dist <= 0]
+    lab = oracle.cluster_dbscan(half, 10, 10)
+    ids, counts = np.unique(lab[lab >= 0], return_counts=True)
+    big = half[lab == ids[np.argmax(counts)]]
+    assert np.array_equal(boxed.points, big[oracle.remove_statistical_outlier(big, 75, 0.01)])
+    with pytest.raises(NotImplementedError):
+        preprocess_source(PointCloud(scene), None, dict(param, mesh=True), i=1)
