@@ -201,37 +201,63 @@ __global__ void dbscan_label_kernel(Grid g, const double *__restrict__ sp, int64
 }
 
 // ------------------------------------------------------------------ k nearest neighbours (mean distance)
-// One thread per query, all threads of a wave walk the same candidate (scalar loads, broadcast);
-// each thread keeps its k smallest squared distances sorted ascending in LDS.
+// One thread per query walks the grid shell by shell around its own cell: after the shell at
+// Chebyshev distance rho every unvisited point is farther than rho * cell, so the search ends as
+// soon as the k-th best squared distance is within (rho * cell)^2.  Near cells come first, so the
+// k smallest squared distances -- kept sorted ascending in LDS, k x 64 doubles per workgroup --
+// settle after little more than k insertions.  Candidates are fetched four at a time.
 constexpr int KNN_THREADS = 64;
-__global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(const double *__restrict__ pts, int64_t N, int k,
-                                                               double *__restrict__ avg) {
-    extern __shared__ double top[];  // [k][KNN_THREADS]: element r of thread t at top[r * KNN_THREADS + t]
+__global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                               const int *__restrict__ cell_start,
+                                                               const int *__restrict__ cell_end,
+                                                               const int *__restrict__ idx_sorted, int k,
+                                                               double *__restrict__ avg /* by original index */) {
+    extern __shared__ double top[];  // element r of thread t at top[r * KNN_THREADS + t]
     const int t = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * KNN_THREADS + t;
-    const bool live = i < N;
-    const int64_t ii = live ? i : 0;
-    const double p[3] = {pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2]};
+    const int64_t j = (int64_t)blockIdx.x * KNN_THREADS + t;
+    if (j >= N) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
     const int m = (int)(N < k ? N : k);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    for (int r = 0; r < m; ++r) top[r * KNN_THREADS + t] = inf;
-    double worst = inf;
-    for (int64_t q = 0; q < N; ++q) {
-        const double d = dist2(p, pts + 3 * q);
-        if (d < worst) {  // insert, keeping ascending order
-            int r = m - 1;
-            while (r > 0 && top[(r - 1) * KNN_THREADS + t] > d) {
-                top[r * KNN_THREADS + t] = top[(r - 1) * KNN_THREADS + t];
-                --r;
-            }
-            top[r * KNN_THREADS + t] = d;
-            worst = top[(m - 1) * KNN_THREADS + t];
+    int have = 0;
+    double worst = inf;  // the m-th best once m candidates are in
+    auto offer = [&](double d) {
+        if (!(d < worst)) return;
+        int r = have < m ? have : m - 1;  // slot that opens up
+        while (r > 0 && top[(r - 1) * KNN_THREADS + t] > d) {
+            top[r * KNN_THREADS + t] = top[(r - 1) * KNN_THREADS + t];
+            --r;
         }
+        top[r * KNN_THREADS + t] = d;
+        if (have < m) ++have;
+        if (have == m) worst = top[(m - 1) * KNN_THREADS + t];
+    };
+    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
+    const int far = max(max(max(cx, g.dim[0] - 1 - cx), max(cy, g.dim[1] - 1 - cy)), max(cz, g.dim[2] - 1 - cz));
+    for (int rho = 0; rho <= far; ++rho) {
+        for (int z = max(cz - rho, 0); z <= min(cz + rho, g.dim[2] - 1); ++z)
+            for (int y = max(cy - rho, 0); y <= min(cy + rho, g.dim[1] - 1); ++y) {
+                const bool face = (abs(z - cz) == rho) || (abs(y - cy) == rho);
+                for (int x = max(cx - rho, 0); x <= min(cx + rho, g.dim[0] - 1); ++x) {
+                    if (!face && abs(x - cx) != rho) continue;  // interior of the cube: visited by an earlier shell
+                    const int c = x + g.dim[0] * (y + g.dim[1] * z);
+                    const int e = cell_end[c];
+                    for (int q = cell_start[c]; q < e; q += 4) {
+                        double d[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) d[u] = (q + u < e) ? dist2(p, sp + 3 * (size_t)(q + u)) : inf;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) offer(d[u]);
+                    }
+                }
+            }
+        const double reach = (double)rho * g.cell * (1.0 - 1e-9);
+        if (have == m && worst <= reach * reach) break;
     }
-    if (!live) return;
     double s = 0.0;
     for (int r = 0; r < m; ++r) s += sqrt(top[r * KNN_THREADS + t]);
-    avg[i] = m > 0 ? s / (double)m : -1.0;
+    avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
 // ------------------------------------------------------------------ plane RANSAC
@@ -331,6 +357,25 @@ void bounds(const double *pts, int64_t N, double lo[3], double hi[3]) {
         }
 }
 
+// grid over the bounding box with the given cell size, coarsened until it has at most 2^24 cells
+int make_grid(const double lo[3], const double hi[3], double cell, Grid &g, int64_t &n_cells, const char *who) {
+    g.cell = cell;
+    while (true) {
+        double cells = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "%s: non-finite coordinates", who);
+            g.lo[k] = lo[k];
+            const double d = std::floor((hi[k] - lo[k]) / g.cell) + 1.0;
+            g.dim[k] = d < 1.0 ? 1 : (d > 1e9 ? 1000000000 : (int)d);
+            cells *= (double)g.dim[k];
+        }
+        if (cells <= 16777216.0) break;
+        g.cell *= 2.0;  // a coarser grid is still a valid (slower) neighbourhood index
+    }
+    n_cells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    return PEDP_OK;
+}
+
 #define PEDP_ROCPRIM(expr)                                                                     \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -415,20 +460,10 @@ int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, 
     double lo[3], hi[3];
     bounds(pts, N, lo, hi);
     Grid g;
-    g.cell = eps * (1.0 + 1e-9);  // >= eps with margin: neighbours within eps are never two cells apart
-    while (true) {
-        double cells = 1.0;
-        for (int k = 0; k < 3; ++k) {
-            PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_cluster_dbscan: non-finite coordinates");
-            g.lo[k] = lo[k];
-            const double d = std::floor((hi[k] - lo[k]) / g.cell) + 1.0;
-            g.dim[k] = d < 1.0 ? 1 : (d > 1e9 ? 1000000000 : (int)d);
-            cells *= (double)g.dim[k];
-        }
-        if (cells <= 16777216.0) break;
-        g.cell *= 2.0;  // a coarser grid is still a valid (slower) neighbourhood index
-    }
-    const int64_t n_cells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    int64_t n_cells = 0;
+    // cell >= eps with margin: neighbours within eps are never two cells apart
+    rc = make_grid(lo, hi, eps * (1.0 + 1e-9), g, n_cells, "pedp_cluster_dbscan");
+    if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     const unsigned n = (unsigned)N;
     size_t tmp_sort = 0, tmp_scan = 0;
@@ -476,16 +511,44 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     PEDP_REQUIRE(k >= 1 && k <= 300, "pedp_knn_mean_distance: k must be in 1..300");  // k x 64 doubles of LDS per workgroup
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(avg, "pedp_knn_mean_distance: null output");
+    double lo[3], hi[3];
+    bounds(pts, N, lo, hi);
+    // cell ~ the radius that holds k points if the cloud were spread over a sheet of the box's
+    // largest extent (scanned surfaces are sheets); any cell size gives the same result
+    double ext = 0.0;
+    for (int d = 0; d < 3; ++d) ext = std::fmax(ext, hi[d] - lo[d]);
+    double cell = ext * std::sqrt((double)k / (3.14159265358979 * (double)N));
+    if (!(cell > 0.0) || !std::isfinite(cell)) cell = 1.0;
+    Grid g;
+    int64_t n_cells = 0;
+    rc = make_grid(lo, hi, cell, g, n_cells, "pedp_knn_mean_distance");
+    if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    int st = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(double) * N) + 512);
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                           (int *)nullptr, n, 0, 32, c->stream));
+    const size_t need = a256(sizeof(double) * 3 * N) * 2 + a256(sizeof(double) * N) + a256(sizeof(unsigned) * N) * 2 +
+                        a256(sizeof(int) * N) * 2 + a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + 4096;
+    int st = c->ops.reserve(need);
     if (st) return st;
     Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N), *d_avg = cv.take<double>(N);
+    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_avg = cv.take<double>(N);
+    unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
+    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
+    void *d_tmp = cv.take<char>(tmp_sort);
     PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
     const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
     PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream,
-                       d_pts, N, k, d_avg);
+                       g, sp, N, cell_start, cell_end, val_s, k, d_avg);
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
