@@ -133,6 +133,32 @@ def test_refine_pose_with_icp_full_flow(oracle):
     assert err < 0.5                                            # and it actually refines towards the truth (mm)
 
 
+def test_refine_pose_with_icp_from_raw_frame(oracle):
+    """The reference's whole per-frame chain on a raw rendered frame (object + back plane): the
+    preprocess_source section switches on voxel grid, plane removal, clustering and the outlier
+    filter on the GPU, then z search and randomised ICP restarts; the refined pose lands on the
+    ground truth."""
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, refine_pose_with_icp
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)                                      # 0.5 mm noise, misses on the z = 600 plane
+    src, tgt = PointCloud(scene), PointCloud(f.model_points, normals=f.normals)
+    params = {"preprocess_target": {"max_pcd": 100000},
+              "preprocess_source": {"down_sample": 2, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 300}},
+              "box": False, "mesh": False,
+              "refine_registration": {"distance_threshold": 6.0}, "run_icp": {"fitness_threshold": 0.97, "rmse_threshold": 3.5}}
+    init = synth.start_pose()
+    init[2, 3] += 5.0
+    np.random.seed(3)
+    moved, best, z, tgt_proc = refine_pose_with_icp(src, tgt, PointCloud(scene[::40]), init, params)
+    # the 2,000-vertex model is sampled every ~5 mm, so the point-to-point rmse at the true pose is ~2.8 mm
+    assert best.fitness > 0.97 and best.inlier_rmse < 3.5
+    assert np.abs(np.linalg.inv(best.transformation) - f.T_gt).max() < 1.0
+    assert len(moved.points) == len(f.model_points)
+
+
 def test_dist_hip_backend_single_rank(oracle):
     """pedp_hip.dist with the product backend on one GPU (no process group): same answers as
     the plain calls; exercises HipBackend (torch stream hand-over, device packet view)."""
