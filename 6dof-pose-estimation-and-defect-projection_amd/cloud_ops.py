@@ -82,3 +82,15 @@ def segment_plane(points, distance_threshold, ransac_n=3, num_iterations=100, se
                                               C.c_uint64(_SEED if seed is None else int(seed)), _lib._ptr(plane), _lib._ptr(inl),
                                               C.byref(n)), "pedp_segment_plane")
     return plane, inl[:n.value].copy()
+
+
+def estimate_normals(points, radius, max_nn, prior=None, ctx=None):
+    """Normals by PCA over the hybrid neighbourhood (radius, max_nn); `prior` = existing normals to
+    agree with (Open3D keeps the orientation of normals that are already there)."""
+    ctx = ctx or _lib.default_context()
+    p = _pts(points)
+    pr = None if prior is None or len(prior) == 0 else _pts(prior)
+    out = np.empty_like(p)
+    _lib.check(_lib.load().pedp_estimate_normals(ctx._h, _lib._ptr(p), len(p), float(radius), int(max_nn), _lib._ptr(pr),
+                                                 _lib._ptr(out)), "pedp_estimate_normals")
+    return out

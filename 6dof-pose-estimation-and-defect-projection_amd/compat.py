@@ -7,9 +7,10 @@ stay the reference's own.
 import numpy as np
 
 from . import _lib
-from .geometry import (LineSet, PinholeCameraIntrinsic, PointCloud, RegistrationResult,  # noqa: F401
-                       TriangleMesh)
-from .icp_refine import (background_removal, determine_pose, filter_largest_cluster,  # noqa: F401
+from .geometry import (KDTreeSearchParamHybrid, LineSet, PinholeCameraIntrinsic, PointCloud,  # noqa: F401
+                       RegistrationResult, TriangleMesh)
+from .icp_refine import (background_removal, compute_average_normal, determine_pose, estimate_normals,  # noqa: F401
+                         filter_largest_cluster,
                          flip_plane_normal_if_needed, improve_result, perform_plane_segmentation,
                          predict_z_axis_adjustment, preprocess_source, preprocess_target, refine_pose_with_icp,
                          refine_registration, remove_plane, remove_points_below_plane, remove_statistical_outliers,
@@ -47,7 +48,8 @@ __all__ = [
     "refine_registration", "improve_result", "predict_z_axis_adjustment", "refine_pose_with_icp", "determine_pose",
     "preprocess_source", "preprocess_target", "transform_object",
     "perform_plane_segmentation", "flip_plane_normal_if_needed", "remove_plane", "remove_points_below_plane",
-    "background_removal", "filter_largest_cluster", "remove_statistical_outliers",
+    "background_removal", "filter_largest_cluster", "remove_statistical_outliers", "estimate_normals",
+    "compute_average_normal", "KDTreeSearchParamHybrid",
     "heatmap_to_points", "compute_rays", "intersect_rays_with_mesh", "create_intersection_pcd",
     "project_debug_rays", "load_extrinsics", "ray_tracing",
     "heatmap_to_point3d", "pcd_from_point3d", "calc_coordinates", "align_to_surface",

@@ -260,6 +260,166 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
     avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
+// ------------------------------------------------------------------ normal estimation
+// PointCloud::EstimateNormals with a hybrid search (radius, max_nn): the max_nn nearest points with
+// d^2 < radius^2 in ascending (d^2, index) -- kept sorted in LDS per thread -- give the nine
+// cumulants and the covariance; the normal is the eigenvector of the smallest eigenvalue by the
+// non-iterative solver Open3D uses (FastEigen3x3, after Eberly's robust 3x3 symmetric solver).
+// oracle/cloudops.c states the same arithmetic; acos/cos come from different libms.
+__device__ inline void cross3(const double *a, const double *b, double *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline double dot3(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ void eigenvector0(const double A[9], double e, double *out) {
+    const double r0[3] = {A[0] - e, A[1], A[2]}, r1[3] = {A[1], A[4] - e, A[5]}, r2[3] = {A[2], A[5], A[8] - e};
+    double c01[3], c02[3], c12[3];
+    cross3(r0, r1, c01); cross3(r0, r2, c02); cross3(r1, r2, c12);
+    const double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2_ = dot3(c12, c12);
+    double b[3] = {c01[0], c01[1], c01[2]};
+    double dm = d0;
+    if (d1 > dm) { dm = d1; b[0] = c02[0]; b[1] = c02[1]; b[2] = c02[2]; }
+    if (d2_ > dm) { dm = d2_; b[0] = c12[0]; b[1] = c12[1]; b[2] = c12[2]; }
+    const double s = sqrt(dm);
+    for (int k = 0; k < 3; ++k) out[k] = b[k] / s;
+}
+__device__ void eigenvector1(const double A[9], const double *ev0, double e, double *out) {
+    double U[3], V[3];
+    if (fabs(ev0[0]) > fabs(ev0[1])) {
+        const double inv = 1.0 / sqrt(ev0[0] * ev0[0] + ev0[2] * ev0[2]);
+        U[0] = -ev0[2] * inv; U[1] = 0.0; U[2] = ev0[0] * inv;
+    } else {
+        const double inv = 1.0 / sqrt(ev0[1] * ev0[1] + ev0[2] * ev0[2]);
+        U[0] = 0.0; U[1] = ev0[2] * inv; U[2] = -ev0[1] * inv;
+    }
+    cross3(ev0, U, V);
+    const double AU[3] = {(A[0] * U[0] + A[1] * U[1]) + A[2] * U[2], (A[1] * U[0] + A[4] * U[1]) + A[5] * U[2],
+                          (A[2] * U[0] + A[5] * U[1]) + A[8] * U[2]};
+    const double AV[3] = {(A[0] * V[0] + A[1] * V[1]) + A[2] * V[2], (A[1] * V[0] + A[4] * V[1]) + A[5] * V[2],
+                          (A[2] * V[0] + A[5] * V[1]) + A[8] * V[2]};
+    double m00 = dot3(U, AU) - e, m01 = dot3(U, AV), m11 = dot3(V, AV) - e;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if (fmax(a00, a01) > 0.0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1.0 / sqrt(1.0 + m00 * m00); m00 *= m01; }
+            for (int k = 0; k < 3; ++k) out[k] = m01 * U[k] - m00 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    } else {
+        if (fmax(a11, a01) > 0.0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1.0 / sqrt(1.0 + m11 * m11); m11 *= m01; }
+            for (int k = 0; k < 3; ++k) out[k] = m11 * U[k] - m01 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    }
+}
+__device__ void smallest_eigenvector(const double cov[9], double out[3]) {
+    double A[9];
+    double mx = cov[0];
+    for (int k = 1; k < 9; ++k) if (cov[k] > mx) mx = cov[k];
+    out[0] = out[1] = out[2] = 0.0;
+    if (mx == 0.0) return;
+    for (int k = 0; k < 9; ++k) A[k] = cov[k] / mx;
+    const double norm = (A[1] * A[1] + A[2] * A[2]) + A[5] * A[5];
+    if (norm > 0.0) {
+        const double q = ((A[0] + A[4]) + A[8]) / 3.0;
+        const double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+        const double p = sqrt((((b00 * b00 + b11 * b11) + b22 * b22) + norm * 2.0) / 6.0);
+        const double c00 = b11 * b22 - A[5] * A[5], c01 = A[1] * b22 - A[5] * A[2], c02 = A[1] * A[5] - b11 * A[2];
+        const double det = ((b00 * c00 - A[1] * c01) + A[2] * c02) / ((p * p) * p);
+        double half = det * 0.5;
+        half = half < -1.0 ? -1.0 : (half > 1.0 ? 1.0 : half);
+        const double angle = acos(half) / 3.0;
+        const double beta2 = cos(angle) * 2.0, beta0 = cos(angle + 2.09439510239319549) * 2.0, beta1 = -(beta0 + beta2);
+        const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        double v0[3], v1[3], v2[3];
+        if (half >= 0.0) {
+            eigenvector0(A, e2, v2);
+            if (e2 < e0 && e2 < e1) { out[0] = v2[0]; out[1] = v2[1]; out[2] = v2[2]; return; }
+            eigenvector1(A, v2, e1, v1);
+            if (e1 < e0 && e1 < e2) { out[0] = v1[0]; out[1] = v1[1]; out[2] = v1[2]; return; }
+            cross3(v1, v2, out);
+        } else {
+            eigenvector0(A, e0, v0);
+            if (e0 < e1 && e0 < e2) { out[0] = v0[0]; out[1] = v0[1]; out[2] = v0[2]; return; }
+            eigenvector1(A, v0, e1, v1);
+            if (e1 < e0 && e1 < e2) { out[0] = v1[0]; out[1] = v1[1]; out[2] = v1[2]; return; }
+            cross3(v0, v1, out);
+        }
+    } else {  // diagonal
+        if (A[0] < A[4] && A[0] < A[8]) out[0] = 1.0;
+        else if (A[4] < A[0] && A[4] < A[8]) out[1] = 1.0;
+        else out[2] = 1.0;
+    }
+}
+
+constexpr int NRM_THREADS = 64;
+__global__ __launch_bounds__(NRM_THREADS) void normals_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                              const int *__restrict__ cell_start,
+                                                              const int *__restrict__ cell_end,
+                                                              const int *__restrict__ idx_sorted, double r2, int max_nn,
+                                                              const double *__restrict__ pts /* original order */,
+                                                              const double *__restrict__ prior, double *__restrict__ out) {
+    extern __shared__ double lds[];  // [max_nn][64] squared distances, then [max_nn][64] indices
+    double *top_d = lds;
+    int *top_j = (int *)(lds + (size_t)max_nn * NRM_THREADS);
+    const int t = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * NRM_THREADS + t;
+    if (j >= N) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    int have = 0;
+    for_neighbours(g, p, cell_start, cell_end, [&](int q) {
+        const double d = dist2(p, sp + 3 * (size_t)q);
+        if (!(d < r2)) return;
+        const int jq = idx_sorted[q];
+        int r = have < max_nn ? have : max_nn - 1;
+        if (have == max_nn) {  // full: only a candidate ahead of the current last one enters
+            const double dl = top_d[r * NRM_THREADS + t];
+            if (!(d < dl || (d == dl && jq < top_j[r * NRM_THREADS + t]))) return;
+        }
+        while (r > 0) {
+            const double dp = top_d[(r - 1) * NRM_THREADS + t];
+            const int jp = top_j[(r - 1) * NRM_THREADS + t];
+            if (!(dp > d || (dp == d && jp > jq))) break;
+            top_d[r * NRM_THREADS + t] = dp;
+            top_j[r * NRM_THREADS + t] = jp;
+            --r;
+        }
+        top_d[r * NRM_THREADS + t] = d;
+        top_j[r * NRM_THREADS + t] = jq;
+        if (have < max_nn) ++have;
+    });
+    double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (have >= 3) {
+        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < have; ++q) {
+            const double *x = pts + 3 * (size_t)top_j[q * NRM_THREADS + t];
+            cu[0] += x[0]; cu[1] += x[1]; cu[2] += x[2];
+            cu[3] += x[0] * x[0]; cu[4] += x[0] * x[1]; cu[5] += x[0] * x[2];
+            cu[6] += x[1] * x[1]; cu[7] += x[1] * x[2]; cu[8] += x[2] * x[2];
+        }
+        for (int k = 0; k < 9; ++k) cu[k] /= (double)have;
+        cov[0] = cu[3] - cu[0] * cu[0]; cov[4] = cu[6] - cu[1] * cu[1]; cov[8] = cu[8] - cu[2] * cu[2];
+        cov[1] = cov[3] = cu[4] - cu[0] * cu[1];
+        cov[2] = cov[6] = cu[5] - cu[0] * cu[2];
+        cov[5] = cov[7] = cu[7] - cu[1] * cu[2];
+    }
+    double n[3];
+    smallest_eigenvector(cov, n);
+    const int64_t i = idx_sorted[j];
+    if (sqrt(dot3(n, n)) == 0.0) {
+        if (prior) { n[0] = prior[3 * i]; n[1] = prior[3 * i + 1]; n[2] = prior[3 * i + 2]; }
+        else { n[0] = 0.0; n[1] = 0.0; n[2] = 1.0; }
+    }
+    if (prior && dot3(n, prior + 3 * i) < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    out[3 * i] = n[0]; out[3 * i + 1] = n[1]; out[3 * i + 2] = n[2];
+}
+
 // ------------------------------------------------------------------ plane RANSAC
 __host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -551,6 +711,54 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
                        g, sp, N, cell_start, cell_end, val_s, k, d_avg);
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double radius, int max_nn, const double *prior,
+                          double *normals) {
+    int rc = check_cloud(c, pts, N, "pedp_estimate_normals");
+    if (rc) return rc;
+    PEDP_REQUIRE(radius > 0.0 && std::isfinite(radius), "pedp_estimate_normals: radius must be positive and finite");
+    PEDP_REQUIRE(max_nn >= 1 && max_nn <= 128, "pedp_estimate_normals: max_nn must be in 1..128");
+    if (N == 0) return PEDP_OK;
+    PEDP_REQUIRE(normals, "pedp_estimate_normals: null output");
+    double lo[3], hi[3];
+    bounds(pts, N, lo, hi);
+    Grid g;
+    int64_t n_cells = 0;
+    rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_estimate_normals");
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                           (int *)nullptr, n, 0, 32, c->stream));
+    const size_t need = a256(sizeof(double) * 3 * N) * 4 + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 2 +
+                        a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_prior = cv.take<double>(3 * (size_t)N),
+           *d_out = cv.take<double>(3 * (size_t)N);
+    unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
+    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
+    void *d_tmp = cv.take<char>(tmp_sort);
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    if (prior) PEDP_HIP_CHECK(hipMemcpyAsync(d_prior, prior, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
+    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
+    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((N + NRM_THREADS - 1) / NRM_THREADS)), dim3(NRM_THREADS), lds, c->stream, g,
+                       sp, N, cell_start, cell_end, val_s, radius * radius, max_nn, d_pts, prior ? d_prior : nullptr, d_out);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(normals, d_out, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }

@@ -84,11 +84,27 @@ class PointCloud:
 
         return cloud_ops.cluster_dbscan(self.points, eps, min_points)
 
+    def estimate_normals(self, search_param=None, fast_normal_computation=True):
+        """In place, like Open3D; search_param is a KDTreeSearchParamHybrid (radius, max_nn)."""
+        from . import cloud_ops
+
+        sp = search_param or KDTreeSearchParamHybrid(radius=0.1, max_nn=30)
+        self.normals = cloud_ops.estimate_normals(self.points, sp.radius, sp.max_nn,
+                                                  self.normals if self.has_normals() else None)
+        return self
+
     def remove_statistical_outlier(self, nb_neighbors, std_ratio, print_progress=False):
         from . import cloud_ops
 
         keep = cloud_ops.remove_statistical_outlier(self.points, nb_neighbors, std_ratio)
         return self.select_by_index(keep), [int(i) for i in keep]
+
+
+class KDTreeSearchParamHybrid:
+    """o3d.geometry.KDTreeSearchParamHybrid(radius, max_nn) (src/pose_estimation.py:304-305)."""
+
+    def __init__(self, radius, max_nn):
+        self.radius, self.max_nn = float(radius), int(max_nn)
 
 
 class TriangleMesh:

@@ -20,7 +20,7 @@ import logging
 import numpy as np
 
 from . import registration as reg
-from .geometry import PointCloud, RegistrationResult, clone, normals_of, points_of
+from .geometry import KDTreeSearchParamHybrid, PointCloud, RegistrationResult, clone, normals_of, points_of
 
 
 def transform_object(pcd, transformation):
@@ -36,12 +36,28 @@ def refine_registration(source, target, transformation, param):
                                 transformation, reg.TransformationEstimationPointToPlane())
 
 
+def estimate_normals(pcd, params):
+    """pose_estimation.py:301-306: hybrid search radius 2, at most 5 neighbours (params unused there too)."""
+    pcd.estimate_normals(search_param=KDTreeSearchParamHybrid(radius=2, max_nn=5))
+    return pcd
+
+
+def compute_average_normal(pcd):
+    """pose_estimation.py:314-321: mean normal of the cloud on a 10-unit voxel grid, normalised."""
+    normals = np.asarray(clone(pcd).voxel_down_sample(voxel_size=10).normals)
+    average_normal = np.mean(normals, axis=0)
+    return average_normal / np.linalg.norm(average_normal)
+
+
 def preprocess_target(pcd, param):
     """Subsample the model cloud to `max_pcd` points with the global numpy RNG
-    (np.random.choice(..., replace=False), pose_estimation.py:159-169).  The reference then
-    re-estimates normals and computes FPFH features (:174-179, Open3D KD-tree code, SURVEY s8
-    f2 'next'); here the model's own normals are carried over and the feature slot is None."""
-    cap = param["preprocess_target"]["max_pcd"]
+    (np.random.choice(..., replace=False), pose_estimation.py:159-169), then re-estimate its normals
+    like the reference (:174; radius 2, max_nn 5 -- a model sampled more coarsely than ~1 unit gets
+    (0, 0, 1) everywhere, in Open3D too).  `"keep_normals": True` in the preprocess_target section
+    (not a reference key) keeps the model's own normals instead.  FPFH features (:175-179) are only
+    read by the global-registration path: the slot is None."""
+    section = param["preprocess_target"]
+    cap = section["max_pcd"]
     pts, nrm = points_of(pcd), normals_of(pcd)
     if len(pts) > cap:
         keep = np.random.choice(len(pts), cap, replace=False)
@@ -51,9 +67,11 @@ def preprocess_target(pcd, param):
     else:
         logging.info(f":: Point cloud already has less than or exactly {cap} points.")
         out = pcd
-    if normals_of(out) is None:
-        raise RuntimeError("preprocess_target: the model cloud carries no normals; normal estimation "
-                           "(pose_estimation.py:301-306) belongs to the not-yet-built preprocessing row")
+    if section.get("keep_normals"):
+        if normals_of(out) is None:
+            raise RuntimeError("preprocess_target: keep_normals is set but the model cloud carries no normals")
+    else:
+        estimate_normals(out, section)
     return out, None
 
 
@@ -117,15 +135,9 @@ def preprocess_source(pcd, background, param, i=0):
     The point-cloud operations run on the GPU (pedp_hip.cloud_ops).  Returns (processed, filtered,
     fpfh) with filtered is processed, as in the reference.
 
-    Not built, and what stands in:
-      * normal estimation (:301-306) feeds only compute_average_normal (:314-321), which orients the
-        table plane on the first frame.  estimate_normals(radius=2, max_nn=5) on a voxel grid of a
-        few millimetres finds fewer than three neighbours almost everywhere and Open3D then writes
-        (0, 0, 1); the average normal used here is that (0, 0, 1).  Tracking frames (i > 0) use the
-        reference's (1, 1, 1).
-      * FPFH features (:254-260) are only read by the global-registration path: the slot is None
-        (i == 0) or 0 (i > 0).
-      * param['mesh'] (Poisson re-meshing, :240-245) raises NotImplementedError.
+    Not built: FPFH features (:254-260) are only read by the global-registration path, the slot is
+    None (i == 0) or 0 (i > 0); param['mesh'] (Poisson re-meshing, :240-245) raises
+    NotImplementedError.
     A param dict without a 'preprocess_source' section means "already preprocessed": the cloud is
     passed through (the tracking-frame mutation down_sample = 5 is still applied)."""
     if "preprocess_source" not in param:
@@ -141,7 +153,8 @@ def preprocess_source(pcd, background, param, i=0):
     plane_model, inliers = perform_plane_segmentation(pcd_down, params["plane_removal"])
     average_normal = np.array([1, 1, 1], dtype=float)
     if i == 0:
-        average_normal = np.array([0.0, 0.0, 1.0])
+        estimate_normals(pcd_down, params)
+        average_normal = compute_average_normal(pcd_down)
         logging.info(f":: Average Normal for Source = {average_normal}")
     plane_model, _ = flip_plane_normal_if_needed(plane_model, average_normal)
     source_processed = remove_points_below_plane(pcd_down, plane_model)
@@ -153,6 +166,10 @@ def preprocess_source(pcd, background, param, i=0):
         raise NotImplementedError("preprocess_source: param['mesh'] (Poisson re-meshing) is not part of this build")
     source_processed = filter_largest_cluster(source_processed)
     source_processed = remove_statistical_outliers(source_processed, nb_neighbors=75, std_ratio=0.01)
+    if i == 0:
+        if background is not None:
+            estimate_normals(background, params)
+        estimate_normals(source_processed, params)
     return source_processed, source_processed, (None if i == 0 else 0)
 
 

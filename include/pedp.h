@@ -168,6 +168,13 @@ int pedp_cluster_dbscan(pedp_ctx_t ctx, const double *pts, int64_t N, double eps
  * neighbours (the point itself is one of them), summed in ascending order; the global mean /
  * deviation / threshold over N doubles is host arithmetic (pedp_hip.cloud_ops). */
 int pedp_knn_mean_distance(pedp_ctx_t ctx, const double *pts, int64_t N, int k, double *avg);
+/* estimate_normals with KDTreeSearchParamHybrid(radius, max_nn) (:301-306, callers :174, :216, :250-251):
+ * neighbours = the max_nn nearest points with d^2 < radius^2 (itself included) in ascending
+ * (d^2, index); >= 3 of them give the covariance (nine cumulants) whose smallest eigenvector
+ * (Open3D's non-iterative FastEigen3x3) is the normal, otherwise (0, 0, 1).  prior (nullable,
+ * N x 3): existing normals; the result is flipped to agree with them, as Open3D does. */
+int pedp_estimate_normals(pedp_ctx_t ctx, const double *pts, int64_t N, double radius, int max_nn, const double *prior,
+                          double *normals);
 /* segment_plane with ransac_n = 3 (:323-329).  Iteration t samples three distinct indices from a
  * counter-based generator of (seed, t); plane through them; inliers |n.p + d| < threshold; the best
  * iteration has the most inliers (earliest on ties); all iterations are evaluated (Open3D:

@@ -224,3 +224,154 @@ int64_t pedp_oracle_segment_plane(const double *pts, int64_t N, double threshold
     pedp_oracle_plane_from_points(pts, inliers, n, plane);
     return n;
 }
+
+/* ---- normal estimation, PointCloud::EstimateNormals with KDTreeSearchParamHybrid(radius, max_nn)
+ * (src/pose_estimation.py:301-306): neighbours = the max_nn nearest points with d^2 < radius^2 (the
+ * point itself included), taken in ascending (d^2, index); with >= 3 of them the covariance from
+ * the nine cumulants (utility::ComputeCovariance) and the eigenvector of its smallest eigenvalue by
+ * the non-iterative solver Open3D uses (FastEigen3x3, after Eberly, "A Robust Eigensolver for 3x3
+ * Symmetric Matrices"); otherwise the identity covariance, whose "smallest" eigenvector is (0,0,1).
+ * A zero normal falls back to the prior normal or (0,0,1); with prior normals the result is flipped
+ * to agree with them.  The eigenvector's sign is otherwise whatever the solver yields (Open3D does
+ * not orient it either); point-to-plane ICP does not depend on it. */
+static void cross3(const double *a, const double *b, double *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static void eigenvector0(const double A[9], double e, double *out) {
+    const double r0[3] = {A[0] - e, A[1], A[2]}, r1[3] = {A[1], A[4] - e, A[5]}, r2[3] = {A[2], A[5], A[8] - e};
+    double c01[3], c02[3], c12[3];
+    cross3(r0, r1, c01); cross3(r0, r2, c02); cross3(r1, r2, c12);
+    const double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2_ = dot3(c12, c12);
+    const double *best = c01;
+    double dm = d0;
+    if (d1 > dm) { dm = d1; best = c02; }
+    if (d2_ > dm) { dm = d2_; best = c12; }
+    const double s = sqrt(dm);
+    for (int k = 0; k < 3; ++k) out[k] = best[k] / s;
+}
+static void eigenvector1(const double A[9], const double *ev0, double e, double *out) {
+    double U[3], V[3];
+    if (fabs(ev0[0]) > fabs(ev0[1])) {
+        const double inv = 1.0 / sqrt(ev0[0] * ev0[0] + ev0[2] * ev0[2]);
+        U[0] = -ev0[2] * inv; U[1] = 0.0; U[2] = ev0[0] * inv;
+    } else {
+        const double inv = 1.0 / sqrt(ev0[1] * ev0[1] + ev0[2] * ev0[2]);
+        U[0] = 0.0; U[1] = ev0[2] * inv; U[2] = -ev0[1] * inv;
+    }
+    cross3(ev0, U, V);
+    const double AU[3] = {(A[0] * U[0] + A[1] * U[1]) + A[2] * U[2], (A[1] * U[0] + A[4] * U[1]) + A[5] * U[2],
+                          (A[2] * U[0] + A[5] * U[1]) + A[8] * U[2]};
+    const double AV[3] = {(A[0] * V[0] + A[1] * V[1]) + A[2] * V[2], (A[1] * V[0] + A[4] * V[1]) + A[5] * V[2],
+                          (A[2] * V[0] + A[5] * V[1]) + A[8] * V[2]};
+    double m00 = dot3(U, AU) - e, m01 = dot3(U, AV), m11 = dot3(V, AV) - e;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if (fmax(a00, a01) > 0.0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1.0 / sqrt(1.0 + m00 * m00); m00 *= m01; }
+            for (int k = 0; k < 3; ++k) out[k] = m01 * U[k] - m00 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    } else {
+        if (fmax(a11, a01) > 0.0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1.0 / sqrt(1.0 + m11 * m11); m11 *= m01; }
+            for (int k = 0; k < 3; ++k) out[k] = m11 * U[k] - m01 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    }
+}
+void pedp_oracle_smallest_eigenvector(const double cov[9], double out[3]) {
+    double A[9];
+    double mx = cov[0];
+    for (int k = 1; k < 9; ++k) if (cov[k] > mx) mx = cov[k];
+    out[0] = out[1] = out[2] = 0.0;
+    if (mx == 0.0) return;
+    for (int k = 0; k < 9; ++k) A[k] = cov[k] / mx;
+    const double norm = (A[1] * A[1] + A[2] * A[2]) + A[5] * A[5];
+    if (norm > 0.0) {
+        const double q = ((A[0] + A[4]) + A[8]) / 3.0;
+        const double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+        const double p = sqrt((((b00 * b00 + b11 * b11) + b22 * b22) + norm * 2.0) / 6.0);
+        const double c00 = b11 * b22 - A[5] * A[5], c01 = A[1] * b22 - A[5] * A[2], c02 = A[1] * A[5] - b11 * A[2];
+        const double det = ((b00 * c00 - A[1] * c01) + A[2] * c02) / ((p * p) * p);
+        double half = det * 0.5;
+        half = half < -1.0 ? -1.0 : (half > 1.0 ? 1.0 : half);
+        const double angle = acos(half) / 3.0;
+        const double beta2 = cos(angle) * 2.0, beta0 = cos(angle + 2.09439510239319549) * 2.0, beta1 = -(beta0 + beta2);
+        const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        double v0[3], v1[3], v2[3];
+        if (half >= 0.0) {
+            eigenvector0(A, e2, v2);
+            if (e2 < e0 && e2 < e1) { memcpy(out, v2, sizeof(v2)); return; }
+            eigenvector1(A, v2, e1, v1);
+            if (e1 < e0 && e1 < e2) { memcpy(out, v1, sizeof(v1)); return; }
+            cross3(v1, v2, out);
+        } else {
+            eigenvector0(A, e0, v0);
+            if (e0 < e1 && e0 < e2) { memcpy(out, v0, sizeof(v0)); return; }
+            eigenvector1(A, v0, e1, v1);
+            if (e1 < e0 && e1 < e2) { memcpy(out, v1, sizeof(v1)); return; }
+            cross3(v0, v1, out);
+        }
+    } else { /* diagonal */
+        if (A[0] < A[4] && A[0] < A[8]) out[0] = 1.0;
+        else if (A[4] < A[0] && A[4] < A[8]) out[1] = 1.0;
+        else out[2] = 1.0;
+    }
+}
+
+typedef struct { double d; int64_t j; } cand;
+static int cmp_cand(const void *a, const void *b) {
+    const cand *x = (const cand *)a, *y = (const cand *)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return x->j < y->j ? -1 : (x->j > y->j);
+}
+void pedp_oracle_estimate_normals(const double *pts, int64_t N, double radius, int max_nn, const double *prior,
+                                  double *out) {
+    const double r2 = radius * radius;
+#pragma omp parallel
+    {
+        cand *c = (cand *)malloc(sizeof(cand) * (size_t)(N > 0 ? N : 1));
+#pragma omp for schedule(dynamic, 32)
+        for (int64_t i = 0; i < N; ++i) {
+            int64_t n = 0;
+            for (int64_t j = 0; j < N; ++j) {
+                const double d = d2(pts + 3 * i, pts + 3 * j);
+                if (d < r2) { c[n].d = d; c[n].j = j; ++n; }
+            }
+            qsort(c, (size_t)n, sizeof(cand), cmp_cand);
+            if (n > max_nn) n = max_nn;
+            double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (n >= 3) {
+                double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int64_t q = 0; q < n; ++q) {
+                    const double *p = pts + 3 * c[q].j;
+                    cu[0] += p[0]; cu[1] += p[1]; cu[2] += p[2];
+                    cu[3] += p[0] * p[0]; cu[4] += p[0] * p[1]; cu[5] += p[0] * p[2];
+                    cu[6] += p[1] * p[1]; cu[7] += p[1] * p[2]; cu[8] += p[2] * p[2];
+                }
+                for (int k = 0; k < 9; ++k) cu[k] /= (double)n;
+                cov[0] = cu[3] - cu[0] * cu[0]; cov[4] = cu[6] - cu[1] * cu[1]; cov[8] = cu[8] - cu[2] * cu[2];
+                cov[1] = cov[3] = cu[4] - cu[0] * cu[1];
+                cov[2] = cov[6] = cu[5] - cu[0] * cu[2];
+                cov[5] = cov[7] = cu[7] - cu[1] * cu[2];
+            }
+            double nrm[3];
+            pedp_oracle_smallest_eigenvector(cov, nrm);
+            if (sqrt(dot3(nrm, nrm)) == 0.0) {
+                if (prior) memcpy(nrm, prior + 3 * i, sizeof(nrm));
+                else { nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0; }
+            }
+            if (prior && dot3(nrm, prior + 3 * i) < 0.0)
+                for (int k = 0; k < 3; ++k) nrm[k] = -nrm[k];
+            memcpy(out + 3 * i, nrm, sizeof(nrm));
+        }
+        free(c);
+    }
+}

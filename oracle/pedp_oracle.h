@@ -95,6 +95,9 @@ void pedp_oracle_sample3(uint64_t seed, int64_t t, int64_t N, int64_t out[3]);
 void pedp_oracle_plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]);
 int64_t pedp_oracle_segment_plane(const double *pts, int64_t N, double threshold, int num_iterations, uint64_t seed,
                                   double plane[4], int32_t *inliers);
+void pedp_oracle_smallest_eigenvector(const double cov[9], double out[3]);
+void pedp_oracle_estimate_normals(const double *pts, int64_t N, double radius, int max_nn, const double *prior,
+                                  double *out);
 
 /* depth pre-filters (depth.c): Utils.py:304-442 */
 void pedp_oracle_erode_depth(const float *depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,

@@ -229,6 +229,21 @@ def remove_statistical_outlier(points, nb_neighbors, std_ratio):
     return statistical_outlier_indices(knn_mean_distance(points, nb_neighbors), std_ratio)
 
 
+def estimate_normals(points, radius, max_nn, prior=None):
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    pr = None if prior is None else np.ascontiguousarray(prior, np.float64).reshape(-1, 3)
+    out = np.empty_like(p)
+    lib().pedp_oracle_estimate_normals(_p(p), C.c_int64(len(p)), C.c_double(radius), C.c_int(max_nn), _p(pr), _p(out))
+    return out
+
+
+def smallest_eigenvector(cov):
+    c = np.ascontiguousarray(cov, np.float64).reshape(9)
+    out = np.zeros(3)
+    lib().pedp_oracle_smallest_eigenvector(_p(c), _p(out))
+    return out
+
+
 def segment_plane(points, distance_threshold, num_iterations, seed=0):
     p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
     plane = np.zeros(4)

@@ -232,7 +232,7 @@ def test_refine_pose_with_icp_mutations_and_return_shape(engine):
     from pedp_hip.compat import refine_pose_with_icp
 
     g, src, tgt, T_start = _problem()
-    params = {"preprocess_target": {"max_pcd": 10_000}, "refine_registration": {"distance_threshold": 8.0},
+    params = {"preprocess_target": {"max_pcd": 10_000, "keep_normals": True}, "refine_registration": {"distance_threshold": 8.0},
               "run_icp": {"fitness_threshold": 0.5, "rmse_threshold": 10.0}}
     init = T_start.copy()
     init[2, 3] += 6.0
@@ -264,12 +264,12 @@ def test_preprocess_target_subsamples_with_global_rng():
     np.random.seed(3)
     expect = np.random.choice(100, 10, replace=False)
     np.random.seed(3)
-    out, feat = preprocess_target(pc, {"preprocess_target": {"max_pcd": 10}})
+    out, feat = preprocess_target(pc, {"preprocess_target": {"max_pcd": 10, "keep_normals": True}})
     assert feat is None and np.array_equal(out.points, pts[expect]) and out.has_normals()
-    same, _ = preprocess_target(pc, {"preprocess_target": {"max_pcd": 100}})
+    same, _ = preprocess_target(pc, {"preprocess_target": {"max_pcd": 100, "keep_normals": True}})
     assert same is pc
     with pytest.raises(RuntimeError, match="normals"):
-        preprocess_target(PointCloud(pts), {"preprocess_target": {"max_pcd": 1000}})
+        preprocess_target(PointCloud(pts), {"preprocess_target": {"max_pcd": 1000, "keep_normals": True}})
 
 
 def test_load_extrinsics_and_shard_bounds(tmp_path):

@@ -146,12 +146,18 @@ def test_preprocess_source_flow_matches_oracle_chain(ctx, oracle):
     # the oracle's chain
     down, _ = oracle.voxel_down_sample(scene, 4)
     plane, inl = oracle.segment_plane(down, 2.0, 200, seed=0)
+    # first frame: the average normal (estimate_normals radius 2 / max_nn 5, 10-unit voxel mean) orients the plane
+    nrm = oracle.estimate_normals(down, 2.0, 5)
+    _, coarse = oracle.voxel_down_sample(down, 10, nrm)
+    avg = coarse.mean(axis=0); avg /= np.linalg.norm(avg)
+    assert abs(avg[2]) > 0.9
     rest = np.delete(down, inl, axis=0)                        # remove_plane (box = False)
     labels = oracle.cluster_dbscan(rest, 10, 10)
     ids, counts = np.unique(labels[labels >= 0], return_counts=True)
     big = rest[labels == ids[np.argmax(counts)]]
     ref = big[oracle.remove_statistical_outlier(big, 75, 0.01)]
     assert np.array_equal(out.points, ref) and 200 < len(ref) < len(down)
+    assert out.has_normals() and np.abs(out.normals - oracle.estimate_normals(ref, 2.0, 5)).max() < 1e-9
     assert abs(abs(plane[2]) - 1) < 1e-3                       # the back plane was the segmented plane
     # box = True keeps the half space in front of the plane instead (background_removal returns its input)
     param["box"] = True
@@ -169,3 +175,42 @@ def test_preprocess_source_flow_matches_oracle_chain(ctx, oracle):
     assert np.array_equal(boxed.points, big[oracle.remove_statistical_outlier(big, 75, 0.01)])
     with pytest.raises(NotImplementedError):
         preprocess_source(PointCloud(scene), None, dict(param, mesh=True), i=1)
+
+
+@pytest.mark.parametrize("radius,max_nn", [(2.0, 5), (6.0, 30), (15.0, 100), (0.01, 5)])
+def test_estimate_normals(ctx, oracle, radius, max_nn):
+    from pedp_hip import cloud_ops
+
+    pts, _ = oracle.voxel_down_sample(_scene(seed=13), 1.5)
+    pts = pts[:6000]
+    got = cloud_ops.estimate_normals(pts, radius, max_nn)
+    ref = oracle.estimate_normals(pts, radius, max_nn)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-9
+    if radius >= 6.0:                                            # the table points get the table's normal
+        table = np.abs(pts[:, 2] - 400) < 0.8
+        assert np.mean(np.abs(got[table][:, 2]) > 0.95) > 0.8
+    if radius == 0.01:                                           # nobody has three neighbours: Open3D's default
+        assert np.array_equal(got, np.tile([0.0, 0.0, 1.0], (len(pts), 1)))
+    # existing normals fix the orientation
+    prior = np.tile([0.0, 0.0, -1.0], (len(pts), 1))
+    flipped = cloud_ops.estimate_normals(pts, radius, max_nn, prior)
+    assert np.abs(flipped - oracle.estimate_normals(pts, radius, max_nn, prior)).max() < 1e-9
+    assert np.all((flipped * prior).sum(axis=1) >= 0)
+
+
+def test_preprocess_target_estimates_normals_like_the_reference(ctx, oracle):
+    """preprocess_target re-estimates the model's normals (pose_estimation.py:174) unless told to keep
+    them; on a dense model they agree with the analytic normals up to sign."""
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, preprocess_target
+
+    verts, tris, normals = synth.bumpy_torus(700, 300)           # 210,000 vertices, spacing ~0.5 mm
+    sel = np.random.default_rng(0).choice(len(verts), 60000, replace=False)
+    pts = verts[sel].astype(np.float64)
+    out, feat = preprocess_target(PointCloud(pts), {"preprocess_target": {"max_pcd": 100000}})
+    assert feat is None and out.has_normals()
+    est = np.asarray(out.normals)
+    cosang = np.abs((est * normals[sel]).sum(axis=1))
+    assert np.mean(cosang > 0.9) > 0.9
+    kept, _ = preprocess_target(PointCloud(pts, normals=normals[sel]), {"preprocess_target": {"max_pcd": 100000, "keep_normals": True}})
+    assert np.array_equal(kept.normals, normals[sel])

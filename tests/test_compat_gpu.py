@@ -113,7 +113,7 @@ def test_refine_pose_with_icp_full_flow(oracle):
     hit = np.isfinite(depth)
     scene = synth.scene_from_depth(depth[hit], f.dirs[hit], noise_sigma=0.2)
     src, tgt = PointCloud(scene), PointCloud(f.model_points, normals=f.normals)
-    params = {"preprocess_target": {"max_pcd": 100000}, "refine_registration": {"distance_threshold": 6.0},
+    params = {"preprocess_target": {"max_pcd": 100000, "keep_normals": True}, "refine_registration": {"distance_threshold": 6.0},
               "run_icp": {"fitness_threshold": 0.98, "rmse_threshold": 1.0}}
     init = synth.start_pose()
     init[2, 3] += 4.0
@@ -145,7 +145,7 @@ def test_refine_pose_with_icp_from_raw_frame(oracle):
     depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
     scene = f.scene(depth)                                      # 0.5 mm noise, misses on the z = 600 plane
     src, tgt = PointCloud(scene), PointCloud(f.model_points, normals=f.normals)
-    params = {"preprocess_target": {"max_pcd": 100000},
+    params = {"preprocess_target": {"max_pcd": 100000, "keep_normals": True},
               "preprocess_source": {"down_sample": 2, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 300}},
               "box": False, "mesh": False,
               "refine_registration": {"distance_threshold": 6.0}, "run_icp": {"fitness_threshold": 0.97, "rmse_threshold": 3.5}}
