@@ -114,7 +114,30 @@ def main():
                         best_T=res.transformation, best_fitness=res.fitness, best_rmse=res.inlier_rmse,
                         rng_after=np.random.uniform())
     g7()
+    g8()
     print("golden fixtures written to", HERE)
+
+
+def g8_cloud(seed=0):
+    """A table plane, an object blob, a small far blob and scattered outliers (mm), shuffled."""
+    rng = np.random.default_rng(seed)
+    plane = np.column_stack([rng.uniform(-60, 60, 900), rng.uniform(-40, 40, 900), 400 + rng.normal(0, 0.3, 900)])
+    obj = rng.normal([5, -3, 370], [9, 7, 5], (500, 3))
+    small = rng.normal([50, 30, 385], 2, (60, 3))
+    noise = rng.uniform([-80, -60, 300], [80, 60, 430], (40, 3))
+    pts = np.vstack([plane, obj, small, noise])
+    return pts[rng.permutation(len(pts))]
+
+
+def g8():
+    """G8: point-cloud operations of preprocess_source on a 1,500-point cloud."""
+    pts = g8_cloud()
+    down, _ = oracle.voxel_down_sample(pts, 3.0)
+    plane, inl = oracle.segment_plane(pts, 1.0, 100, seed=7)
+    np.savez_compressed(os.path.join(HERE, "g8_cloud_ops.npz"), points=pts, voxel3=down,
+                        dbscan_6_8=oracle.cluster_dbscan(pts, 6.0, 8), knn20=oracle.knn_mean_distance(pts, 20),
+                        sor_20_1=oracle.remove_statistical_outlier(pts, 20, 1.0), plane=plane, plane_inliers=inl,
+                        normals_8_12=oracle.estimate_normals(pts, 8.0, 12))
 
 
 def g7():

@@ -214,3 +214,19 @@ def test_preprocess_target_estimates_normals_like_the_reference(ctx, oracle):
     assert np.mean(cosang > 0.9) > 0.9
     kept, _ = preprocess_target(PointCloud(pts, normals=normals[sel]), {"preprocess_target": {"max_pcd": 100000, "keep_normals": True}})
     assert np.array_equal(kept.normals, normals[sel])
+
+
+def test_golden_g8(ctx):
+    """The committed fixture (tests/golden/g8_cloud_ops.npz, generated by the oracle)."""
+    import os
+    from pedp_hip import cloud_ops
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_cloud_ops.npz"))
+    pts = g["points"]
+    assert np.array_equal(cloud_ops.voxel_down_sample(pts, 3.0)[0], g["voxel3"])
+    assert np.array_equal(cloud_ops.cluster_dbscan(pts, 6.0, 8), g["dbscan_6_8"])
+    assert np.array_equal(cloud_ops.knn_mean_distance(pts, 20), g["knn20"])
+    assert np.array_equal(cloud_ops.remove_statistical_outlier(pts, 20, 1.0), g["sor_20_1"])
+    plane, inl = cloud_ops.segment_plane(pts, 1.0, 3, 100, seed=7)
+    assert np.array_equal(inl, g["plane_inliers"]) and np.abs(plane - g["plane"]).max() < 1e-12
+    assert np.abs(cloud_ops.estimate_normals(pts, 8.0, 12) - g["normals_8_12"]).max() < 1e-9

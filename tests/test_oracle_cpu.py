@@ -367,3 +367,51 @@ def test_depth_filters_golden_and_python_restatement(oracle):
     pts = np.stack(((us - K[0, 2]) * dd / K[0, 0], (vs - K[1, 2]) * dd / K[1, 1], dd), -1).astype(np.float32)
     pts[dd < 0.001] = 0
     assert same(oracle.depth2xyzmap(dd, K), pts)
+
+
+# ------------------------------------------------------------------ point-cloud operations (G8)
+def test_cloud_ops_golden_and_independent_statements(oracle):
+    g = np.load(os.path.join(GOLD, "g8_cloud_ops.npz"))
+    pts = g["points"]
+    # golden
+    assert np.array_equal(oracle.voxel_down_sample(pts, 3.0)[0], g["voxel3"])
+    assert np.array_equal(oracle.cluster_dbscan(pts, 6.0, 8), g["dbscan_6_8"])
+    assert np.array_equal(oracle.knn_mean_distance(pts, 20), g["knn20"])
+    assert np.array_equal(oracle.remove_statistical_outlier(pts, 20, 1.0), g["sor_20_1"])
+    plane, inl = oracle.segment_plane(pts, 1.0, 100, seed=7)
+    assert np.array_equal(plane, g["plane"]) and np.array_equal(inl, g["plane_inliers"])
+    assert np.abs(oracle.estimate_normals(pts, 8.0, 12) - g["normals_8_12"]).max() < 1e-12
+    # voxel grid: numpy statement (group by floor((p - (min - v/2)) / v), mean per group, lexicographic order)
+    v = 3.0
+    idx = np.floor((pts - (pts.min(axis=0) - v * 0.5)) / v).astype(np.int64)
+    keys, inv = np.unique(idx, axis=0, return_inverse=True)
+    mean = np.stack([np.bincount(inv.ravel(), pts[:, k]) for k in range(3)], 1) / np.bincount(inv.ravel())[:, None]
+    assert g["voxel3"].shape == mean.shape and np.abs(g["voxel3"] - mean).max() < 1e-10
+    # kNN mean distance: scipy's KD-tree (the point itself is its own first neighbour)
+    d, _ = cKDTree(pts).query(pts, k=20)
+    assert np.abs(d.mean(axis=1) - g["knn20"]).max() < 1e-10
+    # DBSCAN: scikit-learn agrees on the noise set and on the partition of the core points
+    sk = pytest.importorskip("sklearn.cluster")
+    eps = 6.0
+    model = sk.DBSCAN(eps=np.nextafter(eps, 0), min_samples=8).fit(pts)     # sklearn: d <= eps, Open3D: d < eps
+    lab = g["dbscan_6_8"]
+    core = np.zeros(len(pts), bool)
+    core[model.core_sample_indices_] = True
+    assert np.array_equal(lab == -1, model.labels_ == -1)
+    pairs = set(zip(lab[core].tolist(), model.labels_[core].tolist()))
+    assert len(pairs) == len(set(a for a, _ in pairs)) == len(set(b for _, b in pairs))   # one-to-one relabelling
+    # plane: the table (z = 400), the inliers are those of a plane through three sampled points
+    assert abs(abs(plane[2]) - 1) < 1e-3 and abs(abs(plane[3]) - 400) < 0.5 and len(inl) > 800
+    assert len(set(oracle.sample3(7, 5, 1500))) == 3
+    # normals: PCA over the same neighbourhoods with numpy's symmetric eigen solver
+    tree = cKDTree(pts)
+    est = g["normals_8_12"]
+    for i in range(0, len(pts), 37):
+        dd, jj = tree.query(pts[i], k=12, distance_upper_bound=8.0)
+        jj = jj[np.isfinite(dd)]
+        if len(jj) < 3:
+            assert np.array_equal(est[i], [0, 0, 1])
+            continue
+        w, V = np.linalg.eigh(np.cov(pts[jj].T, bias=True))
+        if w[1] - w[0] > 1e-6 * w[2]:
+            assert abs(abs(est[i] @ V[:, 0]) - 1) < 1e-6
