@@ -33,44 +33,74 @@ __device__ __forceinline__ float erode_finish(float d_ori, float bad, float tota
     return (bad / total > ratio) ? 0.0f : d_ori;
 }
 
+// The window test per neighbour is "invalid, or farther than depth_diff_thres from the centre".
+// Staged values carry the validity: an invalid reading is staged as +inf and a pixel outside the
+// image as NaN, so for a finite centre d the test is the single comparison |v - d| > thres
+// (+inf: always true; NaN: never, like the reference's comparisons on a NaN reading), and the
+// window size is the closed-form count of in-image pixels.  Centres that are NaN or infinite --
+// where |v - d| is NaN -- count by class instead: a NaN centre makes exactly the invalid readings
+// bad, an infinite centre everything that is not NaN.
 template <int R>
 __global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ depth, float *__restrict__ out, StencilArgs p) {
     constexpr int TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
     __shared__ float tile[TH][TW];
     const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW, gy = y0 + ty - R, gx = x0 + tx - R;
-        tile[ty][tx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? depth[(size_t)gy * p.W + gx] : 0.0f;
+        float v = nan;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+            v = depth[(size_t)gy * p.W + gx];
+            v = (v < 0.001f || v >= p.zfar) ? inf : v;
+        }
+        tile[ty][tx] = v;
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int x = x0 + lx, ys = y0 + ly * STRIP;
     if (x >= p.W) return;
-    float d_ori[STRIP], bad[STRIP], total[STRIP];
+    float d_ori[STRIP];
+    int bad[STRIP];
+    int cls[STRIP];  // 0 finite centre, 1 NaN, 2 infinite
 #pragma unroll
-    for (int j = 0; j < STRIP; ++j) { d_ori[j] = tile[ly * STRIP + j + R][lx + R]; bad[j] = 0.f; total[j] = 0.f; }
+    for (int j = 0; j < STRIP; ++j) {
+        d_ori[j] = (ys + j < p.H) ? depth[(size_t)(ys + j) * p.W + x] : 0.0f;
+        bad[j] = 0;
+        cls[j] = (d_ori[j] != d_ori[j]) ? 1 : (fabsf(d_ori[j]) == inf ? 2 : 0);
+    }
+    const int cols = min(x + R, p.W - 1) - max(x - R, 0) + 1;
 #pragma unroll
     for (int du = -R; du <= R; ++du) {
-        const int u = x + du;
-        if (u < 0 || u >= p.W) continue;
         float col[STRIP + 2 * R];
 #pragma unroll
-        for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
+        for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];  // NaN outside the image
 #pragma unroll
         for (int j = 0; j < STRIP; ++j) {
 #pragma unroll
-            for (int dv = -R; dv <= R; ++dv) {
-                const int v = ys + j + dv;
-                if (v < 0 || v >= p.H) continue;
-                const float cur = col[j + dv + R];
-                total[j] += 1.0f;
-                if (cur < 0.001f || cur >= p.zfar || fabsf(cur - d_ori[j]) > p.a) bad[j] += 1.0f;
-            }
+            for (int dv = -R; dv <= R; ++dv) bad[j] += (fabsf(col[j + dv + R] - d_ori[j]) > p.a) ? 1 : 0;
+        }
+    }
+    // NaN / infinite centres (rare; the branch is taken by a wave only if one of its lanes has one)
+    if (cls[0] | cls[1] | cls[2] | cls[3]) {
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+            if (cls[j] == 0) continue;
+            int b = 0;
+            for (int du = -R; du <= R; ++du)
+                for (int dv = -R; dv <= R; ++dv) {
+                    const float v = tile[ly * STRIP + j + dv + R][lx + du + R];
+                    b += (cls[j] == 1) ? (v == inf) : (v == v);
+                }
+            bad[j] = b;
         }
     }
 #pragma unroll
-    for (int j = 0; j < STRIP; ++j)
-        if (ys + j < p.H) out[(size_t)(ys + j) * p.W + x] = erode_finish(d_ori[j], bad[j], total[j], p.b);
+    for (int j = 0; j < STRIP; ++j) {
+        const int y = ys + j;
+        if (y >= p.H) continue;
+        const int rows = min(y + R, p.H - 1) - max(y - R, 0) + 1;
+        out[(size_t)y * p.W + x] = erode_finish(d_ori[j], (float)bad[j], (float)(rows * cols), p.b);
+    }
 }
 
 // any radius: one thread per pixel straight from global memory (the caches carry the reuse)

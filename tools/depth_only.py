@@ -8,7 +8,9 @@ import torch
 from pedp_hip import _lib, compat, synth
 
 dev = torch.device("cuda:0")
-ctx = _lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+stream = torch.cuda.Stream(device=dev)          # one explicit stream shared by torch and the library:
+ctx = _lib.Context(0, stream=stream.cuda_stream)  # the calls below only enqueue, no host synchronisation
+torch.cuda.set_stream(stream)
 K = np.array([[504.0, 0, 319.5], [0, 504.0, 287.5], [0, 0, 1]])
 for (h, w) in [(576, 640), (720, 1280), (8192, 8192)]:
     base = synth.depth_image(576, 640, seed=0, nan=False)
