@@ -1243,10 +1243,14 @@ int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl, const double *roi) {
         if (!moved) return PEDP_OK;
     } else {
         PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
+        for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = 0.0; cl->perm_hi[k] = -1.0; }  // no region yet: every request rebuilds
     }
-    for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = lo[k]; cl->perm_hi[k] = hi[k]; }
-    unsigned *hist = nullptr;
-    PEDP_HIP_CHECK(hipMalloc((void **)&hist, sizeof(unsigned) * (SORT_CELLS + 1)));
+    struct HistGuard {  // freed on every exit path
+        unsigned *p = nullptr;
+        ~HistGuard() { if (p) (void)hipFree(p); }
+    } guard;
+    PEDP_HIP_CHECK(hipMalloc((void **)&guard.p, sizeof(unsigned) * (SORT_CELLS + 1)));
+    unsigned *hist = guard.p;
     PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (SORT_CELLS + 1), c->stream));
     double sc[3];
     for (int k = 0; k < 3; ++k) {
@@ -1261,7 +1265,7 @@ int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl, const double *roi) {
                        sc[0], sc[1], sc[2], hist, (int32_t *)cl->perm);
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    PEDP_HIP_CHECK(hipFree(hist));
+    for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = lo[k]; cl->perm_hi[k] = hi[k]; }  // valid only now
     return PEDP_OK;
 }
 
@@ -1293,9 +1297,21 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     if (rc) return rc;
     // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
-    PEDP_HIP_CHECK(hipMalloc(&tgt->tgt4, sizeof(float4) * (size_t)pad));
-    PEDP_HIP_CHECK(hipMalloc(&tgt->tile_sph, sizeof(float4) * (size_t)(pad / 16)));
-    PEDP_HIP_CHECK(hipMalloc(&tgt->tile_sph4, sizeof(float4) * (size_t)(pad / 64)));
+    // all three or none: a half-built pack must not look finished to the next call
+    void *t4 = nullptr, *s1 = nullptr, *s4 = nullptr;
+    hipError_t e = hipMalloc(&t4, sizeof(float4) * (size_t)pad);
+    if (e == hipSuccess) e = hipMalloc(&s1, sizeof(float4) * (size_t)(pad / 16));
+    if (e == hipSuccess) e = hipMalloc(&s4, sizeof(float4) * (size_t)(pad / 64));
+    if (e != hipSuccess) {
+        if (t4) (void)hipFree(t4);
+        if (s1) (void)hipFree(s1);
+        if (s4) (void)hipFree(s4);
+        pedp_set_error("pedp_icp: target pack allocation failed: %s", hipGetErrorString(e));
+        return PEDP_ERR_ALLOC;
+    }
+    tgt->tgt4 = t4;
+    tgt->tile_sph = s1;
+    tgt->tile_sph4 = s4;
     tgt->tgt4_pad = pad;
     int64_t grid = (pad + 255) / 256;
     hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
