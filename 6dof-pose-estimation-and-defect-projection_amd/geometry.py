@@ -77,7 +77,7 @@ class PointCloud:
         from . import cloud_ops
 
         plane, inliers = cloud_ops.segment_plane(self.points, distance_threshold, ransac_n, num_iterations)
-        return plane, [int(i) for i in inliers]
+        return plane, inliers  # int32 array (Open3D: list of int); select_by_index takes either
 
     def cluster_dbscan(self, eps, min_points, print_progress=False):
         from . import cloud_ops
@@ -97,7 +97,7 @@ class PointCloud:
         from . import cloud_ops
 
         keep = cloud_ops.remove_statistical_outlier(self.points, nb_neighbors, std_ratio)
-        return self.select_by_index(keep), [int(i) for i in keep]
+        return self.select_by_index(keep), keep
 
 
 class KDTreeSearchParamHybrid:
