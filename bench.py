@@ -155,6 +155,13 @@ def main():
         cast()
         brute_ms.append(_lib.raycast_last_sweep_ms(ctx))
     _lib.raycast_configure(ctx, 0, 0)
+    # (c) BASELINE config 3 in small: 32 start poses refined concurrently (pedp_icp_batched)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(32)])
+    batch_s = []
+    for _ in range(3):
+        tb = time.perf_counter()
+        _lib.icp_batched(ctx, src, tgt, frame.max_correspondence_distance, inits, max_iteration=ICP_ITERS)
+        batch_s.append(time.perf_counter() - tb)
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
@@ -188,6 +195,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), all-gather of hit records"},
             "ray_stage_ms": ray_stage, "ray_stage_mrays_per_s": n_rays / (ray_stage * 1e-3) / 1e6,
             "icp_ms": icp_mean, "icp_iters_per_s": ICP_ITERS / (icp_mean * 1e-3),
+            "icp_batched_ms_per_registration": 1e3 * min(batch_s) / len(inits),
+            "icp_batched_iters_per_s": ICP_ITERS * len(inits) / min(batch_s),
             "icp_passes": passes, "icp_pairs_swept_per_pass": pairs_swept / max(passes, 1),
             "icp_fallback_points_per_pass": fb_points / max(passes, 1),
             "icp_fitness": res["fitness"], "icp_inlier_rmse": res["inlier_rmse"],
