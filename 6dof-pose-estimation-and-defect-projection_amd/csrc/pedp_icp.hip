@@ -436,8 +436,11 @@ __global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__
         const int c = blk_cnt[b];
         blk_cnt[b] = 0;  // ready for the next pass
         blk_segstart[b] = at;
-        for (int r0 = 0; r0 < c; r0 += seg_len) {
-            if (at < max_segs) { seg_blk[at] = b; seg_rank0[at] = r0; seg_n[at] = (c - r0 < seg_len) ? c - r0 : seg_len; }
+        // the block's pieces are made equally long (a 782-unit list is cut 392 + 390, not 424 + 358)
+        const int pieces = (c + seg_len - 1) / seg_len;
+        const int piece = pieces > 0 ? ((c + pieces - 1) / pieces + NN_TU - 1) / NN_TU * NN_TU : seg_len;
+        for (int r0 = 0, k = 0; k < pieces; r0 += piece, ++k) {
+            if (at < max_segs) { seg_blk[at] = b; seg_rank0[at] = r0; seg_n[at] = (c - r0 < piece) ? c - r0 : piece; }
             ++at;
         }
     }
