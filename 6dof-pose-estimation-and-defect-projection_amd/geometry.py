@@ -208,3 +208,13 @@ def normals_of(obj):
 
 def clone(obj):
     return copy.deepcopy(obj)
+
+
+def as_holder(obj):
+    """The object itself if it is our PointCloud, otherwise a PointCloud holding its points / normals /
+    colours (an Open3D cloud handed to the preprocessing chain would otherwise run Open3D's own CPU
+    methods of the same names)."""
+    if obj is None or isinstance(obj, PointCloud):
+        return obj
+    colors = np.asarray(obj.colors) if hasattr(obj, "has_colors") and obj.has_colors() else None
+    return PointCloud(points_of(obj), normals_of(obj), colors)

@@ -20,7 +20,8 @@ import logging
 import numpy as np
 
 from . import registration as reg
-from .geometry import KDTreeSearchParamHybrid, PointCloud, RegistrationResult, clone, normals_of, points_of
+from .geometry import (KDTreeSearchParamHybrid, PointCloud, RegistrationResult, as_holder, clone, normals_of,
+                       points_of)
 
 
 def transform_object(pcd, transformation):
@@ -71,7 +72,17 @@ def preprocess_target(pcd, param):
         if normals_of(out) is None:
             raise RuntimeError("preprocess_target: keep_normals is set but the model cloud carries no normals")
     else:
-        estimate_normals(out, section)
+        if not isinstance(out, PointCloud):  # an Open3D cloud: estimate on the GPU and write the normals back
+            holder = as_holder(out)
+            estimate_normals(holder, section)
+            try:
+                import open3d as o3d  # only reachable when the caller works with Open3D objects
+
+                out.normals = o3d.utility.Vector3dVector(holder.normals)
+            except ImportError:
+                out = holder
+        else:
+            estimate_normals(out, section)
     return out, None
 
 
@@ -147,6 +158,7 @@ def preprocess_source(pcd, background, param, i=0):
     params = param["preprocess_source"]
     if i > 0:
         params["down_sample"] = 5
+    pcd, background = as_holder(pcd), as_holder(background)  # Open3D inputs: the GPU methods, not Open3D's
     if background is not None:
         background = background.voxel_down_sample(voxel_size=params["down_sample"] * 2)
     pcd_down = pcd.voxel_down_sample(voxel_size=params["down_sample"])

@@ -230,3 +230,33 @@ def test_golden_g8(ctx):
     plane, inl = cloud_ops.segment_plane(pts, 1.0, 3, 100, seed=7)
     assert np.array_equal(inl, g["plane_inliers"]) and np.abs(plane - g["plane"]).max() < 1e-12
     assert np.abs(cloud_ops.estimate_normals(pts, 8.0, 12) - g["normals_8_12"]).max() < 1e-9
+
+
+def test_foreign_cloud_objects_take_the_gpu_methods(ctx, oracle):
+    """An Open3D-style cloud (own CPU methods of the same names) handed to preprocess_source is
+    wrapped, so the chain runs on the GPU methods and gives the holder's result."""
+    from pedp_hip import synth
+    from pedp_hip.compat import PointCloud, preprocess_source
+
+    class Foreign:  # stands for o3d.geometry.PointCloud: same attribute surface, methods must not be called
+        def __init__(self, pts):
+            self.points = pts
+            self.normals = np.zeros((0, 3))
+
+        def has_normals(self):
+            return False
+
+        def has_colors(self):
+            return False
+
+        def voxel_down_sample(self, voxel_size):
+            raise AssertionError("the foreign object's CPU method was called")
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    param = {"preprocess_source": {"down_sample": 4, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 200}},
+             "box": False, "mesh": False}
+    a, _, _ = preprocess_source(Foreign(scene), None, param, i=0)
+    b, _, _ = preprocess_source(PointCloud(scene), None, param, i=0)
+    assert isinstance(a, PointCloud) and np.array_equal(a.points, b.points)
