@@ -1120,7 +1120,12 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     // block) keeps a piece within the LDS list of one wave
     const int64_t list_units = NN_LIST_TILES / qt;
     int64_t ms = (w.blocks_cap * n_tiles + list_units - 1) / list_units + w.blocks_cap;
-    if (ms < 8192) ms = 8192;
+    // room for shortest-length (SEG_MIN) pieces up to 8192 of them: the table bounds the sweep's
+    // grid, so a small scene (a few blocks) gets a small grid instead of thousands of idle workgroups
+    const int64_t seg_min_units = SEG_MIN_TILES / qt;
+    int64_t fine = (w.blocks_cap * n_tiles + seg_min_units - 1) / seg_min_units + w.blocks_cap;
+    if (fine > 8192) fine = 8192;
+    if (ms < fine) ms = fine;
     PEDP_REQUIRE(ms < (int64_t)1 << 22, "pedp_icp: problem too large for the segment table (%lld x %lld points)",
                  (long long)Ns, (long long)Nt);
     w.max_segs = (int)ms;
@@ -1200,6 +1205,11 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     const float r2f = (float)(r * r) * 1.00001f;
     const unsigned sel_grid = (unsigned)((4 * w.Ns_pad + 255) / 256);
     const unsigned sweep_grid = (unsigned)((w.max_segs + NN_WAVES - 1) / NN_WAVES);
+    // ambiguous slots are a small fraction of the scene: one workgroup per 8 slots at most, two per CU at most
+    int64_t fbg = w.Ns_pad / 8;
+    if (fbg > 2 * c->num_cus) fbg = 2 * c->num_cus;
+    if (fbg < 1) fbg = 1;
+    const unsigned fb_grid = (unsigned)fbg;
     {
         const int64_t groups = (w.n_words + CULL_WORDS - 1) / CULL_WORDS;
         const int64_t waves = w.blocks_cap * groups;
@@ -1217,7 +1227,7 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
         hipLaunchKernelGGL(nn_select_kernel<QTV>, dim3(sel_grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,       \
                            w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx,   \
                            w.d2, w.fb);                                                                               \
-        hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(2 * c->num_cus), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,     \
+        hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(fb_grid), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,     \
                            w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);       \
     } while (0)
     if (w.qt == 4) PEDP_NN_STAGE(4, 2);
