@@ -155,3 +155,73 @@ def test_align_to_surface_matches_oracle_nn(ctx, oracle):
     assert e_off.size == 0 and e_al.size == 0
     with pytest.raises(RuntimeError, match="normals"):
         compat.align_to_surface(defects, compat.PointCloud(f.model_points))
+
+
+def test_project_heatmap_device_memory(ctx, oracle):
+    """PEDP_DEVICE mode: heat map and outputs are device pointers (torch tensors); only the two
+    counts come back to the host."""
+    import ctypes as C
+    import torch
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    hm = _heatmap(f.height, f.width, 17)
+    ref = oracle.project_heatmap(f.verts_posed, f.tris, hm, f.K, 0.4)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    d_hm = torch.from_numpy(hm).cuda()
+    cap = hm.size
+    d_pts = torch.empty((cap, 3), dtype=torch.float64, device="cuda")
+    d_int = torch.empty(cap, dtype=torch.float64, device="cuda")
+    d_pix = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
+    d_prim = torch.empty(cap, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    cam = _lib.Pinhole(f.K[0, 0], f.K[1, 1], f.K[0, 2], f.K[1, 2], f.width, f.height)
+    org = np.zeros(3)
+    nr, nh = C.c_int64(), C.c_int64()
+    rc = _lib.load().pedp_project_heatmap(ctx._h, mesh._h, C.byref(cam), C.c_void_p(d_hm.data_ptr()), 0.4, _lib._ptr(org),
+                                          _lib.DEVICE, cap, C.c_void_p(d_pts.data_ptr()), C.c_void_p(d_int.data_ptr()),
+                                          C.c_void_p(d_pix.data_ptr()), C.c_void_p(d_prim.data_ptr()), C.byref(nr), C.byref(nh))
+    assert rc == 0, _lib.load().pedp_last_error()
+    ctx.synchronize()
+    m = nh.value
+    assert nr.value == ref["n_rays"] and m == len(ref["points"])
+    assert np.array_equal(d_pix[:m].cpu().numpy(), ref["pixels"])
+    assert np.array_equal(d_prim[:m].cpu().numpy().view(np.uint32), ref["primitive_ids"])
+    assert np.array_equal(d_int[:m].cpu().numpy(), ref["intensities"])
+    assert np.abs(d_pts[:m].cpu().numpy() - ref["points"]).max() < POINT_TOL
+
+
+def test_new_entry_points_reject_bad_arguments(ctx):
+    """Status codes and messages of the entry points added beside the hot path."""
+    import ctypes as C
+    from pedp_hip import _lib, synth
+
+    lib = _lib.load()
+    f = synth.Frame("tiny")
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    err = lambda: lib.pedp_last_error().decode()  # noqa: E731
+    # set_pose on a fixed mesh, bad mem flag, negative capacity
+    assert lib.pedp_mesh_set_pose(mesh._h, None) == -1 and "posable" in err()
+    cam = _lib.Pinhole(100.0, 100.0, 10.0, 10.0, 20, 20)
+    hm = np.ones((20, 20)); org = np.zeros(3); nr, nh = C.c_int64(), C.c_int64()
+    args = lambda mem, cap: (ctx._h, mesh._h, C.byref(cam), _lib._ptr(hm), 0.5, _lib._ptr(org), mem, cap, None, None, None, None,  # noqa: E731
+                             C.byref(nr), C.byref(nh))
+    assert lib.pedp_project_heatmap(*args(7, 10)) == -1 and "mem flag" in err()
+    assert lib.pedp_project_heatmap(*args(_lib.HOST, -1)) == -1 and "capacity" in err()
+    cam0 = _lib.Pinhole(0.0, 100.0, 10.0, 10.0, 20, 20)
+    assert lib.pedp_project_heatmap(ctx._h, mesh._h, C.byref(cam0), _lib._ptr(hm), 0.5, _lib._ptr(org), _lib.HOST, 400, None,
+                                    None, None, None, C.byref(nr), C.byref(nh)) == -1 and "focal" in err()
+    # depth filters: radius, null image, bad mem
+    d = np.ones((4, 4), np.float32); out = np.empty_like(d)
+    assert lib.pedp_erode_depth(ctx._h, _lib._ptr(d), 4, 4, 65, 0.001, 0.8, 100.0, _lib.HOST, _lib._ptr(out)) == -1 and "radius" in err()
+    assert lib.pedp_erode_depth(ctx._h, None, 4, 4, 2, 0.001, 0.8, 100.0, _lib.HOST, _lib._ptr(out)) == -1 and "null" in err()
+    assert lib.pedp_bilateral_filter_depth(ctx._h, _lib._ptr(d), 4, 4, 2, 100.0, 2.0, 1e5, 3, _lib._ptr(out)) == -1
+    assert lib.pedp_depth2xyzmap(ctx._h, _lib._ptr(d), 4, 4, None, _lib.HOST, _lib._ptr(out)) == -1 and "intrinsics" in err()
+    # cloud operations
+    p = np.zeros((5, 3)); lab = np.empty(5, np.int32); avg = np.empty(5)
+    assert lib.pedp_cluster_dbscan(ctx._h, _lib._ptr(p), 5, 0.0, 3, _lib._ptr(lab)) == -1 and "eps" in err()
+    assert lib.pedp_knn_mean_distance(ctx._h, _lib._ptr(p), 5, 0, _lib._ptr(avg)) == -1
+    assert lib.pedp_estimate_normals(ctx._h, _lib._ptr(p), 5, -1.0, 5, None, _lib._ptr(p)) == -1 and "radius" in err()
+    assert lib.pedp_estimate_normals(ctx._h, _lib._ptr(p), 5, 1.0, 500, None, _lib._ptr(p)) == -1 and "max_nn" in err()
+    bad = p.copy(); bad[2, 1] = np.inf
+    assert lib.pedp_cluster_dbscan(ctx._h, _lib._ptr(bad), 5, 1.0, 3, _lib._ptr(lab)) == -1 and "non-finite" in err()
