@@ -75,8 +75,8 @@ class OracleBackend:
             P = o.transform(U, P) if len(pts) else P
 
 
-def main(rank, world, port, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+def main(rank, world, port, out_dir, hip=False):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0" if hip else str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import torch.distributed as dist
     from pedp_hip import dist as pdist
@@ -84,7 +84,9 @@ def main(rank, world, port, out_dir):
 
     r, w, _ = pdist.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    be = OracleBackend()
+    # hip: the PRODUCT backend, both ranks on GPU 0 (gloo moves the CUDA tensors; RCCL refuses two
+    # ranks on one device) -- the multi-rank protocol on real kernels and streams
+    be = pdist.HipBackend(0) if hip else OracleBackend()
     f = synth.Frame("tiny")
     rays = f.rays6[: 48 * 40 - 3]                       # ragged: 1917 rays over 2 ranks
     t_all, id_all = pdist.sharded_cast_rays(be, f.verts_posed, f.tris, rays)
@@ -98,4 +100,4 @@ def main(rank, world, port, out_dir):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], hip=len(sys.argv) > 5 and sys.argv[5] == "hip")

@@ -222,6 +222,37 @@ def test_dist_hip_backend_rccl_single_rank_group(oracle):
             dist.destroy_process_group()
 
 
+def test_two_ranks_on_one_gpu_product_backend(oracle, tmp_path):
+    """Two processes, product backend (HipBackend) on GPU 0, gloo as the transport: the sharded ray
+    cast with its all-gather and the sharded ICP with one packet all-reduce per pass, on the
+    library's streams.  Both ranks must hold the single-process oracle result."""
+    import socket
+    import subprocess
+    import sys
+
+    from pedp_hip import synth
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_dist_worker.py"), str(r), "2", str(port),
+                               str(tmp_path), "hip"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    f = synth.Frame("tiny")
+    rays = f.rays6[: 48 * 40 - 3]
+    ref = oracle.raycast(f.verts_posed, f.tris, rays)
+    g = np.load(os.path.join(GOLD, "g3g4_icp_traces.npz"))
+    ricp = oracle.icp(g["scene_noisy"][:-5], g["model"], g["normals"], 10.0, g["init"], max_iter=6, rel_fitness=-1, rel_rmse=-1)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
+    for r in (r0, r1):
+        assert np.array_equal(r["ids"], ref["primitive_ids"]) and np.array_equal(r["t"].view(np.uint32), ref["t_hit"].view(np.uint32))
+        assert float(r["fitness"]) == ricp["fitness"] and int(r["iters"]) == 6
+        assert np.abs(r["T"] - ricp["T"]).max() < 1e-5
+    assert np.array_equal(r0["T"], r1["T"])      # every rank holds the identical pose
+
+
 def test_icp_with_shuffled_subsampled_target(oracle):
     """preprocess_target subsamples the model with np.random.choice: a target in random order
     (no spatial coherence in index order) must give the same exact correspondences."""
