@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
+    "pedp_cloud_create_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "pedp_cloud_destroy": (None, [C.c_void_p]),
     "pedp_cloud_size": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int)]),
     "pedp_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_void_p,
@@ -277,6 +278,18 @@ class Cloud:
         self.has_normals = nrm is not None
         self._h = C.c_void_p()
         check(load().pedp_cloud_create(ctx._h, _ptr(p), _ptr(nrm), self.N, C.byref(self._h)), "pedp_cloud_create")
+
+    @classmethod
+    def from_device(cls, ctx, points_ptr, n, normals_ptr=None):
+        """Cloud from device memory: N x 3 float64 at `points_ptr` (e.g. tensor.data_ptr() of a
+        contiguous torch.float64 CUDA tensor) on the context's GPU; the data are copied.  The caller
+        makes sure the producing work is complete or ordered on the context's stream."""
+        self = cls.__new__(cls)
+        self.ctx, self.N, self.has_normals = ctx, int(n), normals_ptr is not None
+        self._h = C.c_void_p()
+        check(load().pedp_cloud_create_device(ctx._h, C.c_void_p(points_ptr), C.c_void_p(normals_ptr) if normals_ptr else None,
+                                              self.N, C.byref(self._h)), "pedp_cloud_create_device")
+        return self
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -159,6 +159,132 @@ int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, in
     return PEDP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+constexpr int CS_BLOCKS = 512, CS_THREADS = 256;
+
+// per-workgroup partial sums and bounds of a device-resident cloud (fixed tree: deterministic)
+__global__ __launch_bounds__(CS_THREADS) void cloud_sum_kernel(const double *__restrict__ pts, int64_t N,
+                                                               double *__restrict__ part /* CS_BLOCKS x 9 */) {
+    __shared__ double sh[CS_THREADS / 64][9];
+    const double big = 1.7976931348623157e308;
+    double v[9] = {0, 0, 0, big, big, big, -big, -big, -big};
+    for (int64_t i = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; i < N; i += (int64_t)CS_BLOCKS * CS_THREADS)
+        for (int k = 0; k < 3; ++k) {
+            const double x = pts[3 * i + k];
+            v[k] += x;
+            v[3 + k] = x < v[3 + k] ? x : v[3 + k];
+            v[6 + k] = x > v[6 + k] ? x : v[6 + k];
+        }
+    for (int k = 0; k < 9; ++k) {
+        double x = v[k];
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(x, off, 64);
+            x = k < 3 ? x + o : (k < 6 ? (o < x ? o : x) : (o > x ? o : x));
+        }
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int k = threadIdx.x;
+        double x = sh[0][k];
+        for (int w = 1; w < CS_THREADS / 64; ++w) {
+            const double o = sh[w][k];
+            x = k < 3 ? x + o : (k < 6 ? (o < x ? o : x) : (o > x ? o : x));
+        }
+        part[blockIdx.x * 9 + k] = x;
+    }
+}
+
+// largest |t'|_1 and |t'|_2^2 of the centred float32 coordinates (the NN filter's magnitudes)
+__global__ __launch_bounds__(CS_THREADS) void cloud_norm_kernel(const double *__restrict__ pts, int64_t N, double cx, double cy,
+                                                                double cz, float *__restrict__ part /* CS_BLOCKS x 2 */) {
+    __shared__ float sh[CS_THREADS / 64][2];
+    float n1m = 0.f, n2m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; i < N; i += (int64_t)CS_BLOCKS * CS_THREADS) {
+        const float x = (float)(pts[3 * i] - cx), y = (float)(pts[3 * i + 1] - cy), z = (float)(pts[3 * i + 2] - cz);
+        n1m = fmaxf(n1m, fabsf(x) + fabsf(y) + fabsf(z));
+        n2m = fmaxf(n2m, x * x + y * y + z * z);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        n1m = fmaxf(n1m, __shfl_xor(n1m, off, 64));
+        n2m = fmaxf(n2m, __shfl_xor(n2m, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = n1m; sh[threadIdx.x >> 6][1] = n2m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < CS_THREADS / 64; ++w) { n1m = fmaxf(n1m, sh[w][0]); n2m = fmaxf(n2m, sh[w][1]); }
+        part[blockIdx.x * 2] = fmaxf(n1m, sh[0][0]);
+        part[blockIdx.x * 2 + 1] = fmaxf(n2m, sh[0][1]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_normals, int64_t N, pedp_cloud_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_cloud_create_device: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE(N >= 0 && N < (int64_t)0x7FFFFF00, "pedp_cloud_create_device: N out of range");
+    PEDP_REQUIRE(d_pts || N == 0, "pedp_cloud_create_device: null points");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
+    if (!cl) { pedp_set_error("pedp_cloud_create_device: out of host memory"); return PEDP_ERR_ALLOC; }
+    cl->ctx = c;
+    cl->N = N;
+    const size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
+    hipError_t e = hipMalloc((void **)&cl->pts, bytes);
+    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->pts, d_pts, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && d_normals) {
+        cl->has_normals = true;
+        e = hipMalloc((void **)&cl->normals, bytes);
+        if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->normals, d_normals, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
+    }
+    double part[CS_BLOCKS * 9];
+    float fpart[CS_BLOCKS * 2];
+    if (e == hipSuccess && N > 0) {
+        int st = c->ops.reserve(sizeof(double) * CS_BLOCKS * 9 + sizeof(float) * CS_BLOCKS * 2 + 512);
+        if (st) { pedp_cloud_destroy(cl); return st; }
+        double *d_part = (double *)c->ops.ptr;
+        float *d_fpart = (float *)(d_part + CS_BLOCKS * 9);
+        hipLaunchKernelGGL(cloud_sum_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N, d_part);
+        e = hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) {
+            double sum[3] = {0, 0, 0};
+            for (int k = 0; k < 3; ++k) { cl->lo[k] = part[3 + k]; cl->hi[k] = part[6 + k]; }
+            for (int b = 0; b < CS_BLOCKS; ++b)
+                for (int k = 0; k < 3; ++k) {
+                    sum[k] += part[b * 9 + k];
+                    if (part[b * 9 + 3 + k] < cl->lo[k]) cl->lo[k] = part[b * 9 + 3 + k];
+                    if (part[b * 9 + 6 + k] > cl->hi[k]) cl->hi[k] = part[b * 9 + 6 + k];
+                }
+            for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
+            hipLaunchKernelGGL(cloud_norm_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N,
+                               cl->centroid[0], cl->centroid[1], cl->centroid[2], d_fpart);
+            e = hipMemcpyAsync(fpart, d_fpart, sizeof(fpart), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) {
+                float Tn = 0.f, T2 = 0.f;
+                for (int b = 0; b < CS_BLOCKS; ++b) { Tn = fmaxf(Tn, fpart[2 * b]); T2 = fmaxf(T2, fpart[2 * b + 1]); }
+                cl->Tn = Tn * 1.0001f;
+                cl->T2 = T2 * 1.0001f;
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        pedp_set_error("pedp_cloud_create_device: %s", hipGetErrorString(e));
+        pedp_cloud_destroy(cl);
+        return PEDP_ERR_HIP;
+    }
+    *out = cl;
+    return PEDP_OK;
+}
+
 void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (!cl) return;
     if (cl->ctx) (void)hipSetDevice(cl->ctx->device);

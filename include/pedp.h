@@ -191,6 +191,11 @@ int pedp_segment_plane(pedp_ctx_t ctx, const double *pts, int64_t N, double dist
  */
 int pedp_cloud_create(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N,
                       pedp_cloud_t *out);
+/* The same from DEVICE memory (N x 3 float64 on the context's GPU, e.g. a torch tensor built from
+ * depth2xyzmap's output): device-to-device copies, centroid / bounds / magnitudes by a reduction
+ * on the device.  The call synchronises the stream. */
+int pedp_cloud_create_device(pedp_ctx_t ctx, const double *d_pts, const double *d_normals, int64_t N,
+                             pedp_cloud_t *out);
 void pedp_cloud_destroy(pedp_cloud_t cloud);
 int pedp_cloud_size(pedp_cloud_t cloud, int64_t *N, int *has_normals);
 

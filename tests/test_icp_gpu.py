@@ -156,3 +156,41 @@ def test_cluster_poses_matches_oracle(oracle):
         poses[k, :3, :3] = synth.axis_angle(rng.normal(size=3), rng.uniform(0, np.pi)).astype(np.float32)
     syms = np.stack([np.eye(4), np.diag([-1.0, -1.0, 1.0, 1.0])]).astype(np.float32)
     assert np.array_equal(_lib.cluster_poses(30, 99999, poses, syms), oracle.cluster_poses(30, 99999, poses, syms))
+
+
+def test_device_resident_chain_depth_to_registration(ctx, oracle):
+    """Camera-rate plumbing: depth image on the device -> erode -> bilateral -> depth2xyzmap_batch ->
+    valid points (torch, device) -> Cloud.from_device -> registration.  Nothing but the 4x4 comes back.
+    The registration equals the one on the same points uploaded from the host, and the oracle's."""
+    import torch
+    from pedp_hip import _lib, compat, synth
+
+    f = synth.Frame("parity")
+    t_hit = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    # the filters work in metres (validity 0.001, bilateral window 0.01), the registration in mm
+    z = np.where(np.isfinite(t_hit), t_hit * f.dirs[:, 2] / 1000.0, 0.0).reshape(f.height, f.width).astype(np.float32)
+    d = torch.from_numpy(z).cuda()
+    K = torch.as_tensor(f.K, dtype=torch.float32, device="cuda")
+    dm = compat.bilateral_filter_depth(compat.erode_depth(d, radius=2, depth_diff_thres=0.02, ratio_thres=0.8, zfar=100),
+                                       radius=2, zfar=100, sigmaD=2, sigmaR=100000)
+    xyz = compat.depth2xyzmap_batch(dm[None], K[None], zfar=np.inf)[0]
+    pts = (xyz[xyz[..., 2] > 0].double() * 1000.0).contiguous()
+    torch.cuda.synchronize()
+    assert pts.is_cuda and len(pts) > 500
+    src_dev = _lib.Cloud.from_device(ctx, pts.data_ptr(), len(pts))
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    host_pts = pts.cpu().numpy()
+    a = _lib.icp(ctx, src_dev, tgt, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1, relative_rmse=-1, want_corr=True)
+    b = _lib.icp(ctx, _lib.Cloud(ctx, host_pts), tgt, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1,
+                 relative_rmse=-1, want_corr=True)
+    ref = oracle.icp(host_pts, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=8, rel_fitness=-1, rel_rmse=-1)
+    assert np.array_equal(a["corr"], ref["corr"]) and np.array_equal(b["corr"], ref["corr"])
+    assert a["fitness"] == ref["fitness"] and np.abs(a["T"] - ref["T"]).max() < 1e-5 and np.abs(a["T"] - b["T"]).max() < 1e-9
+    assert np.abs(np.linalg.inv(a["T"]) - f.T_gt).max() < 0.5
+    # with normals, empty cloud
+    n = torch.from_numpy(f.normals).cuda().contiguous(); m = torch.from_numpy(f.model_points).cuda().contiguous()
+    tgt_dev = _lib.Cloud.from_device(ctx, m.data_ptr(), len(m), n.data_ptr())
+    c = _lib.icp(ctx, src_dev, tgt_dev, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1, relative_rmse=-1)
+    assert c["fitness"] == ref["fitness"] and np.abs(c["T"] - ref["T"]).max() < 1e-5
+    empty = _lib.Cloud.from_device(ctx, pts.data_ptr(), 0)
+    assert _lib.icp(ctx, empty, tgt, 10.0, np.eye(4))["fitness"] == 0.0
