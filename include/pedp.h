@@ -82,8 +82,10 @@ int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N
  *     (falls back to 1 on the device otherwise).  All variants return identical bits. */
 int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
 
-/* Milliseconds the last pedp_raycast spent in its sweep kernel (HIP events on the
- * context's stream); synchronises the stream. */
+/* Milliseconds the last pedp_raycast spent in its sweep stage -- for variant 3 the direction
+ * binning, cull masks, segment table and the sweep itself (HIP events on the context's stream,
+ * around everything between the operand set-up and the final t / id / uv write-out);
+ * synchronises on the second event. */
 int pedp_raycast_last_sweep_ms(pedp_ctx_t ctx, float *ms);
 
 /* ---------------------------------------------------------------- fused defect projection
