@@ -328,34 +328,36 @@ __global__ void cluster_sphere_kernel(const float *__restrict__ aos, int64_t F, 
 
 // bounding sphere of 64 consecutive cluster spheres (one mask word of clusters): lets the cull
 // kernel dismiss 1024 triangles with one test
-__global__ void supercluster_sphere_kernel(const float4 *__restrict__ sph, int64_t n_clusters, int64_t n_super,
-                                           float4 *__restrict__ out) {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_super) return;
-    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-    int n = 0;
-    for (int k = 0; k < 64; ++k) {
-        const int64_t c = s * 64 + k;
-        if (c >= n_clusters) break;
-        const float4 q = sph[c];
-        if (q.w < 0.f) continue;
-        lo[0] = fminf(lo[0], q.x - q.w); hi[0] = fmaxf(hi[0], q.x + q.w);
-        lo[1] = fminf(lo[1], q.y - q.w); hi[1] = fmaxf(hi[1], q.y + q.w);
-        lo[2] = fminf(lo[2], q.z - q.w); hi[2] = fmaxf(hi[2], q.z + q.w);
-        ++n;
+// one wave per super-cluster, lane = cluster: min / max are order-free, so the result does not
+// depend on the reduction shape
+__global__ __launch_bounds__(256) void supercluster_sphere_kernel(const float4 *__restrict__ sph, int64_t n_clusters,
+                                                                  int64_t n_super, float4 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_super) return;  // wave-uniform
+    const int64_t c = s * 64 + lane;
+    const float4 q = c < n_clusters ? sph[c] : make_float4(0.f, 0.f, 0.f, -1.f);
+    const bool live = q.w >= 0.f;
+    float lo[3] = {live ? q.x - q.w : 3e38f, live ? q.y - q.w : 3e38f, live ? q.z - q.w : 3e38f};
+    float hi[3] = {live ? q.x + q.w : -3e38f, live ? q.y + q.w : -3e38f, live ? q.z + q.w : -3e38f};
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    if (__builtin_amdgcn_ballot_w64(live) == 0ull) {
+        if (lane == 0) out[s] = make_float4(0.f, 0.f, 0.f, -1.f);
+        return;
     }
-    if (n == 0) { out[s] = make_float4(0.f, 0.f, 0.f, -1.f); return; }
     const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
-    float rad = 0.f;
-    for (int k = 0; k < 64; ++k) {
-        const int64_t c = s * 64 + k;
-        if (c >= n_clusters) break;
-        const float4 q = sph[c];
-        if (q.w < 0.f) continue;
-        const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
-        rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + q.w);
-    }
-    out[s] = make_float4(cx, cy, cz, rad * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f);
+    const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+    float rad = live ? sqrtf(dx * dx + dy * dy + dz * dz) + q.w : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rad = fmaxf(rad, __shfl_xor(rad, off, 64));
+    if (lane == 0)
+        out[s] = make_float4(cx, cy, cz, rad * 1.0001f + 1e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-30f);
 }
 
 // per call: cone of each cluster seen from the shared origin.  rec[2c] = (vx, vy, vz, cos psi),
@@ -837,7 +839,7 @@ static hipError_t mesh_build_records(pedp_ctx_t c, pedp_mesh_s *m, const float *
     hipLaunchKernelGGL(pair_general_kernel, dim3(grid), dim3(256), 0, c->stream, m->tri, m->F_padded, m->tri2);
     hipLaunchKernelGGL(cluster_sphere_kernel, dim3((unsigned)((m->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
                        m->tri, m->F, m->n_clusters, (float4 *)m->spheres);
-    hipLaunchKernelGGL(supercluster_sphere_kernel, dim3((unsigned)((m->n_super + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(supercluster_sphere_kernel, dim3((unsigned)((m->n_super + 3) / 4)), dim3(256), 0, c->stream,
                        (const float4 *)m->spheres, m->n_clusters, m->n_super, (float4 *)m->super_spheres);
     return hipGetLastError();
 }
