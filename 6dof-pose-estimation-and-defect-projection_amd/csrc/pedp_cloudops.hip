@@ -260,6 +260,51 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
     avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
+// Small clouds (the largest cluster that reaches the outlier filter is a few thousand points): one
+// WAVE per query.  The wave writes the squared distances to all N points into LDS, every lane
+// keeps the minimum of its strided share, and the k smallest are extracted one by one with a
+// wave-wide argmin -- in ascending order, which is the order the mean is summed in.  The lane that
+// owned an extracted value rescans its share.  Same multiset and same summation order as the grid
+// kernel and the oracle.
+constexpr int KNN_SMALL_MAX = 4096;
+__global__ __launch_bounds__(64) void knn_mean_small_kernel(const double *__restrict__ pts, int N, int k,
+                                                            double *__restrict__ avg) {
+    extern __shared__ double dist[];  // N squared distances of this query
+    const int lane = threadIdx.x, i = blockIdx.x;
+    const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double lmin = inf;
+    int lidx = -1;
+    for (int q = lane; q < N; q += 64) {
+        const double d = dist2(p, pts + 3 * (size_t)q);
+        dist[q] = d;
+        if (d < lmin) { lmin = d; lidx = q; }
+    }
+    const int m = N < k ? N : k;
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) {
+        double v = lmin;
+        int owner = lane;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int oo = __shfl_xor(owner, off, 64);
+            if (ov < v || (ov == v && oo < owner)) { v = ov; owner = oo; }
+        }
+        s += sqrt(v);  // every lane forms the same sum
+        if (lane == owner) {  // drop the extracted value and find the share's next minimum
+            dist[lidx] = inf;
+            lmin = inf;
+            lidx = -1;
+            for (int q = lane; q < N; q += 64) {
+                const double d = dist[q];
+                if (d < lmin) { lmin = d; lidx = q; }
+            }
+        }
+    }
+    if (lane == 0) avg[i] = m > 0 ? s / (double)m : -1.0;
+}
+
 // ------------------------------------------------------------------ normal estimation
 // PointCloud::EstimateNormals with a hybrid search (radius, max_nn): the max_nn nearest points with
 // d^2 < radius^2 in ascending (d^2, index) -- kept sorted in LDS per thread -- give the nine
@@ -671,6 +716,20 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     PEDP_REQUIRE(k >= 1 && k <= 300, "pedp_knn_mean_distance: k must be in 1..300");  // k x 64 doubles of LDS per workgroup
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(avg, "pedp_knn_mean_distance: null output");
+    if (N <= KNN_SMALL_MAX) {  // a wave per query, all distances in LDS
+        PEDP_HIP_CHECK(hipSetDevice(c->device));
+        int st0 = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(double) * N) + 512);
+        if (st0) return st0;
+        Carver cv0{(char *)c->ops.ptr};
+        double *d_pts0 = cv0.take<double>(3 * (size_t)N), *d_avg0 = cv0.take<double>(N);
+        PEDP_HIP_CHECK(hipMemcpyAsync(d_pts0, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(knn_mean_small_kernel, dim3((unsigned)N), dim3(64), sizeof(double) * (size_t)N, c->stream, d_pts0, (int)N,
+                           k, d_avg0);
+        PEDP_HIP_CHECK(hipGetLastError());
+        PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg0, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return PEDP_OK;
+    }
     double lo[3], hi[3];
     bounds(pts, N, lo, hi);
     // cell ~ the radius that holds k points if the cloud were spread over a sheet of the box's

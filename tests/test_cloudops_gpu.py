@@ -91,6 +91,10 @@ def test_statistical_outlier_removal(ctx, oracle, k, ratio):
     assert np.array_equal(keep, oracle.remove_statistical_outlier(pts, k, ratio))
     few = pts[:40]                       # fewer points than neighbours: all of them are "the k nearest"
     assert np.array_equal(cloud_ops.knn_mean_distance(few, 75), oracle.knn_mean_distance(few, 75))
+    # both kernels: the wave-per-query one (N <= 4096) and the grid walk (larger clouds)
+    assert len(pts) > 4096
+    for sub in (pts[:3000], pts[:4096], pts[:4097]):
+        assert np.array_equal(cloud_ops.knn_mean_distance(sub, k), oracle.knn_mean_distance(sub, k))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 12345])
