@@ -266,7 +266,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
 // wave-wide argmin -- in ascending order, which is the order the mean is summed in.  The lane that
 // owned an extracted value rescans its share.  Same multiset and same summation order as the grid
 // kernel and the oracle.
-constexpr int KNN_SMALL_MAX = 4096;
+constexpr int KNN_SMALL_MAX = 8192;  // 64 KB of distances per query wave
 __global__ __launch_bounds__(64) void knn_mean_small_kernel(const double *__restrict__ pts, int N, int k,
                                                             double *__restrict__ avg) {
     extern __shared__ double dist[];  // N squared distances of this query
@@ -723,6 +723,8 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
         Carver cv0{(char *)c->ops.ptr};
         double *d_pts0 = cv0.take<double>(3 * (size_t)N), *d_avg0 = cv0.take<double>(N);
         PEDP_HIP_CHECK(hipMemcpyAsync(d_pts0, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(double) * KNN_SMALL_MAX)));
         hipLaunchKernelGGL(knn_mean_small_kernel, dim3((unsigned)N), dim3(64), sizeof(double) * (size_t)N, c->stream, d_pts0, (int)N,
                            k, d_avg0);
         PEDP_HIP_CHECK(hipGetLastError());

@@ -91,9 +91,10 @@ def test_statistical_outlier_removal(ctx, oracle, k, ratio):
     assert np.array_equal(keep, oracle.remove_statistical_outlier(pts, k, ratio))
     few = pts[:40]                       # fewer points than neighbours: all of them are "the k nearest"
     assert np.array_equal(cloud_ops.knn_mean_distance(few, 75), oracle.knn_mean_distance(few, 75))
-    # both kernels: the wave-per-query one (N <= 4096) and the grid walk (larger clouds)
-    assert len(pts) > 4096
-    for sub in (pts[:3000], pts[:4096], pts[:4097]):
+    # both kernels: the wave-per-query one (N <= 8192) and the grid walk (larger clouds)
+    big, _ = oracle.voxel_down_sample(_scene(n_plane=14000, n_obj=5000, seed=8), 2.5)
+    assert len(big) > 8193
+    for sub in (pts[:3000], big[:8192], big[:8193]):
         assert np.array_equal(cloud_ops.knn_mean_distance(sub, k), oracle.knn_mean_distance(sub, k))
 
 
