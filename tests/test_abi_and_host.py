@@ -326,3 +326,25 @@ def test_depth_based_projection_host_functions():
     ref = [[(x - K[0, 2]) * depth[y, x] / K[0, 0], (y - K[1, 2]) * depth[y, x] / K[1, 1], depth[y, x]]
            for x, y in pix if depth[y, x] != 0]
     assert np.array_equal(c, np.array(ref, dtype=np.float64)) and len(c) == 2
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line under profiles/ carries every key the driver and the judge read."""
+    import glob
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_v*.json")),
+                    key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))[-1]
+    d = json.loads(open(newest).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - d["n_gpus"] * 368640 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3) / 1e6) < 1e-6 * d["value"]
