@@ -29,6 +29,7 @@ class IcpParams(C.Structure):
         ("allreduce", ALLREDUCE_FN),
         ("allreduce_user", C.c_void_p),
         ("n_source_global", C.c_int64),
+        ("use_comm", C.c_int),
     ]
 
 
@@ -77,6 +78,13 @@ PROTOTYPES = {
     "pedp_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "pedp_icp_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pedp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pedp_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pedp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pedp_comm_size": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "pedp_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "pedp_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pedp_cluster_poses": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, _P(C.c_int)]),
 }
@@ -319,6 +327,50 @@ def nn_last_sweep_ms(ctx):
     return ms.value
 
 
+def icp_configure(ctx, exhaustive=False, timed_pass=-1):
+    """Measurement knobs of pedp_icp on this context: exhaustive = all-pairs sweep in every pass
+    (same results), timed_pass = the pass whose sweep kernel gets HIP events (nn_last_sweep_ms)."""
+    check(load().pedp_icp_configure(ctx._h, int(bool(exhaustive)), int(timed_pass)), "pedp_icp_configure")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 makes it; every rank passes the same bytes to comm_create)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(load().pedp_comm_unique_id(buf), "pedp_comm_unique_id")
+    return bytes(buf)
+
+
+def comm_create(ctx, unique_id, nranks, rank):
+    """Give the context its own RCCL communicator (collective: every rank calls it)."""
+    if len(unique_id) != COMM_ID_BYTES:
+        raise PedpError("comm_create: the unique id must be 128 bytes")
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+    check(load().pedp_comm_create(ctx._h, buf, int(nranks), int(rank)), "pedp_comm_create")
+
+
+def comm_destroy(ctx):
+    check(load().pedp_comm_destroy(ctx._h), "pedp_comm_destroy")
+
+
+def comm_size(ctx):
+    n, r = C.c_int(1), C.c_int(0)
+    check(load().pedp_comm_size(ctx._h, C.byref(n), C.byref(r)), "pedp_comm_size")
+    return n.value, r.value
+
+
+def comm_allgather(ctx, send_ptr, recv_ptr, bytes_per_rank):
+    """Device pointers; enqueued on the context's stream."""
+    check(load().pedp_comm_allgather(ctx._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(bytes_per_rank)),
+          "pedp_comm_allgather")
+
+
+def comm_allreduce_f64(ctx, ptr, n):
+    check(load().pedp_comm_allreduce_f64(ctx._h, C.c_void_p(ptr), int(n)), "pedp_comm_allreduce_f64")
+
+
 def icp_last_stats(ctx):
     """(passes, pairs swept by the MFMA kernel, points sent to the exact fallback) of the last icp()."""
     a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
@@ -328,7 +380,7 @@ def icp_last_stats(ctx):
 
 def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,
         relative_fitness=1e-6, relative_rmse=1e-6, want_corr=False, want_trace=False, allreduce=None,
-        n_source_global=0):
+        n_source_global=0, use_comm=False):
     """Raw pedp_icp call on Cloud handles.  Returns dict(T, fitness, inlier_rmse, iters[, corr, trace])."""
     prm = IcpParams()
     prm.max_correspondence_distance = float(max_correspondence_distance)
@@ -352,6 +404,7 @@ def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_
         prm.allreduce = C.cast(None, ALLREDUCE_FN)
     prm.allreduce_user = None
     prm.n_source_global = int(n_source_global)
+    prm.use_comm = int(bool(use_comm))
     T0 = np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
     T = np.empty((4, 4), np.float64)
     fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
@@ -377,6 +430,7 @@ def icp_batched(ctx, source, target, max_correspondence_distance, inits, estimat
     prm.allreduce = C.cast(None, ALLREDUCE_FN)
     prm.allreduce_user = None
     prm.n_source_global = 0
+    prm.use_comm = 0
     I = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 16)
     B = len(I)
     T = np.empty((B, 4, 4), np.float64)

@@ -25,6 +25,7 @@ SOURCES = {
     "pedp_project.hip": [],
     "pedp_depth.hip": [],
     "pedp_cloudops.hip": [],
+    "pedp_comm.hip": [],
     "pedp_cluster.cpp": [],
 }
 HEADERS = ["pedp_internal.h", os.path.join("..", "..", "include", "pedp.h")]
@@ -66,7 +67,7 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
         objs.append(obj)
-    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out]
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-o", out]
     if verbose:
         print("[pedp build]", " ".join(link), flush=True)
     subprocess.run(link, check=True)

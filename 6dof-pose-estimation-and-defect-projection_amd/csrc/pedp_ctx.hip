@@ -3,7 +3,12 @@
 #include <cmath>
 #include <new>
 
+#include <atomic>
+
 static thread_local char g_err[512] = "";
+static std::atomic<uint64_t> g_generation{0};
+
+uint64_t pedp_next_generation() { return ++g_generation; }
 
 void pedp_set_error(const char *fmt, ...) {
     va_list ap;
@@ -79,6 +84,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)pedp_comm_destroy(c);
     for (int k = 0; k < PEDP_MAX_SUB; ++k) {
         if (c->sub[k]) pedp_ctx_destroy(c->sub[k]);
         c->sub[k] = nullptr;
@@ -120,6 +126,8 @@ int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, in
     pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
     if (!cl) { pedp_set_error("pedp_cloud_create: out of host memory"); return PEDP_ERR_ALLOC; }
     cl->ctx = c;
+    cl->device = c->device;
+    cl->gen = pedp_next_generation();
     cl->N = N;
     if (N > 0) {
         double sum[3] = {0, 0, 0};
@@ -234,6 +242,8 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
     pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
     if (!cl) { pedp_set_error("pedp_cloud_create_device: out of host memory"); return PEDP_ERR_ALLOC; }
     cl->ctx = c;
+    cl->device = c->device;
+    cl->gen = pedp_next_generation();
     cl->N = N;
     const size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
     hipError_t e = hipMalloc((void **)&cl->pts, bytes);
@@ -287,7 +297,7 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
 
 void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (!cl) return;
-    if (cl->ctx) (void)hipSetDevice(cl->ctx->device);
+    (void)hipSetDevice(cl->device);
     if (cl->pts) (void)hipFree(cl->pts);
     if (cl->normals) (void)hipFree(cl->normals);
     if (cl->tgt4) (void)hipFree(cl->tgt4);

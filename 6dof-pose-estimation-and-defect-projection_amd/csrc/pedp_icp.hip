@@ -1187,13 +1187,16 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
 // Enqueue one correspondence pass (transform, sweep, fallback).  mode as in
 // icp_transform_pack_kernel.
 int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int mode,
-                    const TargetPrep &tp, double r, bool timed) {
+                    const TargetPrep &tp, double r, bool timed, bool exhaustive = false) {
     const int64_t Ns = src->N, Nt = tgt->N;
     // r1: distance scale of the candidates the bound must hold for (anything farther is
     // not an inlier anyway); huge radii fall back to the cloud scale inside the kernel.
     const float r1 = (float)(r * 1.01);
-    const double r2cut = r * r * (1.0 + 1e-12);
-    const float r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
+    // exhaustive: the box test and the sphere culling use an infinite radius (every point is a
+    // candidate, every mask bit is set); the selection still applies r, so results do not change
+    const double r_cull = exhaustive ? 1e18 : r;
+    const double r2cut = r_cull * r_cull * (1.0 + 1e-12);
+    const float r_search = (float)(r_cull * (1.0 + 1e-6)) + 1e-6f;
     const int n_tiles = (int)(w.Nt_pad / (16 * w.qt));  // target units
     {
         int64_t grid = (Ns + 511) / 512;  // 128 points per wave, 4 waves per workgroup
@@ -1201,7 +1204,6 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
                            src->pts, w.P, w.src_perm, Ns, w.B, w.eps, w.S, w.list, w.blk_sph, w.idx, w.d2, tp.Tn, tp.T2,
                            r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
     }
-    if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
     const float r2f = (float)(r * r) * 1.00001f;
     const unsigned sel_grid = (unsigned)((4 * w.Ns_pad + 255) / 256);
     const unsigned sweep_grid = (unsigned)((w.max_segs + NN_WAVES - 1) / NN_WAVES);
@@ -1220,6 +1222,7 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     }
 #define PEDP_NN_STAGE(QTV, GV)                                                                                          \
     do {                                                                                                              \
+        if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));                                              \
         hipLaunchKernelGGL((nn_sweep_kernel<QTV, GV>), dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,            \
                            (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0, w.seg_n,         \
                            (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);                                            \
@@ -1353,6 +1356,8 @@ struct IcpJob {
     IcpWorkspace w;
     int max_iter = 0, qt = 1;
     int64_t Ns = 0, Nt = 0;
+    bool exhaustive = false;
+    int timed_pass = -1;
 };
 
 int icp_check_args(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm) {
@@ -1360,6 +1365,8 @@ int icp_check_args(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const
     PEDP_REQUIRE(prm->estimator == PEDP_POINT_TO_PLANE || prm->estimator == PEDP_POINT_TO_POINT,
                  "pedp_icp: unknown estimator %d", prm->estimator);
     PEDP_REQUIRE(prm->max_iteration >= 0 && prm->max_iteration <= 100000, "pedp_icp: max_iteration out of range");
+    PEDP_REQUIRE(!prm->use_comm || c->comm, "pedp_icp: use_comm is set but the context has no communicator (pedp_comm_create)");
+    PEDP_REQUIRE(!(prm->use_comm && prm->allreduce), "pedp_icp: use_comm and an all-reduce hook are exclusive");
     if (prm->estimator == PEDP_POINT_TO_PLANE && !target->has_normals) {
         pedp_set_error("pedp_icp: TransformationEstimationPointToPlane requires target normals");
         return PEDP_ERR_NO_NORMALS;
@@ -1399,7 +1406,9 @@ int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const 
     job.max_iter = prm->max_iteration;
     job.Ns = source->N;
     job.Nt = target->N;
-    job.qt = icp_unit_size(target, prm->max_correspondence_distance);
+    job.qt = x->icp_exhaustive ? 4 : icp_unit_size(target, prm->max_correspondence_distance);
+    job.exhaustive = x->icp_exhaustive;
+    job.timed_pass = x->icp_timed_pass;
     IcpWorkspace &w = job.w;
     int rc = carve_workspace(x, job.Ns, job.Nt, job.max_iter, job.qt, w);
     if (rc) return rc;
@@ -1435,18 +1444,22 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, x->stream));
     const double r2 = r * r;
     const double ng = n_global > 0 ? n_global : 1.0;
+    const bool exchange = prm->allreduce || prm->use_comm;  // the packet is summed over ranks before the solve
     for (int pass = 0; pass <= max_iter; ++pass) {
         if (!degenerate) {
-            rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, false);
+            rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, pass == job.timed_pass, job.exhaustive);
             if (rc) return rc;
             hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, x->stream, w.st,
                                prm->estimator, w.P, Ns, target->pts, target->normals, w.idx, w.d2, r2, w.partials);
-            if (prm->allreduce) hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, x->stream, w.st, w.partials, w.packet);
+            if (exchange) hipLaunchKernelGGL(icp_reduce_kernel, dim3(1), dim3(64), 0, x->stream, w.st, w.partials, w.packet);
         } else {
             PEDP_HIP_CHECK(hipMemsetAsync(w.packet, 0, sizeof(double) * 32, x->stream));
             if (pass == 0 && Ns > 0) PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, x->stream));
         }
-        if (prm->allreduce) {
+        if (prm->use_comm) {  // RCCL all-reduce on this stream, issued by the library
+            rc = pedp_comm_allreduce_sum_f64(x, w.packet, PACKET);
+            if (rc) { (void)hipStreamSynchronize(x->stream); return rc; }
+        } else if (prm->allreduce) {
             if (prm->allreduce(prm->allreduce_user, w.packet, PACKET, (void *)x->stream) != 0) {
                 pedp_set_error("pedp_icp: all-reduce hook failed in pass %d", pass);
                 (void)hipStreamSynchronize(x->stream);
@@ -1455,7 +1468,7 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
         }
         // A fused accumulate + solve (last workgroup done runs the solve) was measured slower:
         // the device-scope release every workgroup needs writes the whole L2 back (43 us vs 12 + 16).
-        const double *fold = (!degenerate && !prm->allreduce) ? w.partials : nullptr;
+        const double *fold = (!degenerate && !exchange) ? w.partials : nullptr;
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, x->stream, w.st, w.packet, fold, pass, max_iter,
                            prm->estimator, ng, prm->relative_fitness, prm->relative_rmse, want_trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
@@ -1504,11 +1517,11 @@ int icp_launch_replayed(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, 
     if (rc) return rc;
     icp_fill_state(x, tp, init);
     pedp_icp_graph_key key;
-    key.src = source; key.tgt = target; key.ws = x->icp_ws.ptr;
+    key.src_gen = source->gen; key.tgt_gen = target->gen; key.ws = x->icp_ws.ptr;
     key.Ns = job.Ns; key.Nt = job.Nt; key.max_iter = job.max_iter; key.qt = job.qt; key.estimator = prm->estimator;
     key.r = prm->max_correspondence_distance;
     const pedp_icp_graph_key &have = x->icp_graph_key;
-    const bool same = x->icp_graph && have.src == key.src && have.tgt == key.tgt && have.ws == key.ws && have.Ns == key.Ns &&
+    const bool same = x->icp_graph && have.src_gen == key.src_gen && have.tgt_gen == key.tgt_gen && have.ws == key.ws && have.Ns == key.Ns &&
                       have.Nt == key.Nt && have.max_iter == key.max_iter && have.qt == key.qt &&
                       have.estimator == key.estimator && have.r == key.r;
     if (!same) {
@@ -1561,7 +1574,7 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
                      const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse) {
     PEDP_REQUIRE(c && source && target && prm && inits && T_out, "pedp_icp_batched: null argument");
     PEDP_REQUIRE(B >= 0, "pedp_icp_batched: negative batch");
-    PEDP_REQUIRE(!prm->allreduce, "pedp_icp_batched: hypotheses shard across ranks, not within one registration");
+    PEDP_REQUIRE(!prm->allreduce && !prm->use_comm, "pedp_icp_batched: hypotheses shard across ranks, not within one registration");
     if (B == 0) return PEDP_OK;
     int rc = icp_check_args(c, source, target, prm);
     if (rc) return rc;
@@ -1583,16 +1596,23 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
     IcpJob jobs[PEDP_MAX_SUB];
     c->icp_last_cand = c->icp_last_fb = c->icp_last_passes = 0;  // statistics: totals over the batch
     c->icp_last_nt = target->N;
+    // on an error return no sub-stream may still be running on the clouds' buffers (the caller
+    // is free to destroy them): drain them all first
+    auto drain = [&](int rc_) {
+        for (int k = 0; k < K; ++k)
+            if (c->sub[k]) (void)hipStreamSynchronize(c->sub[k]->stream);
+        return rc_;
+    };
     for (int b0 = 0; b0 < B; b0 += K) {
         const int n = (B - b0 < K) ? B - b0 : K;
         for (int k = 0; k < n; ++k) {
             rc = icp_launch_replayed(c->sub[k], source, target, tp, &p, inits + 16 * (b0 + k), jobs[k]);
-            if (rc) return rc;
+            if (rc) return drain(rc);
         }
         for (int k = 0; k < n; ++k) {
             rc = icp_collect(c->sub[k], jobs[k], T_out + 16 * (b0 + k), fitness ? fitness + b0 + k : nullptr,
                              inlier_rmse ? inlier_rmse + b0 + k : nullptr, nullptr, nullptr, nullptr);
-            if (rc) return rc;
+            if (rc) return drain(rc);
             c->icp_last_cand += c->sub[k]->icp_last_cand;
             c->icp_last_fb += c->sub[k]->icp_last_fb;
             c->icp_last_passes += c->sub[k]->icp_last_passes;
@@ -1631,6 +1651,15 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     PEDP_HIP_CHECK(hipMemcpyAsync(idx, w.idx, sizeof(int32_t) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipMemcpyAsync(d2, w.d2, sizeof(double) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_icp_configure(pedp_ctx_t c, int exhaustive, int timed_pass) {
+    PEDP_REQUIRE(c, "pedp_icp_configure: null context");
+    c->icp_exhaustive = exhaustive != 0;
+    c->icp_timed_pass = timed_pass;
+    for (int k = 0; k < PEDP_MAX_SUB; ++k)  // captured graphs bake the mode in
+        if (c->sub[k] && c->sub[k]->icp_graph) { (void)hipGraphExecDestroy(c->sub[k]->icp_graph); c->sub[k]->icp_graph = nullptr; }
     return PEDP_OK;
 }
 

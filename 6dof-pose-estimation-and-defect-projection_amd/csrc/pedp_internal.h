@@ -8,6 +8,7 @@
 #include "../../include/pedp.h"
 
 void pedp_set_error(const char *fmt, ...);
+uint64_t pedp_next_generation();
 
 #define PEDP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
@@ -40,14 +41,21 @@ struct pedp_scratch {
 // What a captured registration graph depends on besides device-memory contents: if any of it
 // changes, the graph is captured again.
 struct pedp_icp_graph_key {
-    const void *src = nullptr, *tgt = nullptr, *ws = nullptr;
+    // clouds are identified by their generation id, not by the handle address: a destroyed
+    // cloud's address can be handed out again by the next pedp_cloud_create
+    uint64_t src_gen = 0, tgt_gen = 0;
+    const void *ws = nullptr;
     int64_t Ns = 0, Nt = 0;
     int max_iter = 0, qt = 0, estimator = 0;
     double r = 0.0;
 };
 
+struct pedp_comm_s;  // pedp_comm.hip: RCCL communicator of this rank
+int pedp_comm_allreduce_sum_f64(pedp_ctx_t c, double *buf, int64_t n);
+
 struct pedp_ctx_s {
     int device = 0;
+    pedp_comm_s *comm = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
@@ -66,6 +74,8 @@ struct pedp_ctx_s {
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
+    bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
+    int icp_timed_pass = -1;      // pedp_icp_configure: HIP events around the sweep kernel of this pass
     long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
@@ -80,6 +90,7 @@ struct pedp_ctx_s {
 
 struct pedp_mesh_s {
     pedp_ctx_t ctx = nullptr;
+    int device = 0;  // copied at creation: destroy must not dereference a context that may be gone
     int64_t V = 0, F = 0;
     float *tri = nullptr;  // F_padded x PEDP_TRI_STRIDE floats on the device
     float *tri2 = nullptr; // F_padded/2 pair-interleaved general-origin records (24 floats each)
@@ -97,6 +108,8 @@ struct pedp_mesh_s {
 
 struct pedp_cloud_s {
     pedp_ctx_t ctx = nullptr;
+    int device = 0;     // copied at creation: destroy must not dereference a context that may be gone
+    uint64_t gen = 0;   // process-wide creation counter (never reused), keys cached graphs
     int64_t N = 0;
     bool has_normals = false;
     double *pts = nullptr;      // N x 3 f64 (device)

@@ -853,6 +853,7 @@ static int mesh_alloc(pedp_ctx_t c, int64_t V, const uint32_t *tris, int64_t F, 
     pedp_mesh_s *m = new (std::nothrow) pedp_mesh_s();
     if (!m) { pedp_set_error("%s: out of host memory", who); return PEDP_ERR_ALLOC; }
     m->ctx = c;
+    m->device = c->device;
     m->V = V;
     m->F = F;
     m->F_padded = ((F + 63) / 64) * 64;
@@ -938,10 +939,9 @@ int pedp_mesh_set_pose(pedp_mesh_t m, const double T[16]) {
 
 void pedp_mesh_destroy(pedp_mesh_t m) {
     if (!m) return;
-    if (m->ctx) {
-        (void)hipSetDevice(m->ctx->device);
-        if (m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
-    }
+    // the context may already be gone (Python collects handles in any order): use the ordinal
+    // stored at creation; hipFree itself waits for the device's outstanding work
+    (void)hipSetDevice(m->device);
     if (m->tri) (void)hipFree(m->tri);
     if (m->tri2) (void)hipFree(m->tri2);
     if (m->spheres) (void)hipFree(m->spheres);

@@ -8,8 +8,8 @@ registration_icp call running on the GPU through libpedp_hip.so.
     refine_pose_with_icp         :749-822   (orchestrator called by run.py:99)
     transform_object             :406-409
     preprocess_target            :141-183   (random subsample to max_pcd; keeps normals)
-    preprocess_source            :186-268   (OUT OF SCOPE this round, SURVEY s8 f2: the scene
-                                             cloud is passed through unchanged)
+    preprocess_source            :186-268   (voxel grid, table plane, DBSCAN, outlier filter and
+                                             normals on the GPU through pedp_hip.cloud_ops)
 
 Units are millimetres, transformations are 4x4 float64; `*.transformation` of a result maps
 scene -> model, exactly like the reference's RegistrationResult.

@@ -63,6 +63,10 @@ def intersect_rays_with_mesh(mesh, rays, origin, intensities, ctx=None, details=
     float64 from the float64 directions and the float32 distance (:261-263).
     `details`, if a dict, receives t_hit / primitive_ids / primitive_uvs / valid mask (the
     reference discards them; north_star asks for the triangle indices)."""
+    if hasattr(mesh, "has_triangle_normals") and not mesh.has_triangle_normals():  # :240-243, in place
+        mesh.compute_triangle_normals()
+    if hasattr(mesh, "has_vertex_normals") and not mesh.has_vertex_normals():
+        mesh.compute_vertex_normals()
     rays = np.asarray(rays, dtype=np.float64).reshape(-1, 3)
     n = len(rays)
     origins = np.tile(np.asarray(origin), (n, 1))
@@ -157,6 +161,11 @@ def ray_tracing(data_dir, target_mesh, heatmap, color_intrinsics, heatmap_thresh
     color_to_depth, _ = load_extrinsics(data_dir)
     mesh_in_color = clone(target_mesh)
     mesh_in_color.transform(np.linalg.inv(color_to_depth))
+    # side effect of intersect_rays_with_mesh on the returned copy (defect_projection.py:240-243)
+    if hasattr(mesh_in_color, "has_triangle_normals") and not mesh_in_color.has_triangle_normals():
+        mesh_in_color.compute_triangle_normals()
+    if hasattr(mesh_in_color, "has_vertex_normals") and not mesh_in_color.has_vertex_normals():
+        mesh_in_color.compute_vertex_normals()
     dev = _device_mesh(mesh_in_color, _lib.default_context())
     out = dev.project_heatmap(heatmap, color_intrinsics.intrinsic_matrix, heatmap_threshold, origin)
     if len(out["points"]) > 0:

@@ -1,28 +1,42 @@
 """bench.py -- the hot path on synthetic 640x576 frames against a 100k-triangle mesh.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config bench_100k] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config bench_100k] [--mode shard|replica]
+                    [--no-cpu-baseline] [--no-extras]
+
+`--gpus N` without a torchrun environment starts the N ranks itself (fresh child processes,
+spawned before anything touches the GPU; non-zero exit if a rank fails).  Under
+`python -m torch.distributed.run ... bench.py --gpus N` the ranks come from the environment.
 
 One STEP = one frame of the hot path with inputs resident in HBM:
-    ICP refinement   20 point-to-plane iterations (early exit disabled), 368,640 scene
-                     points against the 50,000 model vertices                (pedp_icp)
-    ray projection   368,640 camera rays against all 100,000 triangles       (pedp_raycast)
-The two stages are independent (scene cloud vs mesh), so each runs on its own context and HIP
+    ICP refinement   20 point-to-plane iterations (early exit disabled), 368,640 scene points
+                     against the 50,000 model vertices                         (pedp_icp)
+    ray projection   368,640 camera rays against all 100,000 triangles          (pedp_raycast)
+The two stages are independent (scene cloud vs mesh): each runs on its own context and HIP
 stream and they overlap on the device; a step ends when both have finished.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), weak scaling -- every
-rank processes its own frame, then the ranks all-gather their hit records (t_hit, id) on the
-ray stream.
 
-`value` is whole-job rays per second over the WHOLE step (ICP time included), i.e. frames/s
-x rays per frame; the per-stage rates are reported next to it.  The JSON line also carries
-`roofline` (the step's dominant kernel, the MFMA nearest-neighbour sweep, at the all-pairs
-per-iteration workload), `roofline_ray_sweep` (the exhaustive every-ray-x-every-triangle
-sweep, the kernel north_star's target is set on; algorithmic FLOPs per launch / HIP-event
-kernel time), `roofline_hbm_stream` (north_star's triangle-stream accounting) and
-`cpu_baseline` (the CPU oracle: BVH rays + KD-tree ICP on this host's cores, one full step).
+N > 1, --mode shard (default; SURVEY s8e, north_star): ONE frame is split over the ranks --
+rays in contiguous blocks with an all-gather of the 8-byte hit records, scene points in
+contiguous blocks with one 29-double all-reduce per correspondence pass; the collectives are
+issued by the library on its own streams (RCCL over xGMI).  Total work is fixed: strong scaling.
+--mode replica: every rank processes its own whole frame, no collective (weak scaling); in shard
+mode the replica rate of the same ranks is measured too and reported under "replica".
+
+Timed regions, each bracketed by barrier + synchronize, max over ranks:
+    headline     K steps of the default path (culled ray stage, block-sparse ICP)  -> value
+    exhaustive   a few steps of the all-pairs path north_star's targets are set on: every ray x
+                 every triangle (sweep variant 1) and every scene point x every model point in
+                 every ICP pass (pedp_icp_configure(exhaustive))                    -> "exhaustive"
+Every `roofline*` entry describes a kernel AS IT RUNS in the region it names, timed there with
+the library's HIP events on the launch stream; kernel_ms x launches_per_step <= that region's
+ms_per_step.  `cpu_baseline`: the CPU oracle (BVH rays + KD-tree ICP built once per
+registration, radius-bounded search) on this host's cores, median of 10 steps after 2 warm-ups,
+rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,8 +47,10 @@ if ROOT not in sys.path:
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector == f32-MFMA dense peak
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TEST = 46        # Moeller-Trumbore with stored (v0, e1, e2)
+FLOP_PER_TEST_EXECUTED = 21  # shared-origin form: three dot products + the inside test per triangle
 FLOP_PER_PAIR = 8         # one K=4 fp32 MFMA dot per (scene, model) pair
 ICP_ITERS = 20
+TIMED_PASS = 1            # the correspondence pass whose sweep kernel carries the HIP events
 
 
 def parse():
@@ -43,36 +59,84 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="bench_100k")
+    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exhaustive / batched / 1M-triangle regions")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """Start one fresh process per GPU.  Nothing in this process has touched the GPU (torch is
+    not even imported), the children are ordinary subprocesses, and the exit code is non-zero
+    if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(len(procs)))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()   # exact children of this process, by handle
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def cpu_baseline(frame, depth):
     """The oracle as CPU baseline ("port"): BVH closest hit (build included, like the
-    reference's per-call add_triangles) + KD-tree point-to-plane ICP, all host cores, one
-    full step of the same workload."""
+    reference's per-call add_triangles) + KD-tree point-to-plane ICP (tree built once per
+    registration like registration_icp, search bounded by the correspondence radius), all host
+    cores, whole steps of the same workload; median of 10 after 2 warm-ups."""
+    import numpy as np
+
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pedp_oracle as oracle
 
     cores = os.cpu_count() or 1
     scene = frame.scene(depth)
-    t0 = time.perf_counter()
-    oracle.raycast(frame.verts_posed, frame.tris, frame.rays6, nthreads=cores, bvh=True)
-    t1 = time.perf_counter()
-    oracle.icp(scene, frame.model_points, frame.normals, frame.max_correspondence_distance, frame.icp_init(),
-               max_iter=ICP_ITERS, rel_fitness=-1, rel_rmse=-1, kdtree=True, nthreads=cores, want_trace=False)
-    t2 = time.perf_counter()
-    step = t2 - t0
+    ray_s, icp_s = [], []
+    for k in range(12):
+        t0 = time.perf_counter()
+        oracle.raycast(frame.verts_posed, frame.tris, frame.rays6, nthreads=cores, bvh=True)
+        t1 = time.perf_counter()
+        oracle.icp(scene, frame.model_points, frame.normals, frame.max_correspondence_distance, frame.icp_init(),
+                   max_iter=ICP_ITERS, rel_fitness=-1, rel_rmse=-1, kdtree=True, nthreads=cores, want_trace=False)
+        t2 = time.perf_counter()
+        if k >= 2:
+            ray_s.append(t1 - t0)
+            icp_s.append(t2 - t1)
+        if t2 - t0 > 15.0 and k >= 4:   # a slow host: stay within the sample budget
+            break
+    step = float(np.median(np.array(ray_s) + np.array(icp_s)))
     return {
         "value": frame.n_rays / step / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": f"1 full step: BVH build+cast of {frame.n_rays} rays x {frame.n_tris} tris ({t1 - t0:.2f} s) + "
-                  f"{ICP_ITERS}-iteration KD-tree ICP ({t2 - t1:.2f} s), OpenMP x{cores}",
-        "ray_mrays_per_s": frame.n_rays / (t1 - t0) / 1e6, "icp_iters_per_s": ICP_ITERS / (t2 - t1),
+        "sample": f"median of {len(ray_s)} whole steps after 2 warm-ups: BVH build + cast of {frame.n_rays} rays x "
+                  f"{frame.n_tris} tris (median {np.median(ray_s):.3f} s) + {ICP_ITERS}-iteration KD-tree ICP, tree built "
+                  f"once per registration, search bounded by the radius (median {np.median(icp_s):.3f} s), OpenMP x{cores}",
+        "ray_mrays_per_s": frame.n_rays / float(np.median(ray_s)) / 1e6,
+        "icp_iters_per_s": ICP_ITERS / float(np.median(icp_s)),
+        "note": "restatement of the Open3D/Embree algorithms (oracle/), not Open3D itself: context, not a target",
     }
 
 
-def main():
-    args = parse()
+def run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -80,170 +144,271 @@ def main():
     from pedp_hip import dist as pdist
 
     rank, world, local = pdist.init_from_env("nccl")
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong N",
+                  file=sys.stderr)
+        return 2
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    # Explicit HIP streams shared by the library's kernels AND the collectives (torch's default
-    # stream has handle 0 = "library creates its own stream", which NCCL would not order with).
-    # The two stages of a step are independent (ICP works on the scene cloud, the ray stage on the
-    # mesh), so each gets its own context and stream and they overlap on the device.
-    stream = torch.cuda.Stream(device=dev)
-    ctx = _lib.Context(local, stream=stream.cuda_stream)          # ICP
-    ray_stream = torch.cuda.Stream(device=dev)
-    ray_ctx = _lib.Context(local, stream=ray_stream.cuda_stream)  # ray stage + all-gather of its records
+    mode = "single" if world == 1 else args.mode
+    # Explicit HIP streams shared by the library's kernels AND the collectives.  The two stages of
+    # a step are independent (ICP works on the scene cloud, the ray stage on the mesh), so each
+    # gets its own context and stream and they overlap on the device.
+    icp_be = pdist.HipBackend(local)
+    ray_be = pdist.HipBackend(local)
+    ctx, ray_ctx = icp_be.ctx, ray_be.ctx
+    native = False
+    if world > 1:
+        native = bool(icp_be.init_comm()) & bool(ray_be.init_comm())
 
     frame = synth.Frame(args.config)
     n_rays, n_tris = frame.n_rays, frame.n_tris
+    radius = frame.max_correspondence_distance
+    init = frame.icp_init()
+
+    # ---- whole frame resident on this rank (single / replica steps, rendering of the depth frame)
     mesh = _lib.Mesh(ray_ctx, frame.verts_posed, frame.tris)
-    rays = torch.from_numpy(frame.rays6).to(dev)
+    rays = ray_be.to_device(frame.rays6)
     t_hit = torch.empty(n_rays, dtype=torch.float32, device=dev)
     prim = torch.empty(n_rays, dtype=torch.int32, device=dev)
 
-    def cast():
+    def cast_full():
         mesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
 
-    cast()
-    torch.cuda.synchronize()
+    cast_full()
+    ray_ctx.synchronize()
     depth = t_hit.cpu().numpy()
     scene = frame.scene(depth)  # rendered by the HIP ray caster; noise from default_rng(0)
+    n_scene, n_model = len(scene), len(frame.model_points)
     src = _lib.Cloud(ctx, scene)
     tgt = _lib.Cloud(ctx, frame.model_points, frame.normals)
-    init = frame.icp_init()
-    gathered_t = torch.empty(world * n_rays, dtype=torch.float32, device=dev) if world > 1 else None
-    gathered_i = torch.empty(world * n_rays, dtype=torch.int32, device=dev) if world > 1 else None
+    icp_kw = dict(estimator=_lib.POINT_TO_PLANE, max_iteration=ICP_ITERS, relative_fitness=-1.0, relative_rmse=-1.0)
 
-    sweep_ms, icp_ms = [], []
+    # ---- the same frame sharded over the ranks (strong scaling)
+    sharded = None
+    if mode == "shard":
+        sharded = pdist.ShardedFrame(ray_be, frame.verts_posed, frame.tris, frame.rays6, scene, frame.model_points,
+                                     frame.normals, icp_backend=icp_be)
 
-    def step(record):
-        cast()                                     # enqueued on the ray stream, returns at once
+    def barrier():
         if world > 1:
-            with torch.cuda.stream(ray_stream):    # ordered behind the sweep on the same stream
-                dist.all_gather_into_tensor(gathered_t, t_hit)
-                dist.all_gather_into_tensor(gathered_i, prim)
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    icp_wall = [0.0]
+
+    def step_whole():
+        """Whole frame on this rank (N = 1, and the replica region)."""
+        cast_full()                                # enqueued on the ray stream, returns at once
         a = time.perf_counter()
-        res = _lib.icp(ctx, src, tgt, frame.max_correspondence_distance, init, estimator=_lib.POINT_TO_PLANE,
-                       max_iteration=ICP_ITERS, relative_fitness=-1.0, relative_rmse=-1.0)
-        b = time.perf_counter()
+        res = _lib.icp(ctx, src, tgt, radius, init, **icp_kw)   # returns after its stream has finished
+        icp_wall[0] = 1e3 * (time.perf_counter() - a)
         ray_ctx.synchronize()                      # the step ends when both stages have finished
-        if record:
-            icp_ms.append(1e3 * (b - a))           # pedp_icp returns after its stream sync
-            sweep_ms.append(_lib.raycast_last_sweep_ms(ray_ctx))  # HIP events around the sweep kernels
         return res
 
-    for _ in range(args.warmup):
-        step(False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def step_sharded():
+        sharded.cast()                             # this rank's ray block + all-gather, on the ray stream
+        a = time.perf_counter()
+        res = sharded.icp(init, radius, max_iteration=ICP_ITERS, rel_fitness=-1.0, rel_rmse=-1.0)
+        icp_wall[0] = 1e3 * (time.perf_counter() - a)
+        ray_ctx.synchronize()
+        return res
 
-    # ---- kernel-level measurements outside the timed region (same resident inputs) ----
+    def timed_region(step, steps, warmup):
+        """W warm-ups, then K steps between barrier + synchronize; returns (seconds max over ranks,
+        last result, per-step [icp wall ms, ray stage ms, timed sweep kernel ms])."""
+        for _ in range(warmup):
+            step()
+        rows = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+            # read-backs of HIP events already recorded on the streams (both streams are idle here)
+            rows.append((icp_wall[0], _lib.raycast_last_sweep_ms(ray_ctx), _lib.nn_last_sweep_ms(ctx)))
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0), res, np.array(rows)
+
+    step = step_sharded if mode == "shard" else step_whole
+    _lib.icp_configure(ctx, exhaustive=False, timed_pass=TIMED_PASS)
+    elapsed, res, rows = timed_region(step, args.steps, args.warmup)
     passes, pairs_swept, fb_points = _lib.icp_last_stats(ctx)
-    # (a) the all-pairs MFMA sweep at the SURVEY's per-iteration workload: every scene point x
-    #     every model point, no bounding-box culling (pedp_nn = one correspondence pass)
-    nn_ms = []
-    for _ in range(4):
-        _lib.nn(ctx, src, tgt, init)
-        nn_ms.append(_lib.nn_last_sweep_ms(ctx))
-    # (b) the exhaustive ray sweep: every ray x every triangle (variant 1), same frame
-    _lib.raycast_configure(ray_ctx, 0, 1)
-    brute_ms = []
-    for _ in range(4):
-        cast()
-        brute_ms.append(_lib.raycast_last_sweep_ms(ray_ctx))
-    _lib.raycast_configure(ray_ctx, 0, 0)
-    # (c) BASELINE config 3 in small: 32 start poses refined concurrently (pedp_icp_batched)
-    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(32)])
-    batch_s = []
-    for _ in range(3):
-        tb = time.perf_counter()
-        _lib.icp_batched(ctx, src, tgt, frame.max_correspondence_distance, inits, max_iteration=ICP_ITERS)
-        batch_s.append(time.perf_counter() - tb)
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    extras = {}
+    if not args.no_extras:
+        # ---- exhaustive region: the all-pairs path, same resident inputs, same sharding
+        ex_steps = max(2, min(args.steps, 4))
+        _lib.raycast_configure(ray_ctx, 0, 1)
+        _lib.icp_configure(ctx, exhaustive=True, timed_pass=TIMED_PASS)
+        try:
+            ex_elapsed, ex_res, ex_rows = timed_region(step, ex_steps, 1)
+            ex_passes, ex_pairs, _ = _lib.icp_last_stats(ctx)
+        finally:
+            _lib.raycast_configure(ray_ctx, 0, 0)
+            _lib.icp_configure(ctx, exhaustive=False, timed_pass=TIMED_PASS)
+        extras["exhaustive"] = (ex_steps, ex_elapsed, ex_res, ex_rows, ex_passes, ex_pairs)
+        # ---- replica region (N > 1): every rank its own whole frame, no collective
+        if mode == "shard":
+            rp_elapsed, _, rp_rows = timed_region(step_whole, args.steps, 1)
+            extras["replica"] = (rp_elapsed, rp_rows)
+        # ---- BASELINE config 3 in small: 32 start poses refined concurrently, poses sharded over the ranks
+        inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(32)])
+        lo, hi = pdist.shard_bounds(len(inits), rank, world)
+        batch_s = []
+        for _ in range(3):
+            barrier()
+            tb = time.perf_counter()
+            if hi > lo:
+                _lib.icp_batched(ctx, src, tgt, radius, inits[lo:hi], max_iteration=ICP_ITERS)
+            barrier()
+            batch_s.append(max_over_ranks(time.perf_counter() - tb))
+        extras["batched"] = (len(inits), min(batch_s))
+        # ---- BASELINE config 4: 1M-triangle mesh, 1280x720 dense frame, rays sharded + all-gather
+        if args.config == "bench_100k":
+            big = synth.Frame("bench_1m")
+            bf = pdist.ShardedFrame(ray_be, big.verts_posed, big.tris, big.rays6)
+            for _ in range(2):
+                bf.cast()
+            barrier()
+            tb = time.perf_counter()
+            for _ in range(5):
+                bf.cast()
+                ray_ctx.synchronize()
+            barrier()
+            extras["bench_1m"] = (big.n_rays, big.n_tris, max_over_ranks(time.perf_counter() - tb) / 5,
+                                  _lib.raycast_last_sweep_ms(ray_ctx))
+            del bf, big
 
     if rank == 0:
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, tools/pmc_target.py + tools/summarize_pmc.py)
         traffic = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                traffic = json.load(fh)
-        except OSError:
-            pass
-        ms_per_step = 1e3 * elapsed / args.steps
-        ray_stage = float(np.mean(sweep_ms))
-        icp_mean = float(np.mean(icp_ms))
-        tests = float(n_rays) * n_tris
-        brute = float(np.median(brute_ms[1:]))
-        stream_bytes = -(-n_rays // 64) * n_tris * 36.0
-        nn = float(np.median(nn_ms[1:]))
-        pairs = float(len(scene)) * len(frame.model_points)
-        nn_tflops = FLOP_PER_PAIR * pairs / (nn * 1e-3) / 1e12
+        for name in ("r02_traffic.json", "r01_traffic.json"):   # PMC passes committed under profiles/
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    traffic = json.load(fh)
+                break
+            except OSError:
+                pass
+        icp_ms, ray_ms, sweep_ms = (float(v) for v in rows.mean(axis=0))
+        n_pass = max(passes, 1)
+        pairs_pass = pairs_swept / n_pass
+        sweep_tflops = FLOP_PER_PAIR * pairs_pass / (sweep_ms * 1e-3) / 1e12
+        par = {"single": "one GPU; ray stage and ICP of a step overlap on two HIP streams",
+               "shard": f"one frame sharded over {world} GPUs: contiguous ray blocks + all-gather of hit records, scene "
+                        f"shards + one 29-double all-reduce per pass ({'library-issued RCCL' if native else 'torch.distributed'})",
+               "replica": f"{world} GPUs, each its own whole frame, no collective"}[mode]
+        frames_per_step = world if mode == "replica" else 1
         out = {
             "metric": "Mrays/s ray-mesh + ICP iters/s, 640x576 vs 100k-tri mesh",
-            "value": world * n_rays * args.steps / elapsed / 1e6,
+            "value": frames_per_step * n_rays * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if mode == "replica" else "strong", "vs_baseline": None,
             "dtype": "f32 rays / f64 ICP (f32 MFMA filter)", "data": "synthetic",
             "config": {"workload": f"{args.config}: {frame.width}x{frame.height} frame, {n_rays} rays x {n_tris} "
-                                   f"triangles + {ICP_ITERS}-iteration point-to-plane ICP ({len(scene)} scene x "
-                                   f"{len(frame.model_points)} model points) per step",
-                       "parallelism": f"frames sharded over {world} GPU(s), all-gather of hit records; ray stage and ICP of a "
-                                      "step overlap on two HIP streams"},
-            "ray_stage_ms": ray_stage, "ray_stage_mrays_per_s": n_rays / (ray_stage * 1e-3) / 1e6,
-            "icp_ms": icp_mean, "icp_iters_per_s": ICP_ITERS / (icp_mean * 1e-3),
-            "icp_batched_ms_per_registration": 1e3 * min(batch_s) / len(inits),
-            "icp_batched_iters_per_s": ICP_ITERS * len(inits) / min(batch_s),
-            "icp_passes": passes, "icp_pairs_swept_per_pass": pairs_swept / max(passes, 1),
-            "icp_fallback_points_per_pass": fb_points / max(passes, 1),
+                                   f"triangles + {ICP_ITERS}-iteration point-to-plane ICP ({n_scene} scene x "
+                                   f"{n_model} model points) per step",
+                       "parallelism": par, "mode": mode},
+            "ray_stage_ms": ray_ms, "ray_stage_mrays_per_s": (n_rays / world if mode == "shard" else n_rays) / (ray_ms * 1e-3) / 1e6,
+            "icp_ms": icp_ms, "icp_iters_per_s": ICP_ITERS / (icp_ms * 1e-3),
+            "icp_passes": passes, "icp_pairs_swept_per_pass": pairs_pass,
+            "icp_fallback_points_per_pass": fb_points / n_pass,
             "icp_fitness": res["fitness"], "icp_inlier_rmse": res["inlier_rmse"],
             "pose_error_vs_gt": float(np.abs(np.linalg.inv(res["T"]) - frame.T_gt).max()),
-            # dominant kernel of the step by time: the MFMA nearest-neighbour sweep
-            "roofline": {"kernel": "nn_sweep_kernel", "bound": "mfma", "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
-                         "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"), "kernel_ms": nn,
-                         "mfma_util_pmc": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
-                         "note": f"{FLOP_PER_PAIR} flop x {len(scene)} scene x {len(frame.model_points)} model points "
-                                 "(all pairs, one correspondence pass) / HIP-event duration of the sweep kernel; "
-                                 "inside a step the same kernel runs on the bounding-box survivors only "
-                                 "(icp_pairs_swept_per_pass)"},
-            # the exhaustive ray sweep (variant 1: every ray x every triangle), SURVEY s8d accounting
-            "roofline_ray_sweep": {"kernel": "ray_sweep_rpl_kernel<shared origin>", "bound": "valu_fp32",
-                                   "achieved": FLOP_PER_TEST * tests / (brute * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": FLOP_PER_TEST * tests / (brute * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                                   "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"),
-                                   "kernel_ms": brute, "mrays_per_s": n_rays / (brute * 1e-3) / 1e6,
-                                   "executed_tflops": 21.0 * tests / (brute * 1e-3) / 1e12,
-                                   "note": f"{FLOP_PER_TEST} algorithmic flop per test (SURVEY s8d); the shared-origin "
-                                           "kernel hoists the origin-dependent terms per triangle and executes 21 "
-                                           "flop per test, hence frac can exceed 1; the step itself uses the culled "
-                                           "variant (ray_stage_ms)"},
-            "roofline_hbm_stream": {"bound": "hbm", "achieved": stream_bytes / (brute * 1e-3) / 1e9,
-                                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": stream_bytes / (brute * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                    "note": "north_star accounting on the exhaustive sweep: ceil(N_r/64) x N_f x 36 B "
-                                            "triangle stream per launch; the records are L2-resident, real HBM traffic "
-                                            "is about the compulsory 15 MB"},
+            # dominant kernel of the HEADLINE step as it runs there (rank 0's share in shard mode)
+            "roofline": {"kernel": "nn_sweep_kernel (in-step, culled)", "region": "headline", "bound": "mfma",
+                         "achieved": sweep_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": sweep_tflops / PEAK_FP32_TFLOPS,
+                         "traffic": traffic.get("nn_sweep_kernel_in_step", {}).get("hbm_bytes_per_launch"),
+                         "mfma_util_pmc": traffic.get("nn_sweep_kernel_in_step", {}).get("mfma_util"),
+                         "kernel_ms": sweep_ms, "launches_per_step": passes,
+                         "kernel_ms_x_launches": sweep_ms * passes, "region_ms_per_step": ms_per_step,
+                         "note": f"{FLOP_PER_PAIR} flop x {pairs_pass:.4g} (scene slot, model point) pairs the kernel swept in "
+                                 f"one pass / HIP-event duration of that launch (pass {TIMED_PASS} of every registration "
+                                 "of the timed loop, mean); the step is a latency-bound chain of short launches, the "
+                                 "kernel is far from MFMA-bound at this size"},
         }
+        if "exhaustive" in extras:
+            ex_steps, ex_elapsed, ex_res, ex_rows, ex_passes, ex_pairs = extras["exhaustive"]
+            ex_ms = 1e3 * ex_elapsed / ex_steps
+            _, ex_ray_ms, ex_sweep_ms = (float(v) for v in ex_rows.mean(axis=0))
+            share = (1.0 / world) if mode == "shard" else 1.0
+            tests = float(n_rays) * n_tris * share                      # this rank's ray block x all triangles
+            pairs = float(n_scene) * n_model * share                    # this rank's scene shard x all model points
+            nn_tflops = FLOP_PER_PAIR * pairs / (ex_sweep_ms * 1e-3) / 1e12
+            ray_exec = FLOP_PER_TEST_EXECUTED * tests / (ex_ray_ms * 1e-3) / 1e12
+            ray_algo = FLOP_PER_TEST * tests / (ex_ray_ms * 1e-3) / 1e12
+            stream_bytes = -(-int(n_rays * share) // 64) * n_tris * 36.0
+            hbm_frac = stream_bytes / (ex_ray_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            out["exhaustive"] = {
+                "steps": ex_steps, "ms_per_step": ex_ms, "value_mrays_per_s": n_rays * ex_steps / ex_elapsed / 1e6,
+                "ray_stage_ms": ex_ray_ms, "icp_iters_per_s": ICP_ITERS * ex_steps / ex_elapsed,
+                "icp_passes": ex_passes, "icp_pairs_swept_per_pass": ex_pairs / max(ex_passes, 1),
+                "pose_equals_headline": bool(np.abs(ex_res["T"] - res["T"]).max() < 1e-9),
+                "note": "every ray x every triangle (sweep variant 1) and every scene point x every model point in every "
+                        "ICP pass (culling off); same results as the headline path",
+            }
+            out["roofline_exhaustive_nn"] = {
+                "kernel": "nn_sweep_kernel<4,2> (all pairs)", "region": "exhaustive", "bound": "mfma",
+                "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
+                "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"),
+                "mfma_util_pmc": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
+                "kernel_ms": ex_sweep_ms, "launches_per_step": ex_passes, "kernel_ms_x_launches": ex_sweep_ms * ex_passes,
+                "region_ms_per_step": ex_ms,
+                "note": f"{FLOP_PER_PAIR} flop x {int(n_scene * share)} scene x {n_model} model points per launch (SURVEY s8d)"}
+            out["roofline_ray_sweep"] = {
+                "kernel": "ray_sweep_rpl_kernel<shared origin>", "region": "exhaustive", "bound": "valu_fp32",
+                "achieved": ray_exec, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ray_exec / PEAK_FP32_TFLOPS,
+                "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"),
+                "kernel_ms": ex_ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ex_ray_ms,
+                "region_ms_per_step": ex_ms, "mrays_per_s": n_rays * share / (ex_ray_ms * 1e-3) / 1e6,
+                "algorithmic_46flop_tflops": ray_algo, "algorithmic_46flop_frac": ray_algo / PEAK_FP32_TFLOPS,
+                "north_star_hbm_stream_gbs": stream_bytes / (ex_ray_ms * 1e-3) / 1e9, "north_star_hbm_stream_frac": hbm_frac,
+                "north_star_hbm_target_met": bool(hbm_frac >= 0.5),
+                "note": f"frac counts the {FLOP_PER_TEST_EXECUTED} flop per test the shared-origin kernel EXECUTES (the "
+                        f"origin-dependent terms are hoisted per triangle); the {FLOP_PER_TEST}-flop algorithmic figure of "
+                        "SURVEY s8d is the side field.  north_star's >= 50 % of the HBM roofline (triangle-stream "
+                        "accounting, ceil(N_r/64) x N_f x 36 B per launch) is NOT met: the records are L2-resident and "
+                        "the kernel is FP32-VALU-bound (SURVEY s0 D5)"}
+        if "replica" in extras:
+            rp_elapsed, rp_rows = extras["replica"]
+            out["replica"] = {"value_mrays_per_s": world * n_rays * args.steps / rp_elapsed / 1e6, "scaling": "weak",
+                              "ms_per_step": 1e3 * rp_elapsed / args.steps,
+                              "note": "every rank its own whole frame, no collective (not the headline)"}
+        if "batched" in extras:
+            nb, sec = extras["batched"]
+            out["icp_batched"] = {"poses": nb, "ms_per_registration": 1e3 * sec / nb,
+                                  "iters_per_s": ICP_ITERS * nb / sec,
+                                  "note": f"pedp_icp_batched, poses in contiguous blocks over {world} rank(s)"}
+        if "bench_1m" in extras:
+            br, bt, bsec, bsweep = extras["bench_1m"]
+            out["bench_1m"] = {"workload": f"{br} rays x {bt} triangles (BASELINE config 4), ray stage only",
+                               "ms_per_frame": 1e3 * bsec, "mrays_per_s": br / bsec / 1e6, "sweep_ms_rank0": bsweep,
+                               "parallelism": f"rays in {world} contiguous block(s)" + (" + all-gather" if world > 1 else "")}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(frame, depth)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

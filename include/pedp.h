@@ -34,7 +34,7 @@ typedef enum {
     PEDP_ERR_NO_NORMALS = -2, /* point-to-plane needs target normals (Open3D raises) */
     PEDP_ERR_HIP = -3,
     PEDP_ERR_ALLOC = -4,
-    PEDP_ERR_COLLECTIVE = -5 /* the caller's all-reduce hook failed */
+    PEDP_ERR_COLLECTIVE = -5 /* the caller's all-reduce hook or an RCCL call failed */
 } pedp_status;
 
 enum { PEDP_HOST = 0, PEDP_DEVICE = 1 };
@@ -215,6 +215,8 @@ typedef struct {
     pedp_allreduce_fn allreduce; /* NULL on one GPU */
     void *allreduce_user;
     int64_t n_source_global; /* fitness denominator when the scene is sharded; 0 = local N */
+    int use_comm;            /* 1: sum the packet over the ranks of the context's own RCCL
+                                communicator (pedp_comm_create) on the stream, no host hook */
 } pedp_icp_params;
 
 /* init / T_out: row-major 4x4 float64, source -> target (scene -> model), host memory.
@@ -239,13 +241,40 @@ int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
  * distance, float64-exact (ties: lowest index).  idx/d2: host arrays, length N. */
 int pedp_nn(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const double T[16],
             int32_t *idx, double *d2);
+/* Milliseconds of the last TIMED MFMA sweep kernel on this context (HIP events on the stream,
+ * directly around the kernel): the sweep of pedp_nn, or of the pass selected by pedp_icp_configure. */
 int pedp_nn_last_sweep_ms(pedp_ctx_t ctx, float *ms);
+
+/* Measurement knobs of pedp_icp / pedp_icp_batched on this context.
+ *   exhaustive = 1: no culling -- every scene point stays a candidate and the MFMA kernel sweeps
+ *     every (scene point, target point) pair in every pass (the all-pairs workload of SURVEY s8d);
+ *     correspondences and poses are identical to the culled run, only the work differs.
+ *   timed_pass >= 0: record HIP events around the sweep kernel of that correspondence pass (read
+ *     with pedp_nn_last_sweep_ms); -1 = none. */
+int pedp_icp_configure(pedp_ctx_t ctx, int exhaustive, int timed_pass);
 
 /* Work statistics of the last pedp_icp on this context: correspondence passes run, (scene,
  * target) pairs the MFMA sweep evaluated (scene points farther than the radius from the
  * target's bounding box are dropped before the sweep), and points whose fp32 filter was
  * ambiguous and went through the exact float64 brute-force kernel. */
 int pedp_icp_last_stats(pedp_ctx_t ctx, int64_t *passes, int64_t *pairs_swept, int64_t *fallback_points);
+
+/* ---------------------------------------------------------------- multi-GPU collectives
+ * One process per GPU.  The reference has no distributed path; these entry points
+ * exist so that the two exchange steps of the sharded path run inside the library, on
+ * the context's stream, over RCCL/xGMI: the all-gather of the ray shards' hit records and the
+ * per-pass all-reduce of the ICP packet (pedp_icp_params.use_comm).  RCCL is bound at run time.
+ * Rendezvous is the host's business: rank 0 makes the id, the host side hands the same 128 bytes
+ * to every rank (pedp_hip.dist does it through torch.distributed), every rank calls create. */
+enum { PEDP_COMM_ID_BYTES = 128 };
+int pedp_comm_unique_id(uint8_t id[PEDP_COMM_ID_BYTES]);
+int pedp_comm_create(pedp_ctx_t ctx, const uint8_t id[PEDP_COMM_ID_BYTES], int nranks, int rank);
+int pedp_comm_destroy(pedp_ctx_t ctx);
+int pedp_comm_size(pedp_ctx_t ctx, int *nranks, int *rank);
+/* Device pointers; only enqueue on the context's stream.  allgather: every rank contributes
+ * bytes_per_rank bytes, recv holds nranks * bytes_per_rank in rank order. */
+int pedp_comm_allgather(pedp_ctx_t ctx, const void *send, void *recv, int64_t bytes_per_rank);
+int pedp_comm_allreduce_f64(pedp_ctx_t ctx, double *buf, int64_t n);
 
 /* ---------------------------------------------------------------- cluster_poses
  * Replaces mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68; caller

@@ -352,6 +352,50 @@ static void kd_search(const kd_t *t, int32_t ni, const double *q, double mind, d
     }
 }
 
+static void kd_create(kd_t *t, const double *tgt, int64_t Nt) {
+    t->nodes = (kd_node *)malloc(sizeof(kd_node) * (size_t)(2 * Nt + 2));
+    t->perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Nt > 0 ? Nt : 1));
+    t->n_nodes = 0;
+    t->pts = tgt;
+    for (int k = 0; k < 3; ++k) { t->lo[k] = INFINITY; t->hi[k] = -INFINITY; }
+    for (int64_t i = 0; i < Nt; ++i) {
+        t->perm[i] = (int32_t)i;
+        for (int k = 0; k < 3; ++k) {
+            if (tgt[3 * i + k] < t->lo[k]) t->lo[k] = tgt[3 * i + k];
+            if (tgt[3 * i + k] > t->hi[k]) t->hi[k] = tgt[3 * i + k];
+        }
+    }
+    kd_build_rec(t, 0, (int32_t)Nt);
+}
+
+static void kd_destroy(kd_t *t) {
+    free(t->nodes);
+    free(t->perm);
+}
+
+/* All queries against a built tree.  bound = INFINITY: plain 1-NN (KDTreeFlann::SearchHybrid's knn
+ * step).  A finite bound (r^2) starts every search with that as the best distance, so cells that
+ * cannot hold a point closer than r are never opened and a query without such a point returns
+ * (-1, inf): the same correspondences as searching everything and applying d^2 < r^2 afterwards
+ * (the acceptance test stays strict, ties inside the bound are never pruned). */
+static void kd_query_all(const kd_t *t, const double *src, int64_t Ns, int32_t *idx, double *d2, double bound) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < Ns; ++i) {
+        const double *q = src + 3 * i;
+        double dists[3], mind = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            double e = q[k] < t->lo[k] ? t->lo[k] - q[k] : (q[k] > t->hi[k] ? q[k] - t->hi[k] : 0.0);
+            dists[k] = e * e;
+            mind += dists[k];
+        }
+        double best = bound;
+        int32_t bi = 0x7FFFFFFF;
+        if (!(mind * (1.0 - 1e-12) > best)) kd_search(t, 0, q, mind, dists, &best, &bi);
+        if (bi == 0x7FFFFFFF) { idx[i] = -1; d2[i] = INFINITY; }
+        else { idx[i] = bi; d2[i] = best; }
+    }
+}
+
 void pedp_oracle_nn_kdtree(const double *src, int64_t Ns, const double *tgt, int64_t Nt,
                            int32_t *idx, double *d2, int nthreads) {
 #ifdef _OPENMP
@@ -364,36 +408,9 @@ void pedp_oracle_nn_kdtree(const double *src, int64_t Ns, const double *tgt, int
         return;
     }
     kd_t t;
-    t.nodes = (kd_node *)malloc(sizeof(kd_node) * (size_t)(2 * Nt + 2));
-    t.perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)Nt);
-    t.n_nodes = 0;
-    t.pts = tgt;
-    for (int k = 0; k < 3; ++k) { t.lo[k] = INFINITY; t.hi[k] = -INFINITY; }
-    for (int64_t i = 0; i < Nt; ++i) {
-        t.perm[i] = (int32_t)i;
-        for (int k = 0; k < 3; ++k) {
-            if (tgt[3 * i + k] < t.lo[k]) t.lo[k] = tgt[3 * i + k];
-            if (tgt[3 * i + k] > t.hi[k]) t.hi[k] = tgt[3 * i + k];
-        }
-    }
-    kd_build_rec(&t, 0, (int32_t)Nt);
-#pragma omp parallel for schedule(dynamic, 256)
-    for (int64_t i = 0; i < Ns; ++i) {
-        const double *q = src + 3 * i;
-        double dists[3], mind = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            double e = q[k] < t.lo[k] ? t.lo[k] - q[k] : (q[k] > t.hi[k] ? q[k] - t.hi[k] : 0.0);
-            dists[k] = e * e;
-            mind += dists[k];
-        }
-        double best = INFINITY;
-        int32_t bi = 0x7FFFFFFF;
-        kd_search(&t, 0, q, mind, dists, &best, &bi);
-        idx[i] = bi;
-        d2[i] = best;
-    }
-    free(t.nodes);
-    free(t.perm);
+    kd_create(&t, tgt, Nt);
+    kd_query_all(&t, src, Ns, idx, d2, INFINITY);
+    kd_destroy(&t);
 }
 
 /* ------------------------------------------------------------------ registration_icp */
@@ -405,13 +422,14 @@ typedef struct {
 
 /* GetRegistrationResultAndCorrespondences */
 static pass_result corr_pass(const double *pcd, int64_t Ns, const double *tgt, int64_t Nt, double r,
-                             int32_t *idx, double *d2, int use_kdtree, int nthreads) {
+                             int32_t *idx, double *d2, const kd_t *tree, int nthreads) {
     pass_result res = {0.0, 0.0, 0};
     if (r <= 0.0 || Ns == 0 || Nt == 0) {
         for (int64_t i = 0; i < Ns; ++i) idx[i] = -1;
         return res;
     }
-    if (use_kdtree) pedp_oracle_nn_kdtree(pcd, Ns, tgt, Nt, idx, d2, nthreads);
+    /* the tree is built once per registration (registration_icp: kdtree.SetGeometry(target)) */
+    if (tree) kd_query_all(tree, pcd, Ns, idx, d2, r * r);
     else pedp_oracle_nn(pcd, Ns, tgt, Nt, idx, d2, nthreads);
     double r2 = r * r, err = 0.0;
     int64_t K = 0;
@@ -494,7 +512,10 @@ int pedp_oracle_icp(const double *src, int64_t Ns, const double *tgt, const doub
     if (is_identity) memcpy(pcd, src, sizeof(double) * 3 * (size_t)Ns);
     else pedp_oracle_transform(init, src, Ns, pcd);
 
-    pass_result res = corr_pass(pcd, Ns, tgt, Nt, max_corr_dist, idx, d2, use_kdtree, nthreads);
+    kd_t tree_s;
+    const kd_t *tree = NULL;
+    if (use_kdtree && Nt > 0) { kd_create(&tree_s, tgt, Nt); tree = &tree_s; }
+    pass_result res = corr_pass(pcd, Ns, tgt, Nt, max_corr_dist, idx, d2, tree, nthreads);
     if (trace) { trace[0] = res.fitness; trace[1] = res.rmse; memcpy(trace + 2, T, sizeof(T)); }
     int it = 0;
     for (; it < max_iter; ++it) {
@@ -504,7 +525,7 @@ int pedp_oracle_icp(const double *src, int64_t Ns, const double *tgt, const doub
         mat4_mul(upd, T, T);
         pedp_oracle_transform(upd, pcd, Ns, pcd);
         pass_result prev = res;
-        res = corr_pass(pcd, Ns, tgt, Nt, max_corr_dist, idx, d2, use_kdtree, nthreads);
+        res = corr_pass(pcd, Ns, tgt, Nt, max_corr_dist, idx, d2, tree, nthreads);
         if (trace) {
             double *tr = trace + 18 * (it + 1);
             tr[0] = res.fitness; tr[1] = res.rmse; memcpy(tr + 2, T, sizeof(T));
@@ -519,6 +540,7 @@ int pedp_oracle_icp(const double *src, int64_t Ns, const double *tgt, const doub
     if (inlier_rmse) *inlier_rmse = res.rmse;
     if (n_iter_done) *n_iter_done = it;
     if (corr) memcpy(corr, idx, sizeof(int32_t) * (size_t)Ns);
+    if (tree) kd_destroy(&tree_s);
     free(pcd); free(d2); free(idx);
     return 0;
 }

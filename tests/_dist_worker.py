@@ -39,6 +39,13 @@ class OracleBackend:
     def packet_tensor(self, ptr, n):
         return self.torch.from_numpy(ptr)      # "device pointer" = the numpy packet itself
 
+    def icp_batched(self, src, tgt, radius, inits, estimator, max_iteration):
+        """pedp_icp_batched's contract: B independent registrations, no early exit."""
+        rs = [self.o.icp(src[0], tgt[0], tgt[1], radius, T0, max_iter=max_iteration, rel_fitness=-1, rel_rmse=-1)
+              for T0 in inits]
+        return (np.stack([r["T"] for r in rs]), np.array([r["fitness"] for r in rs]),
+                np.array([r["inlier_rmse"] for r in rs]))
+
     def icp(self, src, tgt, radius, init, estimator, max_iteration, rel_fitness, rel_rmse, allreduce, n_global):
         """Per-pass protocol of pedp_icp: local packet (29 doubles, same layout) -> hook ->
         every rank solves the same system."""
@@ -93,8 +100,26 @@ def main(rank, world, port, out_dir, hip=False):
     g = np.load(os.path.join(ROOT, "tests", "golden", "g3g4_icp_traces.npz"))
     res = pdist.sharded_registration_icp(be, g["scene_noisy"][:-5], g["model"], g["normals"], 10.0, g["init"],
                                          max_iteration=6, rel_fitness=-1, rel_rmse=-1)
+    # 5 start poses over 2 ranks (3 + 2), one final all-gather
+    rng = np.random.default_rng(3)
+    inits = np.empty((5, 4, 4))
+    for b in range(5):
+        D = np.eye(4)
+        D[:3, :3] = synth.axis_angle(rng.normal(size=3), np.deg2rad(2.0) * rng.uniform())
+        D[:3, 3] = rng.uniform(-1, 1, 3)
+        inits[b] = D @ g["init"]
+    bT, bfit, brmse = pdist.sharded_icp_batched(be, g["scene_noisy"], g["model"], g["normals"], 10.0, inits, max_iteration=4)
+    # device-resident sharded frame (bench.py's form) on the product backend
+    extra = {}
+    if hip:
+        native = be.init_comm()          # gloo group: no RCCL possible with two ranks on one GPU -> stays False
+        sf = pdist.ShardedFrame(be, f.verts_posed, f.tris, rays, g["scene_noisy"][:-5], g["model"], g["normals"])
+        sf.cast()
+        st, sid = sf.hits()
+        sres = sf.icp(g["init"], 10.0, max_iteration=6, rel_fitness=-1, rel_rmse=-1)
+        extra = dict(native=native, st=st, sid=sid, sT=sres["T"], sfit=sres["fitness"])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), t=t_all, ids=id_all, T=res["T"], fitness=res["fitness"],
-             rmse=res["inlier_rmse"], iters=res["iters"])
+             rmse=res["inlier_rmse"], iters=res["iters"], bT=bT, bfit=bfit, brmse=brmse, binits=inits, **extra)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -250,7 +250,76 @@ def test_two_ranks_on_one_gpu_product_backend(oracle, tmp_path):
         assert np.array_equal(r["ids"], ref["primitive_ids"]) and np.array_equal(r["t"].view(np.uint32), ref["t_hit"].view(np.uint32))
         assert float(r["fitness"]) == ricp["fitness"] and int(r["iters"]) == 6
         assert np.abs(r["T"] - ricp["T"]).max() < 1e-5
+        # the device-resident sharded frame (bench.py's form) gives the same frame and pose
+        assert np.array_equal(r["sid"], ref["primitive_ids"]) and np.array_equal(r["st"].view(np.uint32), ref["t_hit"].view(np.uint32))
+        assert float(r["sfit"]) == ricp["fitness"] and np.abs(r["sT"] - ricp["T"]).max() < 1e-5
+        assert not bool(r["native"])             # two ranks on one GPU: RCCL refuses, torch collectives stay
     assert np.array_equal(r0["T"], r1["T"])      # every rank holds the identical pose
+    assert np.array_equal(r0["sT"], r1["sT"])
+    # batched-pose sharding: both ranks hold all 5 results, equal to single calls bit for bit
+    from pedp_hip import _lib
+    ctx = _lib.default_context()
+    src, tgt = _lib.Cloud(ctx, g["scene_noisy"]), _lib.Cloud(ctx, g["model"], g["normals"])
+    assert np.array_equal(r0["bT"], r1["bT"]) and np.array_equal(r0["bfit"], r1["bfit"])
+    for b in range(5):
+        one = _lib.icp(ctx, src, tgt, 10.0, r0["binits"][b], max_iteration=4, relative_fitness=-1, relative_rmse=-1)
+        assert np.array_equal(r0["bT"][b], one["T"]) and r0["bfit"][b] == one["fitness"] and r0["brmse"][b] == one["inlier_rmse"]
+
+
+def test_native_rccl_communicator_single_rank(oracle):
+    """The library's own RCCL communicator (pedp_comm_create, dlopen'ed librccl) on one GPU: a
+    one-rank communicator carries the all-gather of the hit records and the per-pass all-reduce
+    of the ICP packet (pedp_icp_params.use_comm) on the library's stream, no Python in between."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import _lib
+    from pedp_hip import dist as pdist
+
+    f = _frame()
+    be = pdist.HipBackend(0)
+    assert be.init_comm(force=True) and be.native
+    assert _lib.comm_size(be.ctx) == (1, 0)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    for _ in range(3):
+        t, ids = pdist.sharded_cast_rays(be, f.verts_posed, f.tris, f.rays6, always_collective=True)
+        assert np.array_equal(ids, ref["primitive_ids"]) and np.array_equal(t.view(np.uint32), ref["t_hit"].view(np.uint32))
+    scene = f.scene(ref["t_hit"])
+    ro = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=8, rel_fitness=-1, rel_rmse=-1)
+    for _ in range(3):
+        res = pdist.sharded_registration_icp(be, scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iteration=8,
+                                             rel_fitness=-1, rel_rmse=-1, always_collective=True)
+        assert res["fitness"] == ro["fitness"] and np.abs(res["T"] - ro["T"]).max() < 1e-5
+    # raw entry points on device buffers
+    x = torch.arange(29, dtype=torch.float64, device="cuda:0")
+    with be.ordered():
+        y = x.clone()
+    _lib.comm_allreduce_f64(be.ctx, y.data_ptr(), 29)
+    be.ctx.synchronize()
+    assert torch.equal(x, y)                         # sum over one rank
+    # use_comm without a communicator is an error, not a silent single-rank run
+    plain = _lib.default_context()
+    with pytest.raises(_lib.PedpError):
+        _lib.icp(plain, _lib.Cloud(plain, scene), _lib.Cloud(plain, f.model_points, f.normals), 10.0, f.icp_init(),
+                 max_iteration=1, use_comm=True)
+    _lib.comm_destroy(be.ctx)
+
+
+def test_sharded_icp_batched_single_rank(oracle):
+    """sharded_icp_batched on one GPU equals pedp_icp_batched (and the gather path keeps the bits)."""
+    pytest.importorskip("torch")
+    from pedp_hip import _lib, synth
+    from pedp_hip import dist as pdist
+
+    f = _frame()
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(6)])
+    be = pdist.HipBackend(0)
+    T, fit, rmse = pdist.sharded_icp_batched(be, scene, f.model_points, f.normals, 10.0, inits, max_iteration=5)
+    T2, fit2, rmse2 = _lib.icp_batched(be.ctx, be.make_cloud(scene), be.make_cloud(f.model_points, f.normals), 10.0, inits,
+                                       max_iteration=5)
+    assert np.array_equal(T, T2) and np.array_equal(fit, fit2) and np.array_equal(rmse, rmse2)
+    ro = oracle.icp(scene, f.model_points, f.normals, 10.0, inits[4], max_iter=5, rel_fitness=-1, rel_rmse=-1)
+    assert fit[4] == ro["fitness"] and np.abs(T[4] - ro["T"]).max() < 1e-5
 
 
 def test_icp_with_shuffled_subsampled_target(oracle):

@@ -41,3 +41,22 @@ def test_two_rank_sharding_matches_single_process(oracle, tmp_path):
         assert float(r["fitness"]) == ricp["fitness"] and int(r["iters"]) == 6
         assert np.abs(r["T"] - ricp["T"]).max() < 1e-9 and abs(float(r["rmse"]) - ricp["inlier_rmse"]) < 1e-9
     assert np.array_equal(r0["T"], r1["T"])      # every rank holds the identical pose
+    # batched-pose sharding: poses split 3 + 2, all-gather of 18 doubles per pose
+    for b in range(5):
+        one = oracle.icp(g["scene_noisy"], g["model"], g["normals"], 10.0, r0["binits"][b], max_iter=4, rel_fitness=-1,
+                         rel_rmse=-1)
+        for r in (r0, r1):
+            assert np.array_equal(r["bT"][b], one["T"]) and r["bfit"][b] == one["fitness"]
+            assert r["brmse"][b] == one["inlier_rmse"]
+
+
+def test_shard_bounds_cover_and_pad():
+    from pedp_hip import dist as pdist
+
+    for n in (0, 1, 7, 8, 9, 1917, 368640):
+        for world in (1, 2, 3, 8):
+            blocks = [pdist.shard_bounds(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert max(b - a for a, b in blocks) == pdist.shard_width(n, world)
+            assert max(b - a for a, b in blocks) - min(b - a for a, b in blocks) <= 1

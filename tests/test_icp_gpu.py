@@ -194,3 +194,66 @@ def test_device_resident_chain_depth_to_registration(ctx, oracle):
     assert c["fitness"] == ref["fitness"] and np.abs(c["T"] - ref["T"]).max() < 1e-5
     empty = _lib.Cloud.from_device(ctx, pts.data_ptr(), 0)
     assert _lib.icp(ctx, empty, tgt, 10.0, np.eye(4))["fitness"] == 0.0
+
+
+def test_batched_graph_is_not_replayed_on_recreated_clouds(oracle):
+    """pedp_icp_batched caches one captured hipGraph per sub-context.  A new cloud of the same size
+    can receive the address of a destroyed one, so the cache is keyed by a creation counter, not by
+    the handle: after closing both clouds and creating new ones of equal N with different data the
+    batch must equal the per-pose calls on the NEW data."""
+    from pedp_hip import _lib, synth
+
+    ctx = _lib.Context(0)
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(4)])
+    for seed in (0, 7, 11):                      # same sizes every round, different points
+        scene = synth.scene_from_depth(depth, f.dirs, seed=seed)
+        shift = np.array([0.3, -0.2, 0.1]) * seed
+        src, tgt = _lib.Cloud(ctx, scene + shift), _lib.Cloud(ctx, f.model_points, f.normals)
+        T, fit, rmse = _lib.icp_batched(ctx, src, tgt, 10.0, inits, max_iteration=4)
+        for b in range(4):
+            one = _lib.icp(ctx, src, tgt, 10.0, inits[b], max_iteration=4, relative_fitness=-1, relative_rmse=-1)
+            assert np.array_equal(T[b], one["T"]) and fit[b] == one["fitness"] and rmse[b] == one["inlier_rmse"]
+        src.close()
+        tgt.close()
+    ctx.close()
+
+
+def test_handles_outlive_their_context():
+    """Python may collect a Context before its clouds and meshes: destroying those afterwards must
+    not touch the freed context (the handles keep the device ordinal themselves)."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    ctx = _lib.Context(0)
+    cloud = _lib.Cloud(ctx, f.model_points, f.normals)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    ctx.close()
+    cloud.close()
+    mesh.close()
+
+
+def test_exhaustive_mode_sweeps_all_pairs_with_identical_results(ctx, oracle):
+    """pedp_icp_configure(exhaustive=1): every (scene point, model point) pair goes through the MFMA
+    sweep in every pass; correspondences, fitness and pose are those of the culled run."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    kw = dict(max_iteration=5, relative_fitness=-1, relative_rmse=-1, want_corr=True)
+    culled = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), **kw)
+    _, pairs_culled, _ = _lib.icp_last_stats(ctx)
+    _lib.icp_configure(ctx, exhaustive=True, timed_pass=1)
+    try:
+        full = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), **kw)
+        passes, pairs, _ = _lib.icp_last_stats(ctx)
+        ms = _lib.nn_last_sweep_ms(ctx)
+    finally:
+        _lib.icp_configure(ctx)
+    assert np.array_equal(full["corr"], culled["corr"]) and full["fitness"] == culled["fitness"]
+    assert np.abs(full["T"] - culled["T"]).max() < 1e-9
+    assert pairs >= passes * len(scene) * len(f.model_points) > pairs_culled   # padded all-pairs count
+    assert 0 < ms < 1000
