@@ -103,6 +103,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
     if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
+    for (hipEvent_t e : c->nn_evs)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -304,6 +306,8 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (cl->perm) (void)hipFree(cl->perm);
     if (cl->tile_sph) (void)hipFree(cl->tile_sph);
     if (cl->tile_sph4) (void)hipFree(cl->tile_sph4);
+    if (cl->tile_sphw) (void)hipFree(cl->tile_sphw);
+    if (cl->tgt_s) (void)hipFree(cl->tgt_s);
     delete cl;
 }
 

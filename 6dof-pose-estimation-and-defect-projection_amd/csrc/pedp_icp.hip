@@ -45,6 +45,24 @@
 #define PEDP_NN_EXPERIMENT 0
 #endif
 
+#ifndef PEDP_ICP_STAMPS
+#define PEDP_ICP_STAMPS 0
+#endif
+#if PEDP_ICP_STAMPS
+// Diagnostic build only (tools/icp_stamps.py): s_memtime at the phase boundaries of the fused
+// pass's kernels, written to a buffer nothing else reads.  [kernel 0..2][workgroup or wave][8]
+__device__ long long g_icp_stamps[3][4096][8];
+#define PEDP_STAMP(kern, unit, slot)                                                   \
+    do {                                                                               \
+        if ((unit) < 4096) g_icp_stamps[kern][unit][slot] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int pedp_debug_icp_stamps(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_stamps), sizeof(long long) * 3 * 4096 * 8) == hipSuccess ? 0 : -3;
+}
+#else
+#define PEDP_STAMP(kern, unit, slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +78,7 @@ constexpr int NN_TU = 4;    // rows are padded to multiples of 16 * NN_TU (= the
 constexpr int NN_LIST_TILES = 2048; // most MFMA tiles one sweep wave walks (its unit list lives in LDS)
 constexpr int SEG_MIN_TILES = 64;   // MFMA tiles per sweep segment at least
 constexpr int CULL_WORDS = 8;       // 64-unit mask words one cull wave fills
-constexpr int SORT_BITS = 5;          // spatial sort: 32^3 Hilbert-ordered cells over the cloud's bounding box
+constexpr int SORT_BITS = 8;          // spatial sort: 256^3 Hilbert-ordered cells over the cloud's bounding box
 constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
 constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
 constexpr int ACC_BLOCKS = 256;
@@ -80,6 +98,12 @@ struct IcpState {
     long long sum_tiles;       // surviving (scene block, target tile) pairs, summed over passes
     long long sum_cand;  // statistics over the passes of this registration
     long long sum_fb;
+    // fused pass: the live chunk set is rebuilt from the whole scene when `rebuild` is set (pass 0,
+    // and whenever the accumulated motion could have carried an outside point into reach)
+    int rebuild;
+    int n_rebuilds;
+    int n_live;                // entries of the live list (written by icp_finish_kernel)
+    double mu_theta, mu_tau;   // sum of |R - I|_F and of |t + (R - I) c| since the last rebuild
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -93,10 +117,11 @@ __device__ __forceinline__ double dist2(double ax, double ay, double az, double 
 }
 
 // ------------------------------------------------------------------ spatial order of a cloud
-// Counting sort by the Hilbert-curve index of the point's cell in a 32^3 grid over the bounding box:
+// Stable sort by the Hilbert-curve index of the point's cell in a 256^3 grid over the bounding box:
 // consecutive entries of `perm` are neighbours in space, so 128-point scene blocks and 16-point
-// target tiles are compact and their bounding spheres are small.  Order inside a cell is
-// arbitrary (atomics); nothing downstream depends on it.
+// target tiles are compact and their bounding spheres are small.  Inside a cell the points keep
+// ascending index (stable radix sort), so the order -- and with it the order of every float64 sum
+// of a registration -- is a function of the data alone.
 // 3-D Hilbert index of cell (x, y, z), SORT_BITS bits per axis (Skilling, "Programming the
 // Hilbert curve", 2004: axes -> transpose, then bit interleave).  Unlike Morton order, points
 // that are consecutive along the curve are always neighbours in space, so no 128-point scene
@@ -133,53 +158,10 @@ __device__ __forceinline__ unsigned point_cell(const double *__restrict__ pts, i
     if (!(fx >= 0.0 && fx < top && fy >= 0.0 && fy < top && fz >= 0.0 && fz < top)) return (unsigned)SORT_CELLS;
     return hilbert3((unsigned)(int)fx, (unsigned)(int)fy, (unsigned)(int)fz);
 }
-// one atomic per wave for the (possibly huge) outside bucket, per-lane atomics for real cells
-__device__ __forceinline__ unsigned cell_add(unsigned *__restrict__ ctr, unsigned cell, bool active) {
-    const bool outside = active && cell == (unsigned)SORT_CELLS;
-    const unsigned long long om = __builtin_amdgcn_ballot_w64(outside);
-    unsigned res = 0;
-    if (om != 0ull) {
-        const int lane = threadIdx.x & 63, leader = __builtin_ctzll(om);
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&ctr[SORT_CELLS], (unsigned)__builtin_popcountll(om));
-        base = __shfl(base, leader, 64);
-        if (outside) res = base + (unsigned)__builtin_popcountll(om & ((1ull << lane) - 1ull));
-    }
-    if (active && !outside) res = atomicAdd(&ctr[cell], 1u);
-    return res;
-}
-__global__ void cell_count_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
-                                  double sx, double sy, double sz, unsigned *__restrict__ hist) {
+__global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
+                                double sx, double sy, double sz, unsigned *__restrict__ key) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < N;
-    (void)cell_add(hist, active ? point_cell(pts, i, lox, loy, loz, sx, sy, sz) : 0u, active);
-}
-__global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ hist) {
-    __shared__ unsigned part[1024];
-    constexpr int PER = SORT_CELLS / 1024;
-    unsigned loc[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { loc[k] = hist[threadIdx.x * PER + k]; sum += loc[k]; }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - sum;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { hist[threadIdx.x * PER + k] = run; run += loc[k]; }
-    if (threadIdx.x == 1023) hist[SORT_CELLS] = run;  // the outside bucket follows all real cells
-}
-__global__ void cell_scatter_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
-                                    double sx, double sy, double sz, unsigned *__restrict__ cursor,
-                                    int32_t *__restrict__ perm) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < N;
-    const unsigned at = cell_add(cursor, active ? point_cell(pts, i, lox, loy, loz, sx, sy, sz) : 0u, active);
-    if (active) perm[at] = (int32_t)i;
+    if (i < N) key[i] = point_cell(pts, i, lox, loy, loz, sx, sy, sz);
 }
 
 // ------------------------------------------------------------------ target preparation
@@ -195,6 +177,18 @@ __global__ void pack_target_kernel(const double *__restrict__ pts, const int32_t
     float x = (float)(pts[3 * i] - cx), y = (float)(pts[3 * i + 1] - cy), z = (float)(pts[3 * i + 2] - cz);
     double w = (double)x * x + (double)y * y + (double)z * z;
     out[k] = make_float4(x, y, z, (float)w);
+}
+// sorted float64 rows of the target (row k = point perm[k]): the exact re-scoring reads them with
+// one load per row instead of perm -> point
+__global__ void sort_rows_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm, int64_t N, int64_t N_pad,
+                                 double *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N_pad) return;
+    const bool real = k < N;
+    const int64_t i = real ? perm[k] : 0;
+    out[3 * k] = real ? pts[3 * i] : 0.0;
+    out[3 * k + 1] = real ? pts[3 * i + 1] : 0.0;
+    out[3 * k + 2] = real ? pts[3 * i + 2] : 0.0;
 }
 __global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int64_t n_units_all, int UNIT_ROWS,
                                    float4 *__restrict__ sph) {
@@ -338,6 +332,12 @@ __global__ __launch_bounds__(256) void icp_transform_pack_kernel(
     }
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------ NN sweep (MFMA)
 __device__ __forceinline__ void lexmin(double &d, int &j, double od, int oj) {
     if (od < d || (od == d && oj < j)) { d = od; j = oj; }
@@ -452,7 +452,115 @@ __global__ __launch_bounds__(1024) void nn_segment_kernel(IcpState *__restrict__
     }
 }
 
-// ---- 3. sweep: one wave per segment ----
+// ---- 3. sweep ----
+// Ranks [r0, r0 + n_s) of a block's surviving-unit mask, expanded into an LDS list by one wave
+// (prefix popcount over the mask words), followed by 2 G pad units (rows that can never win: the
+// last group is filled up with them and the prefetch of the trip after it reads them).
+template <int G>
+__device__ __forceinline__ void expand_ranks(const unsigned long long *__restrict__ mw, int n_words, int r0, int n_s,
+                                             unsigned pad_unit, unsigned *__restrict__ mine, int lane) {
+    int running = 0;
+    for (int wg = 0; wg < n_words && running < r0 + n_s; wg += 64) {
+        unsigned long long word = (wg + lane < n_words) ? mw[wg + lane] : 0ull;
+        const int pc = __builtin_popcountll(word);
+        int incl = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        int rank = running + incl - pc;
+        if (pc > 0 && rank < r0 + n_s && rank + pc > r0) {
+            const unsigned tile0 = (unsigned)(wg + lane) * 64u;
+            while (word != 0ull) {
+                const int bit = __builtin_ctzll(word);
+                word &= word - 1ull;
+                if (rank >= r0 && rank < r0 + n_s) mine[rank - r0] = tile0 + (unsigned)bit;
+                ++rank;
+            }
+        }
+        running += __shfl(incl, 63, 64);
+    }
+    if (lane < 2 * G) mine[n_s + lane] = pad_unit;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+}
+
+// The MFMA loop of one wave over the n_s units of its LDS list: keeps, per lane and scene
+// sub-block, the best unit value b1, its unit t1 and the second-best unit value b2 (running
+// across calls).  Per unit (QT MFMA tiles = 16 QT target rows) the values a lane sees are folded
+// with two v_min3 per MFMA, and only once per unit the running triple is updated.  The matrix
+// pipe works on the next tile while the VALU folds this one (software pipeline), and the A
+// operands of a whole group of G units are fetched one group ahead: G QT x NN_SB MFMAs cover the
+// load latency.
+template <int QT, int G>
+__device__ __forceinline__ void sweep_list(const unsigned *__restrict__ mine, int n_s,
+                                           const float *__restrict__ tgtf, int frag, const float (&b)[NN_SB],
+                                           float (&b1)[NN_SB], int (&t1)[NN_SB], float (&b2)[NN_SB]) {
+    if (n_s <= 0) return;
+    constexpr int U = G * QT;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float vq[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) vq[sb] = __uint_as_float(0x7F800000u);
+    float a[U];
+    unsigned units[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        units[g] = mine[g];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) a[g * QT + u] = tgtf[((size_t)units[g] * QT + u) * 64 + frag];
+    }
+    f32x4 acc[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
+    for (int k = 0; k < n_s; k += G) {
+        float an[U];
+        unsigned units_n[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            units_n[g] = mine[k + G + g];  // pad units follow the last real one
+#pragma unroll
+            for (int u = 0; u < QT; ++u) an[g * QT + u] = tgtf[((size_t)units_n[g] * QT + u) * 64 + frag];
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int u = t % QT;
+            const unsigned unit = units[t / QT];
+            const float a_next = (t + 1 < U) ? a[t + 1] : an[0];
+#pragma unroll
+            for (int sb = 0; sb < NN_SB; ++sb) {
+                f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
+                const f32x4 cur = acc[sb];
+#if PEDP_NN_EXPERIMENT == 1   /* MFMA only (wrong results): pure matrix-pipe rate of this loop shape */
+                b1[sb] = fminf(b1[sb], cur[0]);
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#else
+                // two v_min3 per MFMA (linear nesting is what the compiler turns into v_min3)
+                if (u == 0) vq[sb] = fminf(fminf(fminf(cur[0], cur[1]), cur[2]), cur[3]);
+                else vq[sb] = fminf(fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), cur[2]), cur[3]);
+                if (u == QT - 1) {
+                    const float v = vq[sb];
+                    t1[sb] = v < b1[sb] ? (int)unit : t1[sb];
+                    b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
+                    b1[sb] = fminf(b1[sb], v);
+                }
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                if (u == QT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // then its VALU ops
+                else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#endif
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) a[t] = an[t];
+#pragma unroll
+        for (int g = 0; g < G; ++g) units[g] = units_n[g];
+    }
+}
+
+// One wave per segment.
 // Triples of segment s: tr_b1 / tr_t1 / tr_b2 [(s * 4 + q) * 128 + slot in block]
 template <int QT, int G>
 __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
@@ -468,112 +576,17 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     const int blk = seg_blk[seg], r0 = seg_rank0[seg], n_s = seg_n[seg];
     const int64_t base = (int64_t)blk * (NN_SB * 16);
     const int frag = (lane & 15) * 4 + (lane >> 4);  // float offset inside a 16-point tile
-
-    // ---- expand ranks [r0, r0 + n_s) of the block's mask into the LDS tile list
     unsigned *mine = surv[wv];
-    {
-        int running = 0;
-        const unsigned long long *mw = mask + (size_t)blk * n_words;
-        for (int wg = 0; wg < n_words && running < r0 + n_s; wg += 64) {
-            unsigned long long word = (wg + lane < n_words) ? mw[wg + lane] : 0ull;
-            const int pc = __builtin_popcountll(word);
-            int incl = pc;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
-            int rank = running + incl - pc;
-            if (pc > 0 && rank < r0 + n_s && rank + pc > r0) {
-                const unsigned tile0 = (unsigned)(wg + lane) * 64u;
-                while (word != 0ull) {
-                    const int bit = __builtin_ctzll(word);
-                    word &= word - 1ull;
-                    if (rank >= r0 && rank < r0 + n_s) mine[rank - r0] = tile0 + (unsigned)bit;
-                    ++rank;
-                }
-            }
-            running += __shfl(incl, 63, 64);
-        }
-    }
-    // pad units behind the list (rows that can never win): the last group is filled up with
-    // them and the prefetch of the trip after it reads them
-    if (lane < 2 * G) mine[n_s + lane] = (unsigned)n_tiles;  // first pad unit (|t|^2 = 1e30)
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    expand_ranks<G>(mask + (size_t)blk * n_words, n_words, r0, n_s, (unsigned)n_tiles, mine, lane);
 
     float b[NN_SB];
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) b[sb] = srcf[(base + sb * 16) * 4 + frag];
-    float b1[NN_SB], b2[NN_SB], vq[NN_SB];
+    float b1[NN_SB], b2[NN_SB];
     int t1[NN_SB];
 #pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; vq[sb] = b1[sb]; t1[sb] = n_tiles; }
-
-    if (n_s > 0) {
-        // Per unit (QT MFMA tiles = 16 QT target rows): the values a lane sees are folded with
-        // two v_min3 per MFMA, and only once per unit the running (best value, unit, second-best
-        // value) is updated.  The matrix pipe works on the next tile while the VALU folds this one
-        // (software pipeline), and the A operands of a whole group of G units (G QT tiles) are
-        // fetched one group ahead: G QT x NN_SB MFMAs cover the load latency.
-        constexpr int U = G * QT;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        float a[U];
-        unsigned units[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            units[g] = mine[g];
-#pragma unroll
-            for (int u = 0; u < QT; ++u) a[g * QT + u] = tgtf[((size_t)units[g] * QT + u) * 64 + frag];
-        }
-        f32x4 acc[NN_SB];
-#pragma unroll
-        for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[sb], zero, 0, 0, 0);
-        for (int k = 0; k < n_s; k += G) {
-            float an[U];
-            unsigned units_n[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                units_n[g] = mine[k + G + g];  // pad units follow the last real one
-#pragma unroll
-                for (int u = 0; u < QT; ++u) an[g * QT + u] = tgtf[((size_t)units_n[g] * QT + u) * 64 + frag];
-            }
-#pragma unroll
-            for (int t = 0; t < U; ++t) {
-                const int u = t % QT;
-                const unsigned unit = units[t / QT];
-                const float a_next = (t + 1 < U) ? a[t + 1] : an[0];
-#pragma unroll
-                for (int sb = 0; sb < NN_SB; ++sb) {
-                    f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, b[sb], zero, 0, 0, 0);
-                    const f32x4 cur = acc[sb];
-#if PEDP_NN_EXPERIMENT == 1   /* MFMA only (wrong results): pure matrix-pipe rate of this loop shape */
-                    b1[sb] = fminf(b1[sb], cur[0]);
-                    acc[sb] = nxt;
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-#else
-                    // two v_min3 per MFMA (linear nesting is what the compiler turns into v_min3)
-                    if (u == 0) vq[sb] = fminf(fminf(fminf(cur[0], cur[1]), cur[2]), cur[3]);
-                    else vq[sb] = fminf(fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), cur[2]), cur[3]);
-                    if (u == QT - 1) {
-                        const float v = vq[sb];
-                        t1[sb] = v < b1[sb] ? (int)unit : t1[sb];
-                        b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);  // b1 <= b2: new second best
-                        b1[sb] = fminf(b1[sb], v);
-                    }
-                    acc[sb] = nxt;
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
-                    if (u == QT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // then its VALU ops
-                    else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-#endif
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < U; ++t) a[t] = an[t];
-#pragma unroll
-            for (int g = 0; g < G; ++g) units[g] = units_n[g];
-        }
-    }
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = n_tiles; }
+    sweep_list<QT, G>(mine, n_s, tgtf, frag, b, b1, t1, b2);
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) {
@@ -758,12 +771,616 @@ __global__ __launch_bounds__(FB_WAVES * 64) void nn_fallback_kernel(const IcpSta
     }
 }
 
-// ------------------------------------------------------------------ accumulate
-__device__ __forceinline__ double wave_sum(double v) {
+// ================================================================== fused pass
+// Radius-limited registrations (unit size 1) run TWO launches per correspondence pass:
+//   icp_pass_kernel    one workgroup (8 waves) per live scene chunk, everything of the pass that
+//                      belongs to the chunk: transform its 128 points, box test, compaction into
+//                      slots, sub-block spheres, two-level culling of the target tiles, MFMA sweep
+//                      of the survivors (triples in LDS), exact selection, exact search for
+//                      ambiguous slots, the chunk's partial sums of J^T J / J^T r in a fixed order;
+//   icp_finish_kernel  partial sums of the live chunks in ascending chunk order, 6x6 solve in
+//                      registers, pose update, convergence, motion bound, live list.
+// A chunk is 128 consecutive entries of the scene's spatial order.  Only LIVE chunks are visited:
+// those that had a point within r + margin of the target's bounding box when the live set was
+// last rebuilt.  A rebuild pass walks the whole scene and recomputes every point from the source
+// through the history of updates -- the same float64 operations, in the same order, as applying
+// them pass by pass, so a point's coordinates do not depend on when its chunk became live.
+// Between rebuilds a point outside the live chunks is farther than r + margin from the box; an
+// update (R, t) moves a point x by at most |R - I| |x - c| + |t + (R - I) c| (c = box centre), and
+// with e = (distance to the box) + rho (rho = half diagonal), E = r + margin + rho:
+//   e_new >= e (1 - theta) - tau   =>   e_n >= E - (Theta E + Tau) = E - mu,
+// so no such point can come within r while mu < margin; icp_finish_kernel requests a rebuild at
+// mu >= 0.95 margin.  Chunk ids, slot order, tile order and the order of the partial sums depend
+// only on the data, never on execution order: results are run-to-run bit-stable.
+//
+// The pass is bound by chains of dependent memory accesses (about a microsecond per level on this
+// part), not by arithmetic.  The kernel is laid out to keep the chain short: what does not depend
+// on the points (word spheres) is requested first, every culling level is one round of
+// independent loads spread over all eight waves, and nothing the later phases need goes through
+// global memory.
+constexpr int CH = NN_SB * 16;   // 128 scene points per chunk = slots per scene block
+constexpr int BK_W = 8;          // waves of a pass workgroup
+constexpr int BK_TL = 2048;      // surviving tiles of a chunk held in LDS per round
+constexpr int BK_QS = 144;       // floats between the lane groups of one wave's triples (bank spread)
+constexpr int BK_WCAP = BK_W * 64;  // mask words (64 tiles each) the fused pass handles: 524,288 target points
+constexpr int PSTRIDE = 32;      // doubles per chunk in the partials: packet, [29] tiles, [30] fallback slots
+constexpr int LIVE_CAP = 8192;   // live chunks the finish kernel lists in LDS (1M scene points)
+
+// chunk of the rank-th set bit of the live mask (ascending), -1 beyond the last; wave-uniform
+__device__ __forceinline__ int live_rank_to_chunk(const unsigned long long *__restrict__ live, int n_lw, int rank, int lane) {
+    int running = 0;
+    for (int w0 = 0; w0 < n_lw; w0 += 64) {
+        const unsigned long long word = (w0 + lane < n_lw) ? live[w0 + lane] : 0ull;
+        const int pc = __builtin_popcountll(word);
+        int incl = pc;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int excl = running + incl - pc;
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(rank >= excl && rank < excl + pc);
+        if (hm != 0ull) {
+            const int srcl = __builtin_ctzll(hm);
+            unsigned long long ww = __shfl(word, srcl, 64);
+            const int k = rank - __shfl(excl, srcl, 64);
+            for (int t = 0; t < k; ++t) ww &= ww - 1ull;
+            return (w0 + srcl) * 64 + __builtin_ctzll(ww);
+        }
+        running += __shfl(incl, 63, 64);
+    }
+    return -1;
 }
+
+__device__ __forceinline__ void xform(const double *__restrict__ M, double &x, double &y, double &z) {
+    const double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+    const double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+    const double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+    x = nx; y = ny; z = nz;
+}
+
+// float <-> int keys with the same order (finite values and +-inf), for an LDS atomicMin
+__device__ __forceinline__ int fkey(float v) {
+    const int b = __float_as_int(v);
+    return b ^ ((b >> 31) & 0x7FFFFFFF);
+}
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7FFFFFFF)); }
+
+// Can a target sphere ts (a tile's, or a whole mask word's) hold the nearest neighbour of a
+// candidate of the chunk?  Every slot has a search radius rho <= r (see "temporal coherence" in
+// icp_pass_kernel), a sub-block the largest of its slots'.  Per 16-slot sub-block: bounding-sphere test; a WIDE sub-block (16 consecutive
+// points of the spatial order that straddle a jump of the curve: radius above r) is resolved
+// point by point, so its tiles are those near an actual point, not the (possibly huge) ball
+// around all sixteen.  Spheres, flags and points are read from LDS (broadcast reads).
+__device__ __forceinline__ bool near_chunk(const float4 &ts, const float4 *__restrict__ bs, const float *__restrict__ rsb,
+                                           unsigned wide, int cnt_lo, int cnt_hi, const float (*__restrict__ cs)[CH],
+                                           const float *__restrict__ rho) {
+    unsigned hit = 0;  // bit sb: the sub-block's sphere is near
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) {
+        const float4 b = bs[sb];
+        const float dx = ts.x - b.x, dy = ts.y - b.y, dz = ts.z - b.z;
+        const float lim = rsb[sb] + b.w + ts.w;
+        const bool k = (b.w >= 0.f) & !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+        hit |= (k ? 1u : 0u) << sb;
+    }
+    if (wide & hit) {  // rare: resolve the wide sub-blocks that passed point by point
+        unsigned todo = wide & hit;
+        hit &= ~wide;
+#pragma nounroll
+        while (todo != 0u && hit == 0u) {
+            const int sb = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            bool any = false;
+            const int j_end = sb < 4 ? cnt_lo : 64 + cnt_hi;  // real slots: [0, cnt_lo) and [64, 64 + cnt_hi)
+#pragma nounroll
+            for (int j = sb * 16; j < sb * 16 + 16 && j < j_end; ++j) {
+                const float px = cs[0][j], py = cs[1][j], pz = cs[2][j];
+                const float ex = ts.x - px, ey = ts.y - py, ez = ts.z - pz;
+                const float lp = rho[j] + ts.w + 1e-5f * (fabsf(px) + fabsf(py) + fabsf(pz)) + 1e-6f;
+                any |= !((ex * ex + ey * ey + ez * ez) > lp * lp * 1.00001f + 1e-6f);
+            }
+            hit |= any ? 1u : 0u;
+        }
+    }
+    return hit != 0u && ts.w >= 0.f;
+}
+
+struct PassArgs {
+    // scene
+    const double *src;          // N x 3 source points
+    const int32_t *perm;        // spatial order
+    int64_t N;
+    int n_chunks;
+    const double *hist;         // [pass + 1][16]: init, then the update of every pass so far
+    int pass;
+    double *Pk;                 // N_pad x 3: transformed points in spatial order (live chunks)
+    double *Tprev;              // N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none)
+    unsigned long long *live;
+    const int32_t *live_list;   // live chunks ascending (valid outside rebuild passes)
+    // target
+    const float *tgtf;          // sorted target operand, 64 floats per 16-row tile
+    int n_tiles, n_words;
+    const float4 *tile_sph, *word_sph;
+    const double *tgt_s;        // sorted target rows, float64 x 3
+    const int32_t *tperm;       // sorted row -> target index
+    int64_t Nt;
+    const double *tgt, *nrm;
+    // parameters
+    float Tn, T2, r1, r_search, wide_radius, r2f;
+    double r2, r2cut, r2live;
+    double lo[3], hi[3];
+    int estimator;
+    int32_t *idx_out;
+    double *partials;           // n_chunks x PSTRIDE: by chunk id in a rebuild pass, by live rank otherwise
+};
+
+// exact float64 scan of the rows of the tiles in `near` (one bit per lane's tile), 64 rows per trip
+__device__ __forceinline__ void scan_near_tiles(unsigned long long near, int unit_of_lane, const PassArgs &a, double qx,
+                                                double qy, double qz, int lane, double &bd, int &bj) {
+    while (near != 0ull) {  // wave-uniform: 64 lanes = 64 rows = 4 tiles per trip
+        int unit = -1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (near != 0ull) {
+                const int bit = __builtin_ctzll(near);
+                near &= near - 1ull;
+                const int u = __shfl(unit_of_lane, bit, 64);
+                if (g == (lane >> 4)) unit = u;
+            }
+        }
+        const int64_t row = (int64_t)unit * 16 + (lane & 15);
+        if (unit >= 0 && row < a.Nt)
+            lexmin(bd, bj, dist2(qx, qy, qz, a.tgt_s[3 * row], a.tgt_s[3 * row + 1], a.tgt_s[3 * row + 2]), a.tperm[row]);
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__restrict__ st, const PassArgs a) {
+    static_assert(W * 64 == 4 * CH, "four threads per slot");
+    __shared__ float tri_b1[W][4 * BK_QS];
+    __shared__ int tri_t1[W][4 * BK_QS], m2key[4 * BK_QS];
+    __shared__ unsigned tl[BK_TL + 8];
+    __shared__ float4 Bs[CH], bsph[NN_SB];
+    __shared__ double sel_p[3][CH], res_d[CH], accsh[W][PSTRIDE];
+    __shared__ float sel_e[CH], sel_S[CH], cs[3][CH], rho_s[CH], rsb[NN_SB];
+    __shared__ unsigned char sel_k[CH];
+    __shared__ unsigned long long mwords[BK_WCAP];
+    __shared__ int sel_i[CH], res_j[CH], fb_slots[CH], wlist[BK_WCAP], wcnt[W], ccnt[2], misc[8];
+    __shared__ float4 wsph[BK_WCAP];
+    // the first unit's live-list entry is requested together with the state (the list has one entry
+    // per chunk, so the index is always inside it; the value is used only when it is valid)
+    int chunk_next = a.live_list[blockIdx.x < (unsigned)a.n_chunks ? blockIdx.x : 0];
+    if (st->done) return;
+    const bool rebuild = st->rebuild != 0;
+    const int n_live = st->n_live;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frag_slot = lane & 15, frag_comp = lane >> 4;  // MFMA B fragment: slot in the sub-block, component
+    const int frag = frag_slot * 4 + frag_comp;              // float offset inside a 16-point target tile
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float inf = __uint_as_float(0x7F800000u);
+    const double dinf = __longlong_as_double(0x7FF0000000000000ll);
+    const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
+    // word spheres do not depend on the chunk: requested before anything else, parked in LDS
+    wsph[tid] = a.word_sph[tid < a.n_words ? tid : 0];
+    for (int unit = blockIdx.x;; unit += gridDim.x) {
+        // a rebuild pass visits every chunk (unit = chunk id), other passes the live list (unit = rank);
+        // `unit` also indexes the chunk's partial sums (see icp_finish_kernel)
+        int chunk;
+        if (rebuild) {
+            chunk = unit;
+            if (chunk >= a.n_chunks) break;
+        } else {
+            if (unit >= n_live) break;
+            chunk = unit == (int)blockIdx.x ? chunk_next : a.live_list[unit];
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 0);
+        // ---- 1. waves 0 and 1: transform the chunk's points (one per thread), box test, compaction of
+        // the candidates into slots -- wave 0's into slots 0.., wave 1's into slots 64.. (ascending
+        // position; no hand-over between the two waves) --, MFMA operand, filter bound, and the bounding
+        // spheres of the eight 16-slot sub-blocks (centred fp32 coordinates)
+        if (tid < CH) {
+            bool valid = false, cand = false, near = false;
+            int pi = -1;
+            double x = 0.0, y = 0.0, z = 0.0, dprev = __longlong_as_double(0x7FF8000000000000ll);
+            const int64_t k = (int64_t)chunk * CH + tid;
+            valid = k < a.N;
+            if (valid) {
+                pi = a.perm[k];
+                if (rebuild) {
+                    x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
+                    for (int q = 0; q <= a.pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                } else {
+                    x = a.Pk[3 * k]; y = a.Pk[3 * k + 1]; z = a.Pk[3 * k + 2];
+                    const double ux = a.Tprev[3 * k], uy = a.Tprev[3 * k + 1], uz = a.Tprev[3 * k + 2];
+                    xform(st->upd, x, y, z);
+                    // Temporal coherence: last pass's neighbour is still a target point, so the new nearest
+                    // neighbour is no farther than it is now.  NaN (no neighbour last pass) fails the
+                    // comparison below and leaves the full radius.
+                    dprev = sqrt(dist2(x, y, z, ux, uy, uz));
+                }
+                const double ex = fmax(fmax(a.lo[0] - x, x - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - y, y - a.hi[1]), 0.0),
+                             ez = fmax(fmax(a.lo[2] - z, z - a.hi[2]), 0.0);
+                const double d2box = ex * ex + ey * ey + ez * ez;
+                cand = d2box <= a.r2cut;   // r2cut = r^2 (1 + 1e-12): rounding-safe
+                near = d2box <= a.r2live;
+            }
+            const unsigned long long mc = __builtin_amdgcn_ballot_w64(cand), mn = __builtin_amdgcn_ballot_w64(near);
+            const int wc = __builtin_popcountll(mc);
+            if (lane == 0) { ccnt[wv] = wc; misc[wv] = mn != 0ull; }
+            if (valid) {  // (a rebuild pass stores every chunk's coordinates; only the live ones are read again)
+                if (!cand) { a.idx_out[pi] = -1; a.Tprev[3 * k] = __longlong_as_double(0x7FF8000000000000ll); }
+                a.Pk[3 * k] = x; a.Pk[3 * k + 1] = y; a.Pk[3 * k + 2] = z;
+            }
+            const int base = wv * 64;
+            const float sx = (float)(x - ccx), sy = (float)(y - ccy), sz = (float)(z - ccz);
+            if (cand) {
+                const int sl = base + __builtin_popcountll(mc & lt);
+                Bs[sl] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
+                // error bound of the fp32 surrogate against the float64 distance, see pack_store()
+                const float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
+                const float Mi = 2.0f * s1 * a.Tn + a.T2;
+                sel_e[sl] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(a.r1, s1 + a.Tn) * (a.Tn + s1)) * 1.0001f;
+                sel_S[sl] = sx * sx + sy * sy + sz * sz;
+                sel_i[sl] = pi;
+                sel_k[sl] = (unsigned char)tid;
+                sel_p[0][sl] = x; sel_p[1][sl] = y; sel_p[2][sl] = z;
+                cs[0][sl] = sx; cs[1][sl] = sy; cs[2][sl] = sz;
+                // search radius of the slot: the distance to last pass's neighbour, rounded up, at most r
+                const float rp = (float)dprev * 1.00001f + 1e-5f * s1 + 1e-6f;
+                rho_s[sl] = rp < a.r_search ? rp : a.r_search;
+            }
+            if (lane >= wc) {  // dummies behind the wave's candidates: never inliers, never selected
+                const int sl = base + lane;
+                Bs[sl] = make_float4(0.f, 0.f, 0.f, 1.f);
+                sel_e[sl] = 0.f; sel_S[sl] = 3e38f; sel_i[sl] = -1;
+                sel_p[0][sl] = 0.0; sel_p[1][sl] = 0.0; sel_p[2][sl] = 0.0;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+            const bool real = lane < wc;
+            const float px = real ? cs[0][base + lane] : 0.f, py = real ? cs[1][base + lane] : 0.f,
+                        pz = real ? cs[2][base + lane] : 0.f;
+            float rmax = real ? rho_s[base + lane] : 0.f;
+            const float big = 3e38f;
+            float lx = real ? px : big, hx = real ? px : -big, ly = real ? py : big, hy = real ? py : -big,
+                  lz = real ? pz : big, hz = real ? pz : -big;
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) {
+                lx = fminf(lx, __shfl_xor(lx, off, 64)); hx = fmaxf(hx, __shfl_xor(hx, off, 64));
+                ly = fminf(ly, __shfl_xor(ly, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64));
+                lz = fminf(lz, __shfl_xor(lz, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
+                rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+            }
+            if ((lane & 15) == 0) {
+                float4 sp = make_float4(0.f, 0.f, 0.f, -1.f);  // empty sub-block: matches nothing
+                if (hx >= lx) {
+                    const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
+                    const float ex = hx - mx, ey = hy - my, ez = hz - mz;
+                    sp = make_float4(mx, my, mz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f +
+                                                     1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz)) + 1e-30f);
+                }
+                bsph[tid >> 4] = sp;
+                rsb[tid >> 4] = rmax;
+            }
+        } else {
+            for (int o = tid - CH; o < 4 * BK_QS; o += W * 64 - CH) m2key[o] = 0x7F800000;  // +inf
+            if (tid == CH) misc[2] = 0;  // ambiguous-slot counter
+        }
+        __syncthreads();
+        // candidates of the two waves: slots [0, cnt_lo) and [64, 64 + cnt_hi); a slot index below
+        // `cnt` (as the wide-sub-block test and the sphere code read it) means "real" per half
+        const int cnt_lo = ccnt[0], cnt_hi = ccnt[1];
+        const bool is_live = !rebuild || (misc[0] | misc[1]) != 0;
+        if (!is_live) {  // workgroup-uniform: the chunk stays outside the live set
+            __syncthreads();
+            continue;
+        }
+        if (rebuild && tid == 0) atomicOr(&a.live[chunk >> 6], 1ull << (chunk & 63));
+        if (cnt_lo + cnt_hi == 0) {  // workgroup-uniform
+            if (tid < PSTRIDE) a.partials[(size_t)unit * PSTRIDE + tid] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        unsigned wide = 0;
+#pragma unroll
+        for (int sb = 0; sb < NN_SB; ++sb) wide |= (bsph[sb].w > a.wide_radius ? 1u : 0u) << sb;
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 1);
+        // ---- 4. culling, level 1: thread t tests the sphere of mask word t (64 tiles = 1024 sorted rows);
+        // surviving words listed in ascending order
+        {
+            const bool keepw = tid < a.n_words && near_chunk(wsph[tid], bsph, rsb, wide, cnt_lo, cnt_hi, cs, rho_s);
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(keepw);
+            if (lane == 0) wcnt[wv] = __builtin_popcountll(km);
+            __syncthreads();
+            int off = 0, nsurv = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { off += w < wv ? wcnt[w] : 0; nsurv += wcnt[w]; }
+            if (keepw) wlist[off + __builtin_popcountll(km & lt)] = tid;
+            if (tid == 0) misc[3] = nsurv;
+        }
+        __syncthreads();
+        const int nsurv = misc[3];
+        // ---- level 2: wave w takes the surviving words w, w + W, ...; lane l tests tile 64 word + l;
+        // the ballot is the word's tile mask.  Four sphere loads in flight per lane.
+        for (int q0 = wv; q0 < nsurv; q0 += 4 * W) {
+            int word[4];
+            float4 ts[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * W;
+                word[u] = q < nsurv ? wlist[q] : -1;
+                const int tile = word[u] * 64 + lane;
+                ts[u] = a.tile_sph[(word[u] >= 0 && tile < a.n_tiles) ? tile : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (word[u] < 0) continue;
+                const int tile = word[u] * 64 + lane;
+                const unsigned long long m =
+                    __builtin_amdgcn_ballot_w64(tile < a.n_tiles && near_chunk(ts[u], bsph, rsb, wide, cnt_lo, cnt_hi, cs, rho_s));
+                if (lane == 0) mwords[q0 + u * W] = m;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 2);
+        // ---- 5. sweep: the surviving tiles, ascending, in W equal pieces (rounds of BK_TL tiles)
+        int c = 0;
+        {
+            // every wave counts the survivors itself (a scan over <= BK_WCAP words)
+            for (int q0 = 0; q0 < nsurv; q0 += 64) {
+                int pc = q0 + lane < nsurv ? __builtin_popcountll(mwords[q0 + lane]) : 0;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) pc += __shfl_xor(pc, off, 64);
+                c += pc;
+            }
+            float b[NN_SB], b1[NN_SB], b2[NN_SB];
+            int t1[NN_SB];
+#pragma unroll
+            for (int sb = 0; sb < NN_SB; ++sb) {
+                const float4 v = Bs[sb * 16 + frag_slot];
+                b[sb] = frag_comp == 0 ? v.x : (frag_comp == 1 ? v.y : (frag_comp == 2 ? v.z : v.w));
+                b1[sb] = inf; b2[sb] = inf; t1[sb] = a.n_tiles;
+            }
+            for (int R0 = 0; R0 < c || R0 == 0; R0 += BK_TL) {
+                const int nr = c - R0 < BK_TL ? c - R0 : BK_TL;
+                const int piece = (((nr + W - 1) / W) + 3) & ~3;
+                const int lo = wv * piece < nr ? wv * piece : nr, hi = lo + piece < nr ? lo + piece : nr;
+                if (R0 > 0) __syncthreads();  // the previous round's list has been read
+                {   // this wave's ranks go straight to their place in the shared list
+                    int running = 0;
+                    const int r0 = R0 + lo, n_s = hi - lo;
+                    for (int q0 = 0; q0 < nsurv && running < r0 + n_s; q0 += 64) {
+                        unsigned long long word = q0 + lane < nsurv ? mwords[q0 + lane] : 0ull;
+                        const int pc = __builtin_popcountll(word);
+                        int incl = pc;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int o = __shfl_up(incl, off, 64);
+                            if (lane >= off) incl += o;
+                        }
+                        int rk = running + incl - pc;
+                        if (pc > 0 && rk < r0 + n_s && rk + pc > r0) {
+                            const unsigned tile0 = (unsigned)wlist[q0 + lane] * 64u;
+                            while (word != 0ull) {
+                                const int bit = __builtin_ctzll(word);
+                                word &= word - 1ull;
+                                if (rk >= r0 && rk < r0 + n_s) tl[rk - R0] = tile0 + (unsigned)bit;
+                                ++rk;
+                            }
+                        }
+                        running += __shfl(incl, 63, 64);
+                    }
+                    if (wv == W - 1 && lane < 8) tl[nr + lane] = (unsigned)a.n_tiles;  // pad units: rows that never win
+                }
+                __syncthreads();
+                sweep_list<1, 4>(tl + lo, hi - lo, a.tgtf, frag, b, b1, t1, b2);
+            }
+#pragma unroll
+            for (int sb = 0; sb < NN_SB; ++sb) {
+                const int o = frag_comp * BK_QS + sb * 16 + frag_slot;
+                tri_b1[wv][o] = b1[sb];
+                tri_t1[wv][o] = t1[sb];
+                atomicMin(&m2key[o], fkey(b2[sb]));
+            }
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 3);
+        __syncthreads();
+        // ---- 6. exact selection, four threads per slot (thread gl reads lane group gl of every wave's
+        // best tile): window = min b1 + 2 eps; every (wave, lane group) whose best tile is inside the
+        // window has its 4 rows re-scored in float64 (the oracle's formula, lexicographic
+        // (d^2, index) min); a second tile of one lane group inside the window sends the slot to the
+        // exact search below.
+        {
+            const int sslot = tid >> 2, gl = tid & 3;
+            const float e = sel_e[sslot], Si = sel_S[sslot];
+            const double px = sel_p[0][sslot], py = sel_p[1][sslot], pz = sel_p[2][sslot];
+            const bool live_slot = sel_i[sslot] >= 0;
+            float m = inf, sm = inf;
+            int mt = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int o = gl * BK_QS + sslot;
+                const float v1 = tri_b1[w][o];
+                const int vt = tri_t1[w][o];
+                sm = v1 < m ? m : fminf(sm, v1);
+                mt = v1 < m ? vt : mt;
+                m = fminf(m, v1);
+            }
+            float m2 = fkey_inv(m2key[gl * BK_QS + sslot]);
+            float mg = fminf(m, __shfl_xor(m, 1, 64)); mg = fminf(mg, __shfl_xor(mg, 2, 64));
+            m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
+            const bool maybe = mg + Si <= a.r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
+            const float win = mg + 2.0f * e;
+            double bd = dinf;
+            int bj = 0x7FFFFFFF;
+            auto rescore = [&](int tile) {
+                const int64_t row0 = (int64_t)tile * 16 + 4 * gl;  // lane group gl: rows 4 gl .. 4 gl + 3 of the tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r;
+                    if (row < a.Nt)
+                        lexmin(bd, bj, dist2(px, py, pz, a.tgt_s[3 * row], a.tgt_s[3 * row + 1], a.tgt_s[3 * row + 2]),
+                               a.tperm[row]);
+                }
+            };
+            if (live_slot && maybe) {
+                if (sm <= win) {  // rare: several waves hold a tile of this lane group inside the window
+                    for (int w = 0; w < W; ++w)
+                        if (tri_b1[w][gl * BK_QS + sslot] <= win) rescore(tri_t1[w][gl * BK_QS + sslot]);
+                } else if (m <= win) {
+                    rescore(mt);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off <= 2; off <<= 1) {
+                const double od = __shfl_xor(bd, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                lexmin(bd, bj, od, oj);
+            }
+            if (gl == 0) {
+                const bool found = live_slot && maybe && bj != 0x7FFFFFFF;
+                res_d[sslot] = found ? bd : dinf;
+                res_j[sslot] = found ? bj : -1;
+                if (live_slot && maybe && m2 <= win) fb_slots[atomicAdd(&misc[2], 1)] = sslot;  // ambiguous
+            }
+        }
+        __syncthreads();
+        // ---- 7. ambiguous slots: exact float64 search over the chunk's surviving tiles that also come
+        // within r of the point itself.  One wave per slot (slots w, w + W, ...), 256 tiles of the LDS
+        // list per step (four sphere loads in flight per lane); the word masks when the list did not
+        // fit one round.
+        const int nfb = misc[2];
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 4);
+        for (int f = wv; f < nfb; f += W) {
+            const int fs = fb_slots[f];
+            const double qx = sel_p[0][fs], qy = sel_p[1][fs], qz = sel_p[2][fs];
+            const float sx = cs[0][fs], sy = cs[1][fs], sz = cs[2][fs];
+            const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
+            double bd = dinf;
+            int bj = 0x7FFFFFFF;
+            auto near_tile = [&](int tile) {
+                const float4 ts = a.tile_sph[tile < 0 ? 0 : tile];
+                const float dx = ts.x - sx, dy = ts.y - sy, dz = ts.z - sz;
+                const float lim = rho_s[fs] + ts.w + slack;
+                return !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+            };
+            if (c <= BK_TL) {
+                for (int k0 = 0; k0 < c; k0 += 256) {
+                    int tu[4];
+                    bool keep[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 64 * u + lane;
+                        tu[u] = k < c ? (int)tl[k] : -1;
+                        keep[u] = near_tile(tu[u]) && tu[u] >= 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        scan_near_tiles(__builtin_amdgcn_ballot_w64(keep[u]), tu[u], a, qx, qy, qz, lane, bd, bj);
+                }
+            } else {
+                for (int q = 0; q < nsurv; ++q) {
+                    const unsigned long long word = mwords[q];  // wave-uniform
+                    if (word == 0ull) continue;
+                    const int tu = wlist[q] * 64 + lane;
+                    const bool keep = ((word >> lane) & 1ull) && near_tile(tu);
+                    scan_near_tiles(__builtin_amdgcn_ballot_w64(keep), tu, a, qx, qy, qz, lane, bd, bj);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off <= 32; off <<= 1) {
+                const double od = __shfl_xor(bd, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                lexmin(bd, bj, od, oj);
+            }
+            if (lane == 0) {
+                res_d[fs] = bd;
+                res_j[fs] = bj == 0x7FFFFFFF ? -1 : bj;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 5);
+        // ---- 8. the chunk's partial sums (layout: see icp_accumulate_kernel).  Four threads per slot,
+        // thread g owns the packet entries k = g (mod 4); entries are summed over the wave's 16 slots
+        // by a shuffle tree, then over the waves in order: a fixed tree.
+        {
+            const int slot = tid >> 2, g = tid & 3;
+            double acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+            const int i = sel_i[slot];
+            int j = res_j[slot];
+            const double dd = res_d[slot];
+            if (i >= 0) {
+                if (j >= 0 && !(dd < a.r2)) j = -1;  // strict, as SearchHybrid's lower_bound
+                const int64_t kp = (int64_t)chunk * CH + sel_k[slot];
+                if (g == 0) {
+                    a.idx_out[i] = j;
+                    if (j < 0) a.Tprev[3 * kp] = __longlong_as_double(0x7FF8000000000000ll);
+                }
+                if (j >= 0) {
+                    const double sx = sel_p[0][slot], sy = sel_p[1][slot], sz = sel_p[2][slot];
+                    const double tx = a.tgt[3 * (int64_t)j], ty = a.tgt[3 * (int64_t)j + 1], tz = a.tgt[3 * (int64_t)j + 2];
+                    if (g == 0) { a.Tprev[3 * kp] = tx; a.Tprev[3 * kp + 1] = ty; a.Tprev[3 * kp + 2] = tz; }
+                    // entry k of the packet goes to thread g = k % 4, accumulator k / 4; every product is
+                    // handed over as soon as it is formed
+#define PEDP_PUT(K, V)                                   \
+    do {                                                 \
+        const double v_ = (V);                           \
+        if (g == ((K) & 3)) acc[(K) >> 2] = v_;          \
+    } while (0)
+                    if (a.estimator == PEDP_POINT_TO_PLANE) {
+                        const double nx = a.nrm[3 * (int64_t)j], ny = a.nrm[3 * (int64_t)j + 1], nz = a.nrm[3 * (int64_t)j + 2];
+                        const double r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+                        const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+                        int k = 0;
+#pragma unroll
+                        for (int u = 0; u < 6; ++u)
+#pragma unroll
+                            for (int v = u; v < 6; ++v) { PEDP_PUT(k, J[u] * J[v]); ++k; }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) PEDP_PUT(21 + u, J[u] * r);
+                    } else {
+                        const double s3[3] = {sx - ccx, sy - ccy, sz - ccz}, t3[3] = {tx - ccx, ty - ccy, tz - ccz};
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) { PEDP_PUT(u, s3[u]); PEDP_PUT(3 + u, t3[u]); }
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) PEDP_PUT(6 + 3 * u + v, t3[u] * s3[v]);
+                    }
+                    PEDP_PUT(27, dd);
+                    PEDP_PUT(28, 1.0);
+#undef PEDP_PUT
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double v = acc[k];
+#pragma unroll
+                for (int off = 4; off <= 32; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (lane < 4) accsh[wv][4 * k + lane] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < PACKET) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) v += accsh[w][tid];
+            a.partials[(size_t)unit * PSTRIDE + tid] = v;
+        }
+        if (tid == PACKET) a.partials[(size_t)unit * PSTRIDE + PACKET] = (double)c;
+        if (tid == PACKET + 1) a.partials[(size_t)unit * PSTRIDE + PACKET + 1] = (double)nfb;
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 6);
+#if PEDP_ICP_STAMPS
+        if (tid == 1 && blockIdx.x < 4096)
+            g_icp_stamps[1][blockIdx.x][7] = ((long long)c << 32) | ((long long)nsurv << 24) | (long long)(nfb << 16) | (cnt_lo + cnt_hi);
+#endif
+        __syncthreads();  // LDS is reused by the next chunk
+    }
+}
+
+// ------------------------------------------------------------------ accumulate
 
 // Packet layout.  point-to-plane: [0..20] upper triangle of J J^T (row-major), [21..26] J r,
 // [27] sum d^2, [28] count.  point-to-point: [0..2] sum (s-c), [3..5] sum (t-c),
@@ -906,9 +1523,10 @@ __device__ bool solve6_ldlt(const double *Ain, const double *b, double *x) {
 }
 
 __device__ void vec6_to_T(const double *x, double *T) {
-    double ca = cos(x[0]), sa = sin(x[0]);
-    double cb = cos(x[1]), sb = sin(x[1]);
-    double cc = cos(x[2]), sc = sin(x[2]);
+    double ca, sa, cb, sb, cc, sc;  // one argument reduction per angle
+    sincos(x[0], &sa, &ca);
+    sincos(x[1], &sb, &cb);
+    sincos(x[2], &sc, &cc);
     ident4(T);
     T[0] = cc * cb;  T[1] = cc * sb * sa - sc * ca;  T[2] = cc * sb * ca + sc * sa;
     T[4] = sc * cb;  T[5] = sc * sb * sa + cc * ca;  T[6] = sc * sb * ca - cc * sa;
@@ -1081,6 +1699,288 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState *__restrict__ s
     mat4_mul_dev(upd, st->T, st->T);
 }
 
+// ---- fused pass, third launch
+// The same pivoted LDLT as solve6_ldlt (and oracle/icp.c), operation for operation, with the
+// matrix in registers: every index is a compile-time constant after unrolling and the pivot
+// exchange of step k is a chain of predicated swaps, one per candidate row.
+__device__ __forceinline__ void swap_if(bool c, double &x, double &y) {
+    const double t = x;
+    x = c ? y : x;
+    y = c ? t : y;
+}
+__device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__restrict__ b, double *__restrict__ x) {
+    double A[6][6], y[6];
+    int tr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i][j] = Ain[6 * i + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double big = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
+        tr[k] = p;
+#pragma unroll
+        for (int q = k + 1; q < 6; ++q) {
+            const bool sw = p == q;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) swap_if(sw, A[k][j], A[q][j]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) swap_if(sw, A[i][k], A[i][q]);
+        }
+        if (k > 0) {
+            double tmp[6];
+#pragma unroll
+            for (int j = 0; j < k; ++j) tmp[j] = A[j][j] * A[k][j];
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < k; ++j) sacc += A[k][j] * tmp[j];
+            A[k][k] -= sacc;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) {
+                double u = 0.0;
+#pragma unroll
+                for (int j = 0; j < k; ++j) u += A[i][j] * tmp[j];
+                A[i][k] -= u;
+            }
+        }
+        const double akk = A[k][k];
+        if (fabs(akk) > 0.0) {
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) A[i][k] /= akk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = b[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int q = k + 1; q < 6; ++q) swap_if(tr[k] == q, y[k], y[q]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (fabs(A[i][i]) > 2.2250738585072014e-308) y[i] /= A[i][i];
+        else y[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) y[i] -= A[j][i] * y[j];
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int q = k + 1; q < 6; ++q) swap_if(tr[k] == q, y[k], y[q]);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        x[i] = y[i];
+        if (!(y[i] == y[i]) || isinf(y[i])) ok = false;
+    }
+    return ok;
+}
+
+// phase 0: sum the live chunks' partials, solve, update (one GPU); phase 1: sum only (the packet
+// then goes through the all-reduce); phase 2: solve from the summed packet.
+// Order of the sum: 8 contiguous ranges of live-mask words, chunks ascending inside a range, then
+// the ranges in order -- a function of the live set alone.
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *__restrict__ st, unsigned long long *__restrict__ live,
+                                                         int32_t *__restrict__ live_list, int n_lw,
+                                                         const double *__restrict__ partials,
+                                                         double *__restrict__ packet, int phase, int pass, int max_iter,
+                                                         int estimator, double n_source, double rel_fitness, double rel_rmse,
+                                                         double *__restrict__ trace, double *__restrict__ hist, double reachE,
+                                                         double margin, double bcx, double bcy, double bcz) {
+    if (st->done) return;
+    constexpr int PARTS = FIN_THREADS / 32;
+    __shared__ double slice[PARTS][32], pk[32];
+    __shared__ int lst[LIVE_CAP], scan[FIN_THREADS];
+    __shared__ int do_rebuild, n_live_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) PEDP_STAMP(2, 0, 0);
+#if PEDP_ICP_STAMPS
+    if (tid == 0) { g_icp_stamps[2][1][0] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][1] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
+    if (phase != 2) {
+        // Partial sums are indexed by chunk id in a rebuild pass and by live rank otherwise (see
+        // icp_patch_kernel); either way they are summed in ascending chunk order.
+        const bool listing = st->rebuild != 0;
+        int n_live = st->n_live;
+        bool listed = true;
+        if (listing) {
+            // the new live list, ascending: thread t owns a contiguous range of mask words
+            const int per = (n_lw + FIN_THREADS - 1) / FIN_THREADS;
+            const int w_lo = tid * per < n_lw ? tid * per : n_lw, w_hi = w_lo + per < n_lw ? w_lo + per : n_lw;
+            int mine = 0;
+            for (int wi = w_lo; wi < w_hi; ++wi) mine += __builtin_popcountll(live[wi]);
+            scan[tid] = mine;
+            __syncthreads();
+            for (int off = 1; off < FIN_THREADS; off <<= 1) {
+                const int t = tid >= off ? scan[tid - off] : 0;
+                __syncthreads();
+                scan[tid] += t;
+                __syncthreads();
+            }
+            n_live = scan[FIN_THREADS - 1];
+            listed = n_live <= LIVE_CAP;
+            int at = scan[tid] - mine;
+            for (int wi = w_lo; wi < w_hi; ++wi) {
+                unsigned long long word = live[wi];
+                while (word != 0ull) {
+                    const int chunk = wi * 64 + __builtin_ctzll(word);
+                    word &= word - 1ull;
+                    if (listed) lst[at] = chunk;
+                    live_list[at] = chunk;
+                    ++at;
+                }
+            }
+            __syncthreads();
+        }
+        // PARTS contiguous ranges of the live chunks, ascending inside a range, then the ranges in
+        // order: a function of the live set alone.  Up to sixteen loads in flight per thread.
+        const int k = tid & 31, part = tid >> 5;
+        const int lper = (n_live + PARTS - 1) / PARTS;
+        const int l_lo = part * lper < n_live ? part * lper : n_live, l_hi = l_lo + lper < n_live ? l_lo + lper : n_live;
+        double v = 0.0;
+        if (k < PACKET + 2) {
+            int q = l_lo;
+            for (; q + 16 <= l_hi; q += 16) {
+                double x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int at = listing ? (listed ? lst[q + u] : live_list[q + u]) : q + u;
+                    x[u] = partials[(size_t)at * PSTRIDE + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v += x[u];
+            }
+            double x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = q + u < l_hi;
+                const int at = !in ? 0 : (listing ? (listed ? lst[q + u] : live_list[q + u]) : q + u);
+                x[u] = in ? partials[(size_t)at * PSTRIDE + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (q + u < l_hi) v += x[u];
+        }
+        slice[part][k] = v;
+        if (tid == 0) n_live_s = n_live;
+        __syncthreads();
+        if (tid < 32) {
+            double t = 0.0;
+            for (int q = 0; q < PARTS; ++q) t += slice[q][tid];
+            pk[tid] = t;
+            if (tid < PACKET) packet[tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            st->sum_tiles += (long long)pk[PACKET];
+            st->sum_fb += (long long)pk[PACKET + 1];
+            st->n_live = n_live_s;
+#if PEDP_ICP_STAMPS
+            g_icp_stamps[2][1][2] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+        }
+        if (phase == 1) return;
+    } else {
+        if (tid < PACKET) pk[tid] = packet[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        PEDP_STAMP(2, 0, 1);
+        do_rebuild = 0;
+        const double K = pk[28];
+        double fit = 0.0, rmse = 0.0;
+        if (K > 0.0) { fit = K / n_source; rmse = sqrt(pk[27] / K); }
+        st->prev_fitness = st->fitness;
+        st->prev_rmse = st->rmse;
+        st->fitness = fit;
+        st->rmse = rmse;
+        if (trace) {
+            double *tr = trace + 18 * pass;
+            tr[0] = fit; tr[1] = rmse;
+            for (int k = 0; k < 16; ++k) tr[2 + k] = st->T[k];
+        }
+        st->iters = pass;
+        bool stop = pass >= max_iter;
+        if (pass > 0 && fabs(st->prev_fitness - fit) < rel_fitness && fabs(st->prev_rmse - rmse) < rel_rmse) stop = true;
+        if (stop) {
+            st->done = 1;
+        } else {
+            double upd[16];
+            ident4(upd);
+            if (K > 0.0) {
+                if (estimator == PEDP_POINT_TO_PLANE) {
+                    double A[36], nb[6], x[6];
+                    int k = 0;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int v = u; v < 6; ++v) { A[6 * u + v] = pk[k]; A[6 * v + u] = pk[k]; ++k; }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) nb[u] = -pk[21 + u];
+                    if (solve6_ldlt_reg(A, nb, x)) vec6_to_T(x, upd);
+                } else {
+                    const double *c = st->centroid;
+                    double ms[3], mt[3], sig[9];
+                    for (int u = 0; u < 3; ++u) { ms[u] = pk[u] / K; mt[u] = pk[3 + u] / K; }
+                    for (int u = 0; u < 3; ++u)
+                        for (int v = 0; v < 3; ++v) sig[3 * u + v] = pk[6 + 3 * u + v] / K - mt[u] * ms[v];
+                    double U[9], w[3], V[9];
+                    svd3_dev(sig, U, w, V);
+                    const double sgn = (det3_dev(U) * det3_dev(V) < 0.0) ? -1.0 : 1.0;
+                    double R[9];
+                    for (int u = 0; u < 3; ++u)
+                        for (int v = 0; v < 3; ++v)
+                            R[3 * u + v] = U[3 * u] * V[3 * v] + U[3 * u + 1] * V[3 * v + 1] + sgn * U[3 * u + 2] * V[3 * v + 2];
+                    for (int u = 0; u < 3; ++u) {
+                        for (int v = 0; v < 3; ++v) upd[4 * u + v] = R[3 * u + v];
+                        const double msa[3] = {ms[0] + c[0], ms[1] + c[1], ms[2] + c[2]};
+                        upd[4 * u + 3] = (mt[u] + c[u]) - (R[3 * u] * msa[0] + R[3 * u + 1] * msa[1] + R[3 * u + 2] * msa[2]);
+                    }
+                }
+            }
+            PEDP_STAMP(2, 0, 2);
+            for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; hist[16 * (pass + 1) + k] = upd[k]; }
+            mat4_mul_dev(upd, st->T, st->T);
+            // how far this update can move a point near the target: |R - I|_F (>= the spectral norm) and
+            // |t + (R - I) c| about the box centre c
+            double th2 = 0.0, tv[3];
+            for (int u = 0; u < 3; ++u) {
+                tv[u] = upd[4 * u + 3];
+                const double cc[3] = {bcx, bcy, bcz};
+                for (int v = 0; v < 3; ++v) {
+                    const double dlt = upd[4 * u + v] - (u == v ? 1.0 : 0.0);
+                    th2 += dlt * dlt;
+                    tv[u] += dlt * cc[v];
+                }
+            }
+            st->mu_theta += sqrt(th2);
+            st->mu_tau += sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+            const double mu = st->mu_theta * reachE + st->mu_tau;
+            if (!(mu < 0.95 * margin)) {  // also when mu is NaN
+                do_rebuild = 1;
+                st->mu_theta = 0.0;
+                st->mu_tau = 0.0;
+                st->n_rebuilds += 1;
+            }
+            st->rebuild = do_rebuild;
+        }
+        PEDP_STAMP(2, 0, 3);
+    }
+    __syncthreads();
+    if (do_rebuild)
+        for (int wi = tid; wi < n_lw; wi += FIN_THREADS) live[wi] = 0ull;
+}
+
 // ------------------------------------------------------------------ host side
 
 struct TargetPrep {
@@ -1107,10 +2007,19 @@ struct IcpWorkspace {
     int64_t Ns_pad, Nt_pad, blocks_cap;
     int n_words, max_segs;
     int qt;  // MFMA tiles per target unit for this call (1: culled registration, 4: dense sweep)
+    // fused pass (qt == 1 inside a registration)
+    bool fused;
+    double *Pk, *hist, *cpart, *Tprev;
+    unsigned long long *live;
+    int32_t *live_list;
+    int n_lw, n_chunks;
+    const float4 *word_sph;
+    const double *tgt_s;
 };
 
-int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w) {
+int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w, bool fused = false) {
     w.qt = qt;
+    w.fused = fused;
     w.Ns_pad = (int64_t)align_up((size_t)(Ns > 0 ? Ns : 1), NN_PTS_PER_WG);
     w.Nt_pad = (int64_t)align_up((size_t)(Nt > 0 ? Nt : 1), 16 * NN_TU);
     w.blocks_cap = w.Ns_pad / (NN_SB * 16) + 1;
@@ -1126,14 +2035,21 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     int64_t fine = (w.blocks_cap * n_tiles + seg_min_units - 1) / seg_min_units + w.blocks_cap;
     if (fine > 8192) fine = 8192;
     if (ms < fine) ms = fine;
+    if (fused) ms = 1;  // the fused pass keeps its triples in LDS: no segment table
     PEDP_REQUIRE(ms < (int64_t)1 << 22, "pedp_icp: problem too large for the segment table (%lld x %lld points)",
                  (long long)Ns, (long long)Nt);
     w.max_segs = (int)ms;
+    w.n_chunks = (int)((Ns + CH - 1) / CH);
+    w.n_lw = (w.n_chunks + 63) / 64;
+    if (w.n_lw < 1) w.n_lw = 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // what only the segmented (dense / large-radius) path uses shrinks to nothing in the fused pass,
+    // which keeps a chunk's slots, masks and triples in LDS
+    const size_t seg_only = fused ? 0 : 1;
     size_t o_st = take(sizeof(IcpState));
-    size_t o_P = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
-    size_t o_d2 = take(sizeof(double) * (size_t)w.Ns_pad);
+    size_t o_P = take(sizeof(double) * 3 * (size_t)w.Ns_pad * seg_only);
+    size_t o_d2 = take(sizeof(double) * (size_t)w.Ns_pad * seg_only);
     size_t o_part = take(sizeof(double) * ACC_BLOCKS * PACKET);
     size_t o_pack = take(sizeof(double) * 32);
     size_t o_trace = take(sizeof(double) * 18 * (size_t)(max_iter + 1));
@@ -1154,6 +2070,15 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     size_t o_b1 = take(sizeof(float) * tr);
     size_t o_t1 = take(sizeof(int32_t) * tr);
     size_t o_b2 = take(sizeof(float) * tr);
+    size_t o_Pk = 0, o_hist = 0, o_cpart = 0, o_live = 0, o_llist = 0, o_tprev = 0;
+    if (fused) {
+        o_Pk = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
+        o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
+        o_hist = take(sizeof(double) * 16 * (size_t)(max_iter + 2));
+        o_cpart = take(sizeof(double) * PSTRIDE * (size_t)w.blocks_cap);
+        o_live = take(sizeof(unsigned long long) * (size_t)w.n_lw);
+        o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
+    }
     int st = c->icp_ws.reserve(off);
     if (st) return st;
     char *b = (char *)c->icp_ws.ptr;
@@ -1179,15 +2104,21 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     w.tr_b1 = (float *)(b + o_b1);
     w.tr_t1 = (int32_t *)(b + o_t1);
     w.tr_b2 = (float *)(b + o_b2);
+    w.Pk = (double *)(b + o_Pk);
+    w.Tprev = (double *)(b + o_tprev);
+    w.hist = (double *)(b + o_hist);
+    w.cpart = (double *)(b + o_cpart);
+    w.live = (unsigned long long *)(b + o_live);
+    w.live_list = (int32_t *)(b + o_llist);
     // the per-block survivor counters start at zero (the segment kernel re-zeroes them per pass)
-    PEDP_HIP_CHECK(hipMemsetAsync(w.blk_cnt, 0, sizeof(int32_t) * (size_t)w.blocks_cap, c->stream));
+    if (!fused) PEDP_HIP_CHECK(hipMemsetAsync(w.blk_cnt, 0, sizeof(int32_t) * (size_t)w.blocks_cap, c->stream));
     return PEDP_OK;
 }
 
 // Enqueue one correspondence pass (transform, sweep, fallback).  mode as in
 // icp_transform_pack_kernel.
 int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int mode,
-                    const TargetPrep &tp, double r, bool timed, bool exhaustive = false) {
+                    const TargetPrep &tp, double r, hipEvent_t ev0, hipEvent_t ev1, bool exhaustive = false) {
     const int64_t Ns = src->N, Nt = tgt->N;
     // r1: distance scale of the candidates the bound must hold for (anything farther is
     // not an inlier anyway); huge radii fall back to the cloud scale inside the kernel.
@@ -1222,11 +2153,11 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     }
 #define PEDP_NN_STAGE(QTV, GV)                                                                                          \
     do {                                                                                                              \
-        if (timed) PEDP_HIP_CHECK(hipEventRecord(c->nn_ev0, c->stream));                                              \
+        if (ev0) PEDP_HIP_CHECK(hipEventRecord(ev0, c->stream));                                                      \
         hipLaunchKernelGGL((nn_sweep_kernel<QTV, GV>), dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,            \
                            (const float *)w.tgt4, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0, w.seg_n,         \
                            (const float *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);                                            \
-        if (timed) { PEDP_HIP_CHECK(hipEventRecord(c->nn_ev1, c->stream)); c->nn_timed = true; }                       \
+        if (ev1) { PEDP_HIP_CHECK(hipEventRecord(ev1, c->stream)); c->nn_timed = true; }                               \
         hipLaunchKernelGGL(nn_select_kernel<QTV>, dim3(sel_grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,       \
                            w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx,   \
                            w.d2, w.fb);                                                                               \
@@ -1236,6 +2167,39 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     if (w.qt == 4) PEDP_NN_STAGE(4, 2);
     else PEDP_NN_STAGE(1, 4);
 #undef PEDP_NN_STAGE
+    PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
+// Margin of the live set beyond the correspondence radius (see the fused-pass comment).
+inline double fused_margin(double r) { return 2.0 * r; }
+
+// Enqueue the chunk kernel of a fused pass.
+int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int pass, int estimator,
+                       const TargetPrep &tp, double r, hipEvent_t ev0, hipEvent_t ev1) {
+    const double margin = fused_margin(r);
+    PassArgs pa;
+    pa.src = src->pts; pa.perm = w.src_perm; pa.N = src->N; pa.n_chunks = w.n_chunks;
+    pa.hist = w.hist; pa.pass = pass; pa.Pk = w.Pk; pa.Tprev = w.Tprev; pa.live = w.live; pa.live_list = w.live_list;
+    pa.tgtf = (const float *)w.tgt4; pa.n_tiles = (int)(w.Nt_pad / 16); pa.n_words = w.n_words;
+    pa.tile_sph = w.tile_sph; pa.word_sph = w.word_sph; pa.tgt_s = w.tgt_s; pa.tperm = w.tgt_perm; pa.Nt = tgt->N;
+    pa.tgt = tgt->pts; pa.nrm = tgt->normals;
+    pa.Tn = tp.Tn; pa.T2 = tp.T2; pa.r1 = (float)(r * 1.01);
+    pa.r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
+    pa.wide_radius = (float)r;
+    pa.r2f = (float)(r * r) * 1.00001f;
+    pa.r2 = r * r;
+    pa.r2cut = r * r * (1.0 + 1e-12);
+    pa.r2live = (r + margin) * (r + margin) * (1.0 + 1e-12);
+    for (int k = 0; k < 3; ++k) { pa.lo[k] = tp.lo[k]; pa.hi[k] = tp.hi[k]; }
+    pa.estimator = estimator; pa.idx_out = w.idx; pa.partials = w.cpart;
+    // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
+    int64_t g = w.n_chunks;
+    if (g > 2 * c->num_cus) g = 2 * c->num_cus;
+    if (g < 1) g = 1;
+    if (ev0) PEDP_HIP_CHECK(hipEventRecord(ev0, c->stream));
+    hipLaunchKernelGGL(icp_pass_kernel<BK_W>, dim3((unsigned)g), dim3(BK_W * 64), 0, c->stream, w.st, pa);
+    if (ev1) { PEDP_HIP_CHECK(hipEventRecord(ev1, c->stream)); c->nn_timed = true; }
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1261,25 +2225,23 @@ int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl, const double *roi) {
         PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
         for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = 0.0; cl->perm_hi[k] = -1.0; }  // no region yet: every request rebuilds
     }
-    struct HistGuard {  // freed on every exit path
+    struct KeyGuard {  // freed on every exit path
         unsigned *p = nullptr;
-        ~HistGuard() { if (p) (void)hipFree(p); }
+        ~KeyGuard() { if (p) (void)hipFree(p); }
     } guard;
-    PEDP_HIP_CHECK(hipMalloc((void **)&guard.p, sizeof(unsigned) * (SORT_CELLS + 1)));
-    unsigned *hist = guard.p;
-    PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * (SORT_CELLS + 1), c->stream));
+    PEDP_HIP_CHECK(hipMalloc((void **)&guard.p, sizeof(unsigned) * (size_t)cl->N));
     double sc[3];
     for (int k = 0; k < 3; ++k) {
         double ext = hi[k] - lo[k];
         sc[k] = ext > 0.0 ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
     }
     const unsigned grid = (unsigned)((cl->N + 255) / 256);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2],
-                       sc[0], sc[1], sc[2], hist);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2],
-                       sc[0], sc[1], sc[2], hist, (int32_t *)cl->perm);
+    hipLaunchKernelGGL(cell_key_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2], sc[0],
+                       sc[1], sc[2], guard.p);
     PEDP_HIP_CHECK(hipGetLastError());
+    // keys 0 .. SORT_CELLS (the outside bucket): 3 SORT_BITS + 1 bits
+    int rcs = pedp_stable_sort_by_key(c, guard.p, cl->N, 3 * SORT_BITS + 1, (int32_t *)cl->perm);
+    if (rcs) return rcs;
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = lo[k]; cl->perm_hi[k] = hi[k]; }  // valid only now
     return PEDP_OK;
@@ -1314,20 +2276,27 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
     // all three or none: a half-built pack must not look finished to the next call
-    void *t4 = nullptr, *s1 = nullptr, *s4 = nullptr;
+    void *t4 = nullptr, *s1 = nullptr, *s4 = nullptr, *sw = nullptr, *ts = nullptr;
+    const int64_t n_wsph = (pad / 16 + 63) / 64;  // one sphere per mask word of 16-row tiles (1024 rows)
     hipError_t e = hipMalloc(&t4, sizeof(float4) * (size_t)pad);
     if (e == hipSuccess) e = hipMalloc(&s1, sizeof(float4) * (size_t)(pad / 16));
     if (e == hipSuccess) e = hipMalloc(&s4, sizeof(float4) * (size_t)(pad / 64));
+    if (e == hipSuccess) e = hipMalloc(&sw, sizeof(float4) * (size_t)n_wsph);
+    if (e == hipSuccess) e = hipMalloc(&ts, sizeof(double) * 3 * (size_t)pad);
     if (e != hipSuccess) {
         if (t4) (void)hipFree(t4);
         if (s1) (void)hipFree(s1);
         if (s4) (void)hipFree(s4);
+        if (sw) (void)hipFree(sw);
+        if (ts) (void)hipFree(ts);
         pedp_set_error("pedp_icp: target pack allocation failed: %s", hipGetErrorString(e));
         return PEDP_ERR_ALLOC;
     }
     tgt->tgt4 = t4;
     tgt->tile_sph = s1;
     tgt->tile_sph4 = s4;
+    tgt->tile_sphw = sw;
+    tgt->tgt_s = ts;
     tgt->tgt4_pad = pad;
     int64_t grid = (pad + 255) / 256;
     hipLaunchKernelGGL(pack_target_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
@@ -1336,6 +2305,10 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
                        (const float4 *)tgt->tgt4, tgt->N, pad / 16, 16, (float4 *)tgt->tile_sph);
     hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((pad / 64 + 255) / 256)), dim3(256), 0, c->stream,
                        (const float4 *)tgt->tgt4, tgt->N, pad / 64, 64, (float4 *)tgt->tile_sph4);
+    hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((n_wsph + 63) / 64)), dim3(64), 0, c->stream,
+                       (const float4 *)tgt->tgt4, tgt->N, n_wsph, 1024, (float4 *)tgt->tile_sphw);
+    hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
+                       (const int32_t *)tgt->perm, tgt->N, pad, (double *)tgt->tgt_s);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1410,9 +2383,15 @@ int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const 
     job.exhaustive = x->icp_exhaustive;
     job.timed_pass = x->icp_timed_pass;
     IcpWorkspace &w = job.w;
-    int rc = carve_workspace(x, job.Ns, job.Nt, job.max_iter, job.qt, w);
+    const double r = prm->max_correspondence_distance;
+    // the fused pass lists a target's mask words in LDS: up to BK_WCAP words of 1024 rows
+    const bool fused = job.qt == 1 && !job.exhaustive && r > 0.0 && job.Ns > 0 && job.Nt > 0 &&
+                       (job.Nt + 1023) / 1024 <= BK_WCAP;
+    int rc = carve_workspace(x, job.Ns, job.Nt, job.max_iter, job.qt, w, fused);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
+    w.word_sph = (const float4 *)target->tile_sphw;
+    w.tgt_s = (const double *)target->tgt_s;
     w.tile_sph = (const float4 *)(job.qt == 4 ? target->tile_sph4 : target->tile_sph);
     w.tgt_perm = (const int32_t *)target->perm;
     w.src_perm = (const int32_t *)source->perm;
@@ -1425,6 +2404,7 @@ void icp_fill_state(pedp_ctx_t x, const TargetPrep &tp, const double init[16]) {
     IcpState h{};
     for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
+    h.rebuild = 1;  // fused pass: pass 0 builds the live chunk set from the whole scene
     *(IcpState *)x->pinned = h;
 }
 
@@ -1445,9 +2425,57 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     const double r2 = r * r;
     const double ng = n_global > 0 ? n_global : 1.0;
     const bool exchange = prm->allreduce || prm->use_comm;  // the packet is summed over ranks before the solve
+    const bool fused = w.fused && !degenerate;
+    double reachE = 0.0, bc[3] = {0, 0, 0};
+    if (fused) {
+        // history slot 0 = the start transformation; the live mask starts empty
+        PEDP_HIP_CHECK(hipMemcpyAsync(w.hist, hp->T, sizeof(double) * 16, hipMemcpyHostToDevice, x->stream));
+        PEDP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(unsigned long long) * (size_t)w.n_lw, x->stream));
+        double rho2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
+            rho2 += 0.25 * (tp.hi[k] - tp.lo[k]) * (tp.hi[k] - tp.lo[k]);
+        }
+        reachE = r + fused_margin(r) + std::sqrt(rho2);
+    }
+    if (job.timed_pass != -1) x->nn_pairs = 0;
     for (int pass = 0; pass <= max_iter; ++pass) {
+        // timing: one chosen pass (pair nn_ev0/1), or -- timed_pass = -2 -- every fourth pass from
+        // pass 1 on, up to eight pairs, whose mean pedp_nn_last_sweep_ms reports
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (pass == job.timed_pass) { ev0 = x->nn_ev0; ev1 = x->nn_ev1; }
+        if (job.timed_pass == -2 && (pass & 3) == 1 && x->nn_pairs < 8) {
+            for (int k = 0; k < 2; ++k)
+                if (!x->nn_evs[2 * x->nn_pairs + k]) PEDP_HIP_CHECK(hipEventCreate(&x->nn_evs[2 * x->nn_pairs + k]));
+            ev0 = x->nn_evs[2 * x->nn_pairs];
+            ev1 = x->nn_evs[2 * x->nn_pairs + 1];
+            ++x->nn_pairs;
+        }
+        if (fused) {
+            rc = enqueue_fused_pass(x, w, source, target, pass, prm->estimator, tp, r, ev0, ev1);
+            if (rc) return rc;
+            int phase = 0;
+            if (exchange) {
+                hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 1,
+                                   pass, max_iter, prm->estimator, ng, prm->relative_fitness, prm->relative_rmse,
+                                   want_trace ? w.trace : nullptr, w.hist, reachE, fused_margin(r), bc[0], bc[1], bc[2]);
+                if (prm->use_comm) {
+                    rc = pedp_comm_allreduce_sum_f64(x, w.packet, PACKET);
+                    if (rc) { (void)hipStreamSynchronize(x->stream); return rc; }
+                } else if (prm->allreduce(prm->allreduce_user, w.packet, PACKET, (void *)x->stream) != 0) {
+                    pedp_set_error("pedp_icp: all-reduce hook failed in pass %d", pass);
+                    (void)hipStreamSynchronize(x->stream);
+                    return PEDP_ERR_COLLECTIVE;
+                }
+                phase = 2;
+            }
+            hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, phase,
+                               pass, max_iter, prm->estimator, ng, prm->relative_fitness, prm->relative_rmse,
+                               want_trace ? w.trace : nullptr, w.hist, reachE, fused_margin(r), bc[0], bc[1], bc[2]);
+            PEDP_HIP_CHECK(hipGetLastError());
+        } else {
         if (!degenerate) {
-            rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, pass == job.timed_pass, job.exhaustive);
+            rc = enqueue_nn_pass(x, w, source, target, pass == 0 ? 0 : 1, tp, r, ev0, ev1, job.exhaustive);
             if (rc) return rc;
             hipLaunchKernelGGL(icp_accumulate_kernel, dim3(ACC_BLOCKS), dim3(ACC_THREADS), 0, x->stream, w.st,
                                prm->estimator, w.P, Ns, target->pts, target->normals, w.idx, w.d2, r2, w.partials);
@@ -1472,6 +2500,7 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
         hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(256), 0, x->stream, w.st, w.packet, fold, pass, max_iter,
                            prm->estimator, ng, prm->relative_fitness, prm->relative_rmse, want_trace ? w.trace : nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
+        }
         // Passes after convergence are no-ops on the device but still cost launches; with the
         // early exit enabled, look at the flag every 8th pass (one 4-byte read-back, identical
         // on every rank of a sharded run) and stop enqueuing once it is set.
@@ -1646,7 +2675,8 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     *hp = h;
     PEDP_HIP_CHECK(hipMemcpyAsync(w.st, hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
     // every point is a candidate: radius = "infinite" (cloud scale bound)
-    rc = enqueue_nn_pass(c, w, source, target, 0, tp, 1e18, true);
+    c->nn_pairs = 0;
+    rc = enqueue_nn_pass(c, w, source, target, 0, tp, 1e18, c->nn_ev0, c->nn_ev1);
     if (rc) return rc;
     PEDP_HIP_CHECK(hipMemcpyAsync(idx, w.idx, sizeof(int32_t) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipMemcpyAsync(d2, w.d2, sizeof(double) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
@@ -1675,6 +2705,17 @@ int pedp_nn_last_sweep_ms(pedp_ctx_t c, float *ms) {
     PEDP_REQUIRE(c && ms, "pedp_nn_last_sweep_ms: null argument");
     PEDP_REQUIRE(c->nn_timed, "pedp_nn_last_sweep_ms: no timed sweep has run on this context");
     PEDP_HIP_CHECK(hipSetDevice(c->device));
+    if (c->nn_pairs > 0) {  // sampled passes: the mean
+        float sum = 0.f;
+        for (int k = 0; k < c->nn_pairs; ++k) {
+            float one = 0.f;
+            PEDP_HIP_CHECK(hipEventSynchronize(c->nn_evs[2 * k + 1]));
+            PEDP_HIP_CHECK(hipEventElapsedTime(&one, c->nn_evs[2 * k], c->nn_evs[2 * k + 1]));
+            sum += one;
+        }
+        *ms = sum / (float)c->nn_pairs;
+        return PEDP_OK;
+    }
     PEDP_HIP_CHECK(hipEventSynchronize(c->nn_ev1));
     PEDP_HIP_CHECK(hipEventElapsedTime(ms, c->nn_ev0, c->nn_ev1));
     return PEDP_OK;

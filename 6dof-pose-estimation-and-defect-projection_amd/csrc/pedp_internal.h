@@ -9,6 +9,8 @@
 
 void pedp_set_error(const char *fmt, ...);
 uint64_t pedp_next_generation();
+struct pedp_ctx_s;
+int pedp_stable_sort_by_key(pedp_ctx_s *c, unsigned *d_keys, int64_t N, int bits, int32_t *d_perm);
 
 #define PEDP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
@@ -70,6 +72,10 @@ struct pedp_ctx_s {
     bool ray_timed = false;
     bool nn_timed = false;
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;
+    // sampled timing of a registration's sweep kernels (pedp_icp_configure timed_pass = -2): event
+    // pairs around the sweep kernel of every fourth pass, created on first use
+    hipEvent_t nn_evs[16] = {};
+    int nn_pairs = 0;  // pairs recorded by the last timed registration (0: the single pair above)
     // ICP
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
@@ -128,5 +134,7 @@ struct pedp_cloud_s {
     void *tgt4 = nullptr;
     void *tile_sph = nullptr;   // one sphere per 16 sorted rows
     void *tile_sph4 = nullptr;  // one sphere per 64 sorted rows
+    void *tile_sphw = nullptr;  // one sphere per 1024 sorted rows (one cull-mask word of 16-row tiles)
+    void *tgt_s = nullptr;      // sorted rows as float64 x 3 (exact re-scoring)
     int64_t tgt4_pad = 0;
 };

@@ -141,8 +141,8 @@ class HipBackend:
         if self.native:
             _lib.comm_allgather(self.ctx, send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size())
         else:
-            with self.ordered():
-                dist.all_gather_into_tensor(recv, send, group=group)
+            with self.ordered():  # flat views: gloo checks the shapes literally
+                dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
 
     # ---- rays
     def make_mesh(self, vertices_f32, triangles):
@@ -201,7 +201,7 @@ def _gather_rows(backend, rows, world, group):
             host = out.cpu()
     else:
         with _ordered(backend):
-            dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
+            dist.all_gather_into_tensor(out.view(-1), rows.contiguous().view(-1), group=group)
             host = out.cpu()
     return host.numpy().reshape((world,) + tuple(rows.shape))
 

@@ -230,7 +230,10 @@ int pedp_icp(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
 /* Batched refine (FoundationPose hypothesis sizing, estimater.py:104-122): B start
  * poses share one source and one target; no early exit across the batch.  Up to 8 registrations
  * are in flight on internal streams (each replaying one captured hipGraph per pose); the call
- * returns when all are complete.  Results equal B separate pedp_icp calls bit for bit. */
+ * returns when all are complete.  Results equal B separate pedp_icp calls on the same handles bit
+ * for bit (the float64 sums follow the scene's cached spatial order; a different order -- another
+ * handle, another region of start poses -- gives the same correspondences and poses equal to
+ * rounding). */
 int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
                      const pedp_icp_params *params, const double *inits /* B x 16 */, int B,
                      double *T_out /* B x 16 */, double *fitness /* B */,
@@ -250,7 +253,10 @@ int pedp_nn_last_sweep_ms(pedp_ctx_t ctx, float *ms);
  *     every (scene point, target point) pair in every pass (the all-pairs workload of SURVEY s8d);
  *     correspondences and poses are identical to the culled run, only the work differs.
  *   timed_pass >= 0: record HIP events around the sweep kernel of that correspondence pass (read
- *     with pedp_nn_last_sweep_ms); -1 = none. */
+ *     with pedp_nn_last_sweep_ms); -2: around the sweep kernel of every fourth pass from pass 1 on
+ *     (up to eight), pedp_nn_last_sweep_ms then reports their mean; -1 = none.
+ * "Sweep kernel": nn_sweep_kernel on the segmented path, icp_pass_kernel (the whole per-chunk
+ * pass, sweep included) on the fused path of radius-limited registrations. */
 int pedp_icp_configure(pedp_ctx_t ctx, int exhaustive, int timed_pass);
 
 /* Work statistics of the last pedp_icp on this context: correspondence passes run, (scene,
