@@ -75,6 +75,8 @@ PROTOTYPES = {
                            _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_void_p, C.c_void_p]),
     "pedp_icp_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_icp_batched_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
@@ -439,6 +441,35 @@ def icp_batched(ctx, source, target, max_correspondence_distance, inits, estimat
     check(load().pedp_icp_batched(ctx._h, source._h, target._h, C.byref(prm), _ptr(I), B, _ptr(T), _ptr(fit),
                                   _ptr(rmse)), "pedp_icp_batched")
     return T, fit, rmse
+
+
+def icp_batched_ex(ctx, source, target, radii, inits, estimator=POINT_TO_PLANE, max_iteration=30,
+                   relative_fitness=1e-6, relative_rmse=1e-6):
+    """B registrations with their own radius each (and the given criteria, a scalar or one per pose),
+    each stopping by its own criteria.  Returns (T [B,4,4], fitness [B], rmse [B], iterations [B])."""
+    I = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 16)
+    B = len(I)
+    rad = np.broadcast_to(np.asarray(radii, dtype=np.float64), (B,))
+    rf = np.broadcast_to(np.asarray(relative_fitness, dtype=np.float64), (B,))
+    rr = np.broadcast_to(np.asarray(relative_rmse, dtype=np.float64), (B,))
+    prms = (IcpParams * max(B, 1))()
+    for b in range(B):
+        q = prms[b]
+        q.max_correspondence_distance = float(rad[b])
+        q.estimator = int(estimator)
+        q.max_iteration = int(max_iteration)
+        q.relative_fitness = float(rf[b])
+        q.relative_rmse = float(rr[b])
+        q.allreduce = C.cast(None, ALLREDUCE_FN)
+        q.allreduce_user = None
+        q.n_source_global = 0
+        q.use_comm = 0
+    T = np.empty((B, 4, 4), np.float64)
+    fit, rmse = np.empty(B, np.float64), np.empty(B, np.float64)
+    its = np.empty(B, np.int32)
+    check(load().pedp_icp_batched_ex(ctx._h, source._h, target._h, prms, _ptr(I), B, _ptr(T), _ptr(fit), _ptr(rmse),
+                                     _ptr(its)), "pedp_icp_batched_ex")
+    return T, fit, rmse, its
 
 
 def nn(ctx, source, target, T=None):

@@ -90,6 +90,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
         c->sub[k] = nullptr;
     }
     if (c->icp_graph) (void)hipGraphExecDestroy(c->icp_graph);
+    for (hipGraphExec_t g : c->icp_bgraph)
+        if (g) (void)hipGraphExecDestroy(g);
     c->ray_keys.release();
     c->ray_in.release();
     c->ray_out.release();

@@ -103,6 +103,13 @@ struct IcpState {
     int rebuild;
     int n_rebuilds;
     int n_live;                // entries of the live list (written by icp_finish_kernel)
+    // parameters of this registration that the fused pass reads from here rather than from kernel
+    // arguments, so that one captured graph serves start poses with different radii and criteria
+    double r2, r2cut, r2live;  // r^2; rounding-safe r^2 of the box test; (r + margin)^2 of the live test
+    double reachE, margin;     // motion bound: r + margin + rho, margin
+    double rel_fitness, rel_rmse, n_source;
+    float r1, r_search, wide_radius, r2f;
+    int pass, max_iter;        // the pass the fused kernels are in (advanced by icp_finish_kernel), and the limit
     double mu_theta, mu_tau;   // sum of |R - I|_F and of |t + (R - I) c| since the last rebuild
 };
 
@@ -893,7 +900,6 @@ struct PassArgs {
     int64_t N;
     int n_chunks;
     const double *hist;         // [pass + 1][16]: init, then the update of every pass so far
-    int pass;
     double *Pk;                 // N_pad x 3: transformed points in spatial order (live chunks)
     double *Tprev;              // N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none)
     unsigned long long *live;
@@ -906,14 +912,26 @@ struct PassArgs {
     const int32_t *tperm;       // sorted row -> target index
     int64_t Nt;
     const double *tgt, *nrm;
-    // parameters
-    float Tn, T2, r1, r_search, wide_radius, r2f;
-    double r2, r2cut, r2live;
+    // parameters (the radius-dependent ones live in IcpState)
+    float Tn, T2;
     double lo[3], hi[3];
     int estimator;
     int32_t *idx_out;
     double *partials;           // n_chunks x PSTRIDE: by chunk id in a rebuild pass, by live rank otherwise
+    // Several start poses of one (scene, target) pair share a launch: pose b = blockIdx.y owns the
+    // state and the per-pose buffers (Pk, Tprev, live, live_list, hist, idx_out, partials) b * pose_stride
+    // bytes behind pose 0's.
+    size_t pose_stride;
 };
+
+template <typename T>
+__device__ __host__ __forceinline__ T *pose_ptr(T *p, size_t bytes) {
+    return (T *)((char *)p + bytes);
+}
+template <typename T>
+__device__ __host__ __forceinline__ const T *pose_ptr(const T *p, size_t bytes) {
+    return (const T *)((const char *)p + bytes);
+}
 
 // exact float64 scan of the rows of the tiles in `near` (one bit per lane's tile), 64 rows per trip
 __device__ __forceinline__ void scan_near_tiles(unsigned long long near, int unit_of_lane, const PassArgs &a, double qx,
@@ -936,8 +954,14 @@ __device__ __forceinline__ void scan_near_tiles(unsigned long long near, int uni
 }
 
 template <int W>
-__global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__restrict__ st, const PassArgs a) {
+__global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__restrict__ st0, const PassArgs a0) {
     static_assert(W * 64 == 4 * CH, "four threads per slot");
+    const size_t pose_off = (size_t)blockIdx.y * a0.pose_stride;
+    const IcpState *__restrict__ st = pose_ptr(st0, pose_off);
+    PassArgs a = a0;
+    a.Pk = pose_ptr(a0.Pk, pose_off); a.Tprev = pose_ptr(a0.Tprev, pose_off); a.live = pose_ptr(a0.live, pose_off);
+    a.live_list = pose_ptr(a0.live_list, pose_off); a.hist = pose_ptr(a0.hist, pose_off);
+    a.idx_out = pose_ptr(a0.idx_out, pose_off); a.partials = pose_ptr(a0.partials, pose_off);
     __shared__ float tri_b1[W][4 * BK_QS];
     __shared__ int tri_t1[W][4 * BK_QS], m2key[4 * BK_QS];
     __shared__ unsigned tl[BK_TL + 8];
@@ -953,7 +977,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
     int chunk_next = a.live_list[blockIdx.x < (unsigned)a.n_chunks ? blockIdx.x : 0];
     if (st->done) return;
     const bool rebuild = st->rebuild != 0;
-    const int n_live = st->n_live;
+    const int n_live = st->n_live, pass = st->pass;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int frag_slot = lane & 15, frag_comp = lane >> 4;  // MFMA B fragment: slot in the sub-block, component
     const int frag = frag_slot * 4 + frag_comp;              // float offset inside a 16-point target tile
@@ -961,6 +985,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
     const float inf = __uint_as_float(0x7F800000u);
     const double dinf = __longlong_as_double(0x7FF0000000000000ll);
     const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
+    const float r_search = st->r_search;
     // word spheres do not depend on the chunk: requested before anything else, parked in LDS
     wsph[tid] = a.word_sph[tid < a.n_words ? tid : 0];
     for (int unit = blockIdx.x;; unit += gridDim.x) {
@@ -989,7 +1014,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
                 pi = a.perm[k];
                 if (rebuild) {
                     x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
-                    for (int q = 0; q <= a.pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                    for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
                 } else {
                     x = a.Pk[3 * k]; y = a.Pk[3 * k + 1]; z = a.Pk[3 * k + 2];
                     const double ux = a.Tprev[3 * k], uy = a.Tprev[3 * k + 1], uz = a.Tprev[3 * k + 2];
@@ -1002,8 +1027,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
                 const double ex = fmax(fmax(a.lo[0] - x, x - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - y, y - a.hi[1]), 0.0),
                              ez = fmax(fmax(a.lo[2] - z, z - a.hi[2]), 0.0);
                 const double d2box = ex * ex + ey * ey + ez * ez;
-                cand = d2box <= a.r2cut;   // r2cut = r^2 (1 + 1e-12): rounding-safe
-                near = d2box <= a.r2live;
+                cand = d2box <= st->r2cut;   // r2cut = r^2 (1 + 1e-12): rounding-safe
+                near = d2box <= st->r2live;
             }
             const unsigned long long mc = __builtin_amdgcn_ballot_w64(cand), mn = __builtin_amdgcn_ballot_w64(near);
             const int wc = __builtin_popcountll(mc);
@@ -1020,7 +1045,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
                 // error bound of the fp32 surrogate against the float64 distance, see pack_store()
                 const float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
                 const float Mi = 2.0f * s1 * a.Tn + a.T2;
-                sel_e[sl] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(a.r1, s1 + a.Tn) * (a.Tn + s1)) * 1.0001f;
+                sel_e[sl] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(st->r1, s1 + a.Tn) * (a.Tn + s1)) * 1.0001f;
                 sel_S[sl] = sx * sx + sy * sy + sz * sz;
                 sel_i[sl] = pi;
                 sel_k[sl] = (unsigned char)tid;
@@ -1028,7 +1053,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
                 cs[0][sl] = sx; cs[1][sl] = sy; cs[2][sl] = sz;
                 // search radius of the slot: the distance to last pass's neighbour, rounded up, at most r
                 const float rp = (float)dprev * 1.00001f + 1e-5f * s1 + 1e-6f;
-                rho_s[sl] = rp < a.r_search ? rp : a.r_search;
+                rho_s[sl] = rp < r_search ? rp : r_search;
             }
             if (lane >= wc) {  // dummies behind the wave's candidates: never inliers, never selected
                 const int sl = base + lane;
@@ -1083,7 +1108,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
         }
         unsigned wide = 0;
 #pragma unroll
-        for (int sb = 0; sb < NN_SB; ++sb) wide |= (bsph[sb].w > a.wide_radius ? 1u : 0u) << sb;
+        for (int sb = 0; sb < NN_SB; ++sb) wide |= (bsph[sb].w > st->wide_radius ? 1u : 0u) << sb;
         if (tid == 0) PEDP_STAMP(1, blockIdx.x, 1);
         // ---- 4. culling, level 1: thread t tests the sphere of mask word t (64 tiles = 1024 sorted rows);
         // surviving words listed in ascending order
@@ -1209,7 +1234,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
             float m2 = fkey_inv(m2key[gl * BK_QS + sslot]);
             float mg = fminf(m, __shfl_xor(m, 1, 64)); mg = fminf(mg, __shfl_xor(mg, 2, 64));
             m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
-            const bool maybe = mg + Si <= a.r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
+            const bool maybe = mg + Si <= st->r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
             const float win = mg + 2.0f * e;
             double bd = dinf;
             int bj = 0x7FFFFFFF;
@@ -1312,7 +1337,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
             int j = res_j[slot];
             const double dd = res_d[slot];
             if (i >= 0) {
-                if (j >= 0 && !(dd < a.r2)) j = -1;  // strict, as SearchHybrid's lower_bound
+                if (j >= 0 && !(dd < st->r2)) j = -1;  // strict, as SearchHybrid's lower_bound
                 const int64_t kp = (int64_t)chunk * CH + sel_k[slot];
                 if (g == 0) {
                     a.idx_out[i] = j;
@@ -1790,14 +1815,19 @@ __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__
 // Order of the sum: 8 contiguous ranges of live-mask words, chunks ascending inside a range, then
 // the ranges in order -- a function of the live set alone.
 constexpr int FIN_THREADS = 1024;
-__global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *__restrict__ st, unsigned long long *__restrict__ live,
-                                                         int32_t *__restrict__ live_list, int n_lw,
-                                                         const double *__restrict__ partials,
-                                                         double *__restrict__ packet, int phase, int pass, int max_iter,
-                                                         int estimator, double n_source, double rel_fitness, double rel_rmse,
-                                                         double *__restrict__ trace, double *__restrict__ hist, double reachE,
-                                                         double margin, double bcx, double bcy, double bcz) {
+__global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, unsigned long long *live, int32_t *live_list,
+                                                         int n_lw, const double *partials, double *packet, int phase, int estimator,
+                                                         double *__restrict__ trace, double *__restrict__ hist,
+                                                         double bcx, double bcy, double bcz, size_t pose_stride) {
+    {   // pose b = blockIdx.x of a batch: its state and buffers are b * pose_stride bytes behind pose 0's
+        const size_t off = (size_t)blockIdx.x * pose_stride;
+        st = pose_ptr(st, off); live = pose_ptr(live, off); live_list = pose_ptr(live_list, off);
+        partials = pose_ptr(partials, off); packet = pose_ptr(packet, off); hist = pose_ptr(hist, off);
+    }
     if (st->done) return;
+    const int pass = st->pass, max_iter = st->max_iter;
+    const double n_source = st->n_source, rel_fitness = st->rel_fitness, rel_rmse = st->rel_rmse, reachE = st->reachE,
+                 margin = st->margin;
     constexpr int PARTS = FIN_THREADS / 32;
     __shared__ double slice[PARTS][32], pk[32];
     __shared__ int lst[LIVE_CAP], scan[FIN_THREADS];
@@ -1973,6 +2003,7 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *__res
                 st->n_rebuilds += 1;
             }
             st->rebuild = do_rebuild;
+            st->pass = pass + 1;
         }
         PEDP_STAMP(2, 0, 3);
     }
@@ -2015,9 +2046,11 @@ struct IcpWorkspace {
     int n_lw, n_chunks;
     const float4 *word_sph;
     const double *tgt_s;
+    size_t pose_stride;  // bytes between the per-pose blocks of a batch (all pointers above are pose 0's)
 };
 
-int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w, bool fused = false) {
+int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w, bool fused = false,
+                    int poses = 1) {
     w.qt = qt;
     w.fused = fused;
     w.Ns_pad = (int64_t)align_up((size_t)(Ns > 0 ? Ns : 1), NN_PTS_PER_WG);
@@ -2079,7 +2112,9 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
         o_live = take(sizeof(unsigned long long) * (size_t)w.n_lw);
         o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
     }
-    int st = c->icp_ws.reserve(off);
+    off = align_up(off, 4096);
+    w.pose_stride = off;  // a batch lays `poses` such blocks one behind the other
+    int st = c->icp_ws.reserve(off * (size_t)(poses > 0 ? poses : 1));
     if (st) return st;
     char *b = (char *)c->icp_ws.ptr;
     w.st = (IcpState *)(b + o_st);
@@ -2175,30 +2210,24 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
 inline double fused_margin(double r) { return 2.0 * r; }
 
 // Enqueue the chunk kernel of a fused pass.
-int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int pass, int estimator,
-                       const TargetPrep &tp, double r, hipEvent_t ev0, hipEvent_t ev1) {
-    const double margin = fused_margin(r);
+int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int estimator,
+                       const TargetPrep &tp, hipEvent_t ev0, hipEvent_t ev1, int poses = 1) {
     PassArgs pa;
     pa.src = src->pts; pa.perm = w.src_perm; pa.N = src->N; pa.n_chunks = w.n_chunks;
-    pa.hist = w.hist; pa.pass = pass; pa.Pk = w.Pk; pa.Tprev = w.Tprev; pa.live = w.live; pa.live_list = w.live_list;
+    pa.hist = w.hist; pa.Pk = w.Pk; pa.Tprev = w.Tprev; pa.live = w.live; pa.live_list = w.live_list;
     pa.tgtf = (const float *)w.tgt4; pa.n_tiles = (int)(w.Nt_pad / 16); pa.n_words = w.n_words;
     pa.tile_sph = w.tile_sph; pa.word_sph = w.word_sph; pa.tgt_s = w.tgt_s; pa.tperm = w.tgt_perm; pa.Nt = tgt->N;
     pa.tgt = tgt->pts; pa.nrm = tgt->normals;
-    pa.Tn = tp.Tn; pa.T2 = tp.T2; pa.r1 = (float)(r * 1.01);
-    pa.r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
-    pa.wide_radius = (float)r;
-    pa.r2f = (float)(r * r) * 1.00001f;
-    pa.r2 = r * r;
-    pa.r2cut = r * r * (1.0 + 1e-12);
-    pa.r2live = (r + margin) * (r + margin) * (1.0 + 1e-12);
+    pa.Tn = tp.Tn; pa.T2 = tp.T2;
     for (int k = 0; k < 3; ++k) { pa.lo[k] = tp.lo[k]; pa.hi[k] = tp.hi[k]; }
     pa.estimator = estimator; pa.idx_out = w.idx; pa.partials = w.cpart;
+    pa.pose_stride = poses > 1 ? w.pose_stride : 0;
     // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
     int64_t g = w.n_chunks;
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
     if (g < 1) g = 1;
     if (ev0) PEDP_HIP_CHECK(hipEventRecord(ev0, c->stream));
-    hipLaunchKernelGGL(icp_pass_kernel<BK_W>, dim3((unsigned)g), dim3(BK_W * 64), 0, c->stream, w.st, pa);
+    hipLaunchKernelGGL(icp_pass_kernel<BK_W>, dim3((unsigned)g, (unsigned)poses), dim3(BK_W * 64), 0, c->stream, w.st, pa);
     if (ev1) { PEDP_HIP_CHECK(hipEventRecord(ev1, c->stream)); c->nn_timed = true; }
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
@@ -2400,12 +2429,29 @@ int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const 
 
 // start state of a registration in the executor's pinned block (uploaded by the first node of
 // icp_enqueue; the same block receives the final state)
-void icp_fill_state(pedp_ctx_t x, const TargetPrep &tp, const double init[16]) {
+void icp_fill_state(IcpState *dst, const TargetPrep &tp, const double init[16], const pedp_icp_params *prm, int64_t Ns) {
     IcpState h{};
     for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
     h.rebuild = 1;  // fused pass: pass 0 builds the live chunk set from the whole scene
-    *(IcpState *)x->pinned = h;
+    const double r = prm->max_correspondence_distance, margin = fused_margin(r);
+    double rho2 = 0.0;
+    for (int k = 0; k < 3; ++k) rho2 += 0.25 * (tp.hi[k] - tp.lo[k]) * (tp.hi[k] - tp.lo[k]);
+    h.r2 = r * r;
+    h.r2cut = r * r * (1.0 + 1e-12);
+    h.r2live = (r + margin) * (r + margin) * (1.0 + 1e-12);
+    h.reachE = r + margin + std::sqrt(rho2);
+    h.margin = margin;
+    h.rel_fitness = prm->relative_fitness;
+    h.rel_rmse = prm->relative_rmse;
+    const double ng = prm->n_source_global > 0 ? (double)prm->n_source_global : (double)Ns;
+    h.n_source = ng > 0 ? ng : 1.0;
+    h.r1 = (float)(r * 1.01);
+    h.r_search = (float)(r * (1.0 + 1e-6)) + 1e-6f;
+    h.wide_radius = (float)r;
+    h.r2f = (float)(r * r) * 1.00001f;
+    h.max_iter = prm->max_iteration;
+    *dst = h;
 }
 
 // every pass of one registration on x's stream; nothing here allocates or synchronises unless
@@ -2426,17 +2472,12 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     const double ng = n_global > 0 ? n_global : 1.0;
     const bool exchange = prm->allreduce || prm->use_comm;  // the packet is summed over ranks before the solve
     const bool fused = w.fused && !degenerate;
-    double reachE = 0.0, bc[3] = {0, 0, 0};
+    double bc[3] = {0, 0, 0};
     if (fused) {
         // history slot 0 = the start transformation; the live mask starts empty
         PEDP_HIP_CHECK(hipMemcpyAsync(w.hist, hp->T, sizeof(double) * 16, hipMemcpyHostToDevice, x->stream));
         PEDP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(unsigned long long) * (size_t)w.n_lw, x->stream));
-        double rho2 = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
-            rho2 += 0.25 * (tp.hi[k] - tp.lo[k]) * (tp.hi[k] - tp.lo[k]);
-        }
-        reachE = r + fused_margin(r) + std::sqrt(rho2);
+        for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
     }
     if (job.timed_pass != -1) x->nn_pairs = 0;
     for (int pass = 0; pass <= max_iter; ++pass) {
@@ -2452,13 +2493,12 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
             ++x->nn_pairs;
         }
         if (fused) {
-            rc = enqueue_fused_pass(x, w, source, target, pass, prm->estimator, tp, r, ev0, ev1);
+            rc = enqueue_fused_pass(x, w, source, target, prm->estimator, tp, ev0, ev1);
             if (rc) return rc;
             int phase = 0;
             if (exchange) {
                 hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 1,
-                                   pass, max_iter, prm->estimator, ng, prm->relative_fitness, prm->relative_rmse,
-                                   want_trace ? w.trace : nullptr, w.hist, reachE, fused_margin(r), bc[0], bc[1], bc[2]);
+                                   prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
                 if (prm->use_comm) {
                     rc = pedp_comm_allreduce_sum_f64(x, w.packet, PACKET);
                     if (rc) { (void)hipStreamSynchronize(x->stream); return rc; }
@@ -2470,8 +2510,7 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
                 phase = 2;
             }
             hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, phase,
-                               pass, max_iter, prm->estimator, ng, prm->relative_fitness, prm->relative_rmse,
-                               want_trace ? w.trace : nullptr, w.hist, reachE, fused_margin(r), bc[0], bc[1], bc[2]);
+                               prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
             PEDP_HIP_CHECK(hipGetLastError());
         } else {
         if (!degenerate) {
@@ -2536,23 +2575,30 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
     return PEDP_OK;
 }
 
-// Batched registrations are bound by the host's launch rate (a pass is 8 small kernels), so a
-// sub-context captures the whole pass sequence once into a hipGraph and replays it per start
-// pose: the graph's nodes read the start state from the executor's pinned block and everything
-// else from device memory.  Anything the captured launches depend on is in the key.
+// Batched registrations on the SEGMENTED path (dense sweeps, large radii) are bound by the launch
+// rate of their short kernels, so a sub-context captures the whole pass sequence of a registration
+// once into a hipGraph and replays it per start pose: the graph's nodes read the start state from
+// the executor's pinned block and everything else from device memory.  Anything the captured
+// launches depend on is in the key.
+bool graph_key_equal(const pedp_icp_graph_key &a, const pedp_icp_graph_key &b) {
+    return a.src_gen == b.src_gen && a.tgt_gen == b.tgt_gen && a.ws == b.ws && a.Ns == b.Ns && a.Nt == b.Nt &&
+           a.max_iter == b.max_iter && a.qt == b.qt && a.estimator == b.estimator && a.r == b.r &&
+           a.rel_fitness == b.rel_fitness && a.rel_rmse == b.rel_rmse && a.seg == b.seg && a.poses == b.poses;
+}
+
 int icp_launch_replayed(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
                         const pedp_icp_params *prm, const double init[16], IcpJob &job) {
     int rc = icp_job_setup(x, source, target, prm, job);
     if (rc) return rc;
-    icp_fill_state(x, tp, init);
+    icp_fill_state((IcpState *)x->pinned, tp, init, prm, source->N);
     pedp_icp_graph_key key;
     key.src_gen = source->gen; key.tgt_gen = target->gen; key.ws = x->icp_ws.ptr;
     key.Ns = job.Ns; key.Nt = job.Nt; key.max_iter = job.max_iter; key.qt = job.qt; key.estimator = prm->estimator;
     key.r = prm->max_correspondence_distance;
-    const pedp_icp_graph_key &have = x->icp_graph_key;
-    const bool same = x->icp_graph && have.src_gen == key.src_gen && have.tgt_gen == key.tgt_gen && have.ws == key.ws && have.Ns == key.Ns &&
-                      have.Nt == key.Nt && have.max_iter == key.max_iter && have.qt == key.qt &&
-                      have.estimator == key.estimator && have.r == key.r;
+    key.rel_fitness = prm->relative_fitness;
+    key.rel_rmse = prm->relative_rmse;
+    key.seg = job.w.fused ? -1 : 0;
+    const bool same = x->icp_graph && graph_key_equal(x->icp_graph_key, key);
     if (!same) {
         if (x->icp_graph) { (void)hipGraphExecDestroy(x->icp_graph); x->icp_graph = nullptr; }
         hipGraph_t graph = nullptr;
@@ -2574,6 +2620,114 @@ int icp_launch_replayed(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, 
     return PEDP_OK;
 }
 
+// Batched registrations on the FUSED path share their launches: pose b of a group is blockIdx.y
+// of the chunk kernel and blockIdx.x of the finish kernel, and owns one of `G` equal blocks of the
+// workspace.  One captured graph holds `seg` passes (two launches each, no copies) for the whole
+// group; the start states are uploaded in front of the first replay, the states are read back
+// behind every replay, and the graph is replayed until every pose reports done.  Radius, criteria,
+// pass counter and iteration limit live in the device state, so the same graph serves any start
+// poses -- and a group that converges after 7 iterations costs 10 passes of launches, not 31.
+constexpr int BATCH_GROUP_MAX = 32;
+
+int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const TargetPrep &tp,
+                    const pedp_icp_params *prms, const double *inits, int B, double *T_out, double *fitness,
+                    double *inlier_rmse, int32_t *n_iter_done) {
+    bool no_exit = true;
+    for (int b = 0; b < B; ++b) no_exit = no_exit && (prms[b].relative_fitness < 0.0 || prms[b].relative_rmse < 0.0);
+    int G = 1;  // group size: the power of two that holds the batch, at most BATCH_GROUP_MAX (one cached graph per size)
+    int slot = 0;
+    while (G < B && G < BATCH_GROUP_MAX) { G <<= 1; ++slot; }
+    static_assert(sizeof(IcpState) * BATCH_GROUP_MAX <= 32768, "two pinned halves hold a group's states");
+    IcpJob job;
+    job.max_iter = prms[0].max_iteration;
+    job.Ns = source->N;
+    job.Nt = target->N;
+    job.qt = 1;
+    IcpWorkspace &w = job.w;
+    int rc = carve_workspace(c, job.Ns, job.Nt, job.max_iter, 1, w, true, G);
+    if (rc) return rc;
+    w.tgt4 = (const float4 *)target->tgt4;
+    w.word_sph = (const float4 *)target->tile_sphw;
+    w.tgt_s = (const double *)target->tgt_s;
+    w.tile_sph = (const float4 *)target->tile_sph;
+    w.tgt_perm = (const int32_t *)target->perm;
+    w.src_perm = (const int32_t *)source->perm;
+    const int all = job.max_iter + 1;
+    pedp_icp_graph_key key;
+    key.src_gen = source->gen; key.tgt_gen = target->gen; key.ws = c->icp_ws.ptr;
+    key.Ns = job.Ns; key.Nt = job.Nt; key.qt = 1; key.estimator = prms[0].estimator;
+    key.max_iter = 0;  // the limit, the radius and the criteria are in the device state
+    key.r = -1.0;
+    // passes per replay: everything when no pose can stop early, else a stretch that covers the usual
+    // convergence (Open3D's default criteria stop problems of this kind after 6-9 iterations)
+    key.seg = no_exit ? all : (all < 10 ? all : 10);
+    key.poses = G;
+    if (!(c->icp_bgraph[slot] && graph_key_equal(c->icp_bgraph_key[slot], key))) {
+        if (c->icp_bgraph[slot]) { (void)hipGraphExecDestroy(c->icp_bgraph[slot]); c->icp_bgraph[slot] = nullptr; }
+        hipGraph_t graph = nullptr;
+        PEDP_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        double bc[3];
+        for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
+        for (int p = 0; p < key.seg && !rc; ++p) {
+            rc = enqueue_fused_pass(c, w, source, target, prms[0].estimator, tp, nullptr, nullptr, G);
+            hipLaunchKernelGGL(icp_finish_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, c->stream, w.st, w.live, w.live_list,
+                               w.n_lw, w.cpart, w.packet, 0, prms[0].estimator, (double *)nullptr, w.hist, bc[0], bc[1], bc[2],
+                               G > 1 ? w.pose_stride : (size_t)0);
+        }
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph || hipGraphInstantiate(&c->icp_bgraph[slot], graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            c->icp_bgraph[slot] = nullptr;
+            pedp_set_error("pedp_icp_batched: graph capture failed: %s", hipGetErrorString(e));
+            return PEDP_ERR_HIP;
+        }
+        (void)hipGraphDestroy(graph);
+        c->icp_bgraph_key[slot] = key;
+    }
+    IcpState *up = (IcpState *)c->pinned, *down = (IcpState *)((char *)c->pinned + 32768);
+    c->icp_last_cand = c->icp_last_fb = c->icp_last_passes = 0;  // statistics: totals over the batch
+    c->icp_last_nt = target->N;
+    for (int b0 = 0; b0 < B; b0 += G) {
+        const int n = B - b0 < G ? B - b0 : G;
+        for (int k = 0; k < G; ++k) {
+            if (k < n) {
+                icp_fill_state(&up[k], tp, inits + 16 * (b0 + k), &prms[b0 + k], source->N);
+            } else {
+                up[k] = IcpState{};
+                up[k].done = 1;  // an empty seat of the group: every kernel returns at once
+            }
+        }
+        // start states, history slot 0 (each pose's start transformation), empty live masks
+        PEDP_HIP_CHECK(hipMemcpy2DAsync(w.st, w.pose_stride, up, sizeof(IcpState), sizeof(IcpState), (size_t)G,
+                                        hipMemcpyHostToDevice, c->stream));
+        PEDP_HIP_CHECK(hipMemcpy2DAsync(w.hist, w.pose_stride, up[0].T, sizeof(IcpState), sizeof(double) * 16, (size_t)G,
+                                        hipMemcpyHostToDevice, c->stream));
+        PEDP_HIP_CHECK(hipMemset2DAsync(w.live, w.pose_stride, 0, sizeof(unsigned long long) * (size_t)w.n_lw, (size_t)G, c->stream));
+        bool finished = false;
+        for (int guard = 0; guard < (1 << 20) && !finished; ++guard) {
+            PEDP_HIP_CHECK(hipGraphLaunch(c->icp_bgraph[slot], c->stream));
+            PEDP_HIP_CHECK(hipMemcpy2DAsync(down, sizeof(IcpState), w.st, w.pose_stride, sizeof(IcpState), (size_t)G,
+                                            hipMemcpyDeviceToHost, c->stream));
+            PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+            finished = true;
+            for (int k = 0; k < n; ++k) finished = finished && down[k].done;
+        }
+        PEDP_REQUIRE(finished, "pedp_icp_batched: a registration did not finish");
+        for (int k = 0; k < n; ++k) {
+            const IcpState &h = down[k];
+            for (int q = 0; q < 16; ++q) T_out[16 * (b0 + k) + q] = h.T[q];
+            if (fitness) fitness[b0 + k] = h.fitness;
+            if (inlier_rmse) inlier_rmse[b0 + k] = h.rmse;
+            if (n_iter_done) n_iter_done[b0 + k] = h.iters;
+            c->icp_last_cand += h.sum_tiles * 16 * (NN_SB * 16);
+            c->icp_last_fb += h.sum_fb;
+            c->icp_last_passes += h.iters + 1;
+        }
+    }
+    return PEDP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2591,7 +2745,7 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     IcpJob job;
     rc = icp_job_setup(c, source, target, prm, job);
     if (rc) return rc;
-    icp_fill_state(c, tp, init);
+    icp_fill_state((IcpState *)c->pinned, tp, init, prm, source->N);
     rc = icp_enqueue(c, source, target, tp, prm, trace != nullptr, true, job);
     if (rc) return rc;
     return icp_collect(c, job, T_out, fitness, inlier_rmse, n_iter_done, corr, trace);
@@ -2599,21 +2753,55 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
 
 // Hypotheses are independent: up to PEDP_MAX_SUB registrations are in flight at once, each on
 // its own stream and workspace (sub-contexts of c), sharing the clouds' cached preparation.
-int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
-                     const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse) {
-    PEDP_REQUIRE(c && source && target && prm && inits && T_out, "pedp_icp_batched: null argument");
+int pedp_icp_batched_ex(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prms,
+                        const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse, int32_t *n_iter_done) {
+    PEDP_REQUIRE(c && source && target && prms && inits && T_out, "pedp_icp_batched: null argument");
     PEDP_REQUIRE(B >= 0, "pedp_icp_batched: negative batch");
-    PEDP_REQUIRE(!prm->allreduce && !prm->use_comm, "pedp_icp_batched: hypotheses shard across ranks, not within one registration");
     if (B == 0) return PEDP_OK;
-    int rc = icp_check_args(c, source, target, prm);
+    bool uniform = true;
+    double r_max = prms[0].max_correspondence_distance;
+    for (int b = 0; b < B; ++b) {
+        const pedp_icp_params &q = prms[b];
+        PEDP_REQUIRE(!q.allreduce && !q.use_comm, "pedp_icp_batched: hypotheses shard across ranks, not within one registration");
+        PEDP_REQUIRE(q.estimator == prms[0].estimator && q.max_iteration == prms[0].max_iteration,
+                     "pedp_icp_batched: estimator and max_iteration must be the same for the whole batch");
+        uniform = uniform && q.max_correspondence_distance == prms[0].max_correspondence_distance &&
+                  q.relative_fitness == prms[0].relative_fitness && q.relative_rmse == prms[0].relative_rmse;
+        if (q.max_correspondence_distance > r_max) r_max = q.max_correspondence_distance;
+    }
+    int rc = icp_check_args(c, source, target, &prms[0]);
     if (rc) return rc;
-    pedp_icp_params p = *prm;
-    p.relative_fitness = -1.0;  // no early exit across the batch
-    p.relative_rmse = -1.0;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     TargetPrep tp;
-    rc = icp_prepare(c, source, target, p.max_correspondence_distance, inits, B, tp);
+    rc = icp_prepare(c, source, target, r_max, inits, B, tp);
     if (rc) return rc;
+    // The fused path takes a whole group of poses per launch, whatever their radii and criteria (they
+    // live in the device state).  The segmented path replays one graph per pose on sub-contexts and
+    // needs one radius and one set of criteria for that; a mixed batch that is not fused-eligible
+    // runs one by one on the owner's stream -- same results.
+    bool all_fused = !c->icp_exhaustive;
+    for (int b = 0; b < B && all_fused; ++b) {
+        const double r = prms[b].max_correspondence_distance;
+        all_fused = icp_unit_size(target, r) == 1 && r > 0.0 && source->N > 0 && target->N > 0 &&
+                    (target->N + 1023) / 1024 <= BK_WCAP;
+    }
+    if (all_fused) return icp_batch_fused(c, source, target, tp, prms, inits, B, T_out, fitness, inlier_rmse, n_iter_done);
+    if (!uniform) {
+        {
+            for (int b = 0; b < B; ++b) {
+                IcpJob job;
+                rc = icp_job_setup(c, source, target, &prms[b], job);
+                if (rc) return rc;
+                icp_fill_state((IcpState *)c->pinned, tp, inits + 16 * b, &prms[b], source->N);
+                rc = icp_enqueue(c, source, target, tp, &prms[b], false, true, job);
+                if (rc) return rc;
+                rc = icp_collect(c, job, T_out + 16 * b, fitness ? fitness + b : nullptr, inlier_rmse ? inlier_rmse + b : nullptr,
+                                 n_iter_done ? n_iter_done + b : nullptr, nullptr, nullptr);
+                if (rc) return rc;
+            }
+            return PEDP_OK;
+        }
+    }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));  // preparation is visible to the sub-streams
     const int K = B < PEDP_MAX_SUB ? B : PEDP_MAX_SUB;
     for (int k = 0; k < K; ++k) {
@@ -2621,6 +2809,7 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
             rc = pedp_ctx_create(c->device, nullptr, &c->sub[k]);
             if (rc) return rc;
         }
+        c->sub[k]->icp_exhaustive = c->icp_exhaustive;
     }
     IcpJob jobs[PEDP_MAX_SUB];
     c->icp_last_cand = c->icp_last_fb = c->icp_last_passes = 0;  // statistics: totals over the batch
@@ -2635,12 +2824,13 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
     for (int b0 = 0; b0 < B; b0 += K) {
         const int n = (B - b0 < K) ? B - b0 : K;
         for (int k = 0; k < n; ++k) {
-            rc = icp_launch_replayed(c->sub[k], source, target, tp, &p, inits + 16 * (b0 + k), jobs[k]);
+            rc = icp_launch_replayed(c->sub[k], source, target, tp, &prms[b0 + k], inits + 16 * (b0 + k), jobs[k]);
             if (rc) return drain(rc);
         }
         for (int k = 0; k < n; ++k) {
             rc = icp_collect(c->sub[k], jobs[k], T_out + 16 * (b0 + k), fitness ? fitness + b0 + k : nullptr,
-                             inlier_rmse ? inlier_rmse + b0 + k : nullptr, nullptr, nullptr, nullptr);
+                             inlier_rmse ? inlier_rmse + b0 + k : nullptr, n_iter_done ? n_iter_done + b0 + k : nullptr,
+                             nullptr, nullptr);
             if (rc) return drain(rc);
             c->icp_last_cand += c->sub[k]->icp_last_cand;
             c->icp_last_fb += c->sub[k]->icp_last_fb;
@@ -2648,6 +2838,22 @@ int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, con
         }
     }
     return PEDP_OK;
+}
+
+int pedp_icp_batched(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
+                     const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse) {
+    PEDP_REQUIRE(prm, "pedp_icp_batched: null argument");
+    PEDP_REQUIRE(B >= 0 && B <= (1 << 20), "pedp_icp_batched: batch size out of range");
+    pedp_icp_params *all = (pedp_icp_params *)malloc(sizeof(pedp_icp_params) * (size_t)(B > 0 ? B : 1));
+    if (!all) { pedp_set_error("pedp_icp_batched: out of host memory"); return PEDP_ERR_ALLOC; }
+    for (int b = 0; b < B; ++b) {
+        all[b] = *prm;
+        all[b].relative_fitness = -1.0;  // no early exit across the batch
+        all[b].relative_rmse = -1.0;
+    }
+    const int rc = pedp_icp_batched_ex(c, source, target, all, inits, B, T_out, fitness, inlier_rmse, nullptr);
+    free(all);
+    return rc;
 }
 
 int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double T[16], int32_t *idx, double *d2) {
@@ -2690,6 +2896,8 @@ int pedp_icp_configure(pedp_ctx_t c, int exhaustive, int timed_pass) {
     c->icp_timed_pass = timed_pass;
     for (int k = 0; k < PEDP_MAX_SUB; ++k)  // captured graphs bake the mode in
         if (c->sub[k] && c->sub[k]->icp_graph) { (void)hipGraphExecDestroy(c->sub[k]->icp_graph); c->sub[k]->icp_graph = nullptr; }
+    for (int k = 0; k < 6; ++k)
+        if (c->icp_bgraph[k]) { (void)hipGraphExecDestroy(c->icp_bgraph[k]); c->icp_bgraph[k] = nullptr; }
     return PEDP_OK;
 }
 

@@ -49,7 +49,8 @@ struct pedp_icp_graph_key {
     const void *ws = nullptr;
     int64_t Ns = 0, Nt = 0;
     int max_iter = 0, qt = 0, estimator = 0;
-    double r = 0.0;
+    int seg = 0, poses = 0;  // fused-path group graphs: passes per replay, poses per launch
+    double r = 0.0, rel_fitness = 0.0, rel_rmse = 0.0;
 };
 
 struct pedp_comm_s;  // pedp_comm.hip: RCCL communicator of this rank
@@ -86,6 +87,8 @@ struct pedp_ctx_s {
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
     pedp_icp_graph_key icp_graph_key;
+    hipGraphExec_t icp_bgraph[6] = {};   // fused path: one graph per group size 1, 2, 4, ... 32 (poses share launches)
+    pedp_icp_graph_key icp_bgraph_key[6];
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
 };

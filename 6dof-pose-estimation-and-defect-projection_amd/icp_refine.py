@@ -220,7 +220,10 @@ def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, 
     return best_adjustment, best_fitness, best_rmse
 
 
-def improve_result(source_processed, original_target_processed, current_result, parameter):
+SPECULATION = 8   # restarts tried at once (the library keeps up to eight registrations in flight)
+
+
+def improve_result(source_processed, original_target_processed, current_result, parameter, trace=None):
     """Up to 50 randomised ICP restarts around the best scene->model transformation so far
     (pose_estimation.py:547-622).
 
@@ -234,7 +237,16 @@ def improve_result(source_processed, original_target_processed, current_result, 
         across restarts (:580-582);
       * a result with zero fitness or rmse widens the translation noise by 0.25 (:609);
       * exceptions in a restart are logged and skipped (:610-611).
-    """
+
+    Restarts are tried several at a time.  A restart's random draws depend on nothing but the RNG
+    state and the noise width, and its start pose on nothing but the best pose so far; so the next
+    n restarts are drawn ahead under the assumption that none of them changes the best pose or the
+    noise width, and they run as ONE batch on the GPU.  The results are then taken in order: up to
+    and including the first restart that does change something (an improvement, or an invalid
+    result), the sequence is exactly the reference's; the restarts behind it are discarded and the
+    RNG is put back to the state it had after that restart.  Returned numbers, the threshold walk
+    and the RNG state on return are those of the one-by-one loop.  `trace` (a list, optional)
+    receives (threshold, fitness, rmse) of every restart that counted."""
     settings = copy.deepcopy(parameter)
     if not hasattr(current_result, "fitness") or current_result.fitness is None:
         seed = RegistrationResult(current_result)
@@ -245,26 +257,61 @@ def improve_result(source_processed, original_target_processed, current_result, 
     want_fitness = settings["run_icp"]["fitness_threshold"]
     want_rmse = settings["run_icp"]["rmse_threshold"]
     d_src, d_tgt = reg.upload(source_processed), reg.upload(original_target_processed)
-    spread, rounds = 0.1, 0
+    plane = reg.TransformationEstimationPointToPlane()
+    spread, rounds, ahead = 0.1, 0, 1
     logging.info(":: Additional refinements")
-    while rounds < 50 and (best_fitness < want_fitness or best_rmse > want_rmse):
-        trial = settings.copy()  # shallow on purpose: the nested dict is shared
-        trial["refine_registration"]["distance_threshold"] *= np.random.uniform(0.8, 1.2)
-        wobble = np.eye(4)
-        wobble[:3, :3] = reg.get_rotation_matrix_from_xyz([np.random.uniform(-0.01, 0.01) for _ in range(3)])
-        wobble[:3, 3] = np.random.uniform(-spread, spread, 3)
+
+    def unfinished():
+        return rounds < 50 and (best_fitness < want_fitness or best_rmse > want_rmse)
+
+    while unfinished():
+        # ---- draw the next `n` restarts as the one-by-one loop would if nothing changed in between
+        n = min(ahead, 50 - rounds)
+        rng_before = np.random.get_state()
+        radius = settings["refine_registration"]["distance_threshold"]
+        radii, starts, rng_after = [], [], []
+        for _ in range(n):
+            radius = radius * np.random.uniform(0.8, 1.2)
+            wobble = np.eye(4)
+            wobble[:3, :3] = reg.get_rotation_matrix_from_xyz([np.random.uniform(-0.01, 0.01) for _ in range(3)])
+            wobble[:3, 3] = np.random.uniform(-spread, spread, 3)
+            radii.append(radius)
+            starts.append(wobble @ best_T)
+            rng_after.append(np.random.get_state())
         try:
-            res = refine_registration(d_src, d_tgt, wobble @ best_T, trial)
-            if res.fitness > 0 and res.inlier_rmse > 0:
+            results = reg.registration_icp_batch(d_src, d_tgt, radii, starts, plane)
+        except Exception as exc:
+            if n > 1:  # a batch cannot say which restart failed: take this stretch one by one
+                np.random.set_state(rng_before)
+                ahead = 1
+                continue
+            results = [exc]
+        # ---- take the results in order, up to the first one that changes the search state
+        taken, changed = 0, False
+        for k, res in enumerate(results):
+            taken, rounds = k + 1, rounds + 1
+            settings["refine_registration"]["distance_threshold"] = radii[k]   # the shallow-copy walk of the reference
+            if isinstance(res, Exception):  # same contract as the reference: a failed restart is skipped
+                logging.info(f":: Error in refinement iteration {rounds}: {res}. Skipping this iteration.")
+            elif res.fitness > 0 and res.inlier_rmse > 0:
+                if trace is not None:
+                    trace.append((radii[k], res.fitness, res.inlier_rmse))
                 if res.fitness > best_fitness or (res.fitness == best_fitness and res.inlier_rmse < best_rmse):
                     best_fitness, best_rmse, best_T = res.fitness, res.inlier_rmse, res.transformation
                     logging.info(f":: Improved result: Fitness = {best_fitness:.4f}, RMSE = {best_rmse:.4f}")
+                    changed = True
             else:
-                logging.info(f":: Iteration {rounds + 1} produced an invalid result. Skipping.")
+                if trace is not None:
+                    trace.append((radii[k], res.fitness, res.inlier_rmse))
+                logging.info(f":: Iteration {rounds} produced an invalid result. Skipping.")
                 spread += 0.25
-        except Exception as exc:  # same contract as the reference: a failed restart is skipped
-            logging.info(f":: Error in refinement iteration {rounds + 1}: {exc}. Skipping this iteration.")
-        rounds += 1
+                changed = True
+            if changed:
+                break
+        if taken < n:
+            np.random.set_state(rng_after[taken - 1])
+        # look further ahead while nothing happens, start over after a change
+        ahead = 1 if changed else min(SPECULATION, 2 * ahead)
     logging.info(f":: Total iterations: {rounds}")
     out = RegistrationResult(best_T)
     out.fitness, out.inlier_rmse = best_fitness, best_rmse

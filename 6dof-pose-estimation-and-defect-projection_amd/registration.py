@@ -88,3 +88,26 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
         src_idx = np.nonzero(out["corr"] >= 0)[0].astype(np.int32)
         res.correspondence_set = np.stack([src_idx, out["corr"][src_idx]], axis=1)
     return res
+
+
+def registration_icp_batch(source, target, radii, inits, estimation_method=None, criteria=None, ctx=None):
+    """B independent registrations of one source against one target: `radii[b]` and `inits[b]` per
+    registration, one estimation method and one set of criteria.  On device handles (`upload`) they
+    run concurrently through pedp_icp_batched_ex; on anything else they are B calls of
+    registration_icp.  Same results either way -- this is what lets improve_result try several
+    randomised restarts at once (pedp_hip.icp_refine)."""
+    est = estimation_method if estimation_method is not None else TransformationEstimationPointToPoint()
+    crit = criteria if criteria is not None else ICPConvergenceCriteria()
+    if not (isinstance(source, _lib.Cloud) and isinstance(target, _lib.Cloud)):
+        return [registration_icp(source, target, r, T0, est, crit) for r, T0 in zip(radii, inits)]
+    if est.code == _lib.POINT_TO_PLANE and not target.has_normals:
+        raise RuntimeError("TransformationEstimationPointToPlane requires target normals")
+    T, fit, rmse, its = _lib.icp_batched_ex(ctx or source.ctx, source, target, radii, np.asarray(inits, dtype=np.float64),
+                                            estimator=est.code, max_iteration=crit.max_iteration,
+                                            relative_fitness=crit.relative_fitness, relative_rmse=crit.relative_rmse)
+    out = []
+    for b in range(len(T)):
+        res = RegistrationResult(T[b])
+        res.fitness, res.inlier_rmse, res.iterations = float(fit[b]), float(rmse[b]), int(its[b])
+        out.append(res)
+    return out

@@ -239,6 +239,16 @@ int pedp_icp_batched(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
                      double *T_out /* B x 16 */, double *fitness /* B */,
                      double *inlier_rmse /* B */);
 
+/* The same with one parameter struct per start pose (prms[B]): radius and convergence criteria may
+ * differ from pose to pose (estimator and max_iteration may not), each registration stops by its
+ * own criteria, n_iter_done (nullable, B) receives the iteration counts.  This is the form
+ * improve_result's randomised restarts take (src/pose_estimation.py:577-613: every restart has its
+ * own distance threshold and Open3D's default criteria). */
+int pedp_icp_batched_ex(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
+                        const pedp_icp_params *prms /* B */, const double *inits /* B x 16 */, int B,
+                        double *T_out /* B x 16 */, double *fitness /* B */, double *inlier_rmse /* B */,
+                        int32_t *n_iter_done /* B, nullable */);
+
 /* One exact nearest-neighbour pass (the correspondence step alone): for every source
  * point transformed by T, the index of the closest target point and the squared
  * distance, float64-exact (ties: lowest index).  idx/d2: host arrays, length N. */

@@ -192,13 +192,36 @@ def test_improve_result_same_trace_as_oracle_restatement(engine, oracle):
     gold = np.load(os.path.join(GOLD, "g6_improve_result.npz"))
     param = {"refine_registration": {"distance_threshold": 8.0}, "run_icp": {"fitness_threshold": 0.999, "rmse_threshold": 0.05}}
     np.random.seed(0)
-    res = improve_result(src, tgt, T_start, param)        # bare 4x4 -> fitness 0.8 / rmse 3.0 seed
-    assert [c[0] for c in engine.calls] == gold["thresholds"].tolist()        # same RNG draws, same compounding
-    assert all(c[1] == 30 for c in engine.calls)
+    trace = []
+    res = improve_result(src, tgt, T_start, param, trace=trace)   # bare 4x4 -> fitness 0.8 / rmse 3.0 seed
+    # the restarts that counted: same RNG draws, same compounding threshold as the one-by-one loop
+    # (restarts tried ahead and discarded show up in engine.calls only)
+    assert [t[0] for t in trace] == gold["thresholds"].tolist()
+    assert len(engine.calls) >= len(trace) and all(c[1] == 30 for c in engine.calls)
     assert res.fitness == float(gold["best_fitness"]) and res.inlier_rmse == float(gold["best_rmse"])
     assert np.abs(res.transformation - gold["best_T"]).max() < 1e-12
     assert np.random.uniform() == float(gold["rng_after"])                    # RNG left in the same state
     assert param["refine_registration"]["distance_threshold"] == 8.0
+
+
+def test_improve_result_speculation_equals_one_by_one(engine, monkeypatch):
+    """Whatever the look-ahead, improve_result returns the numbers, the threshold walk and the RNG state
+    of the one-by-one loop (look-ahead 1 IS that loop)."""
+    from pedp_hip import icp_refine
+    from pedp_hip.compat import improve_result
+
+    g, src, tgt, T_start = _problem()
+    param = {"refine_registration": {"distance_threshold": 8.0}, "run_icp": {"fitness_threshold": 0.999, "rmse_threshold": 0.05}}
+    runs = []
+    for ahead in (1, 3, 8):
+        monkeypatch.setattr(icp_refine, "SPECULATION", ahead)
+        np.random.seed(5)
+        trace = []
+        res = improve_result(src, tgt, T_start, param, trace=trace)
+        runs.append((trace, res.fitness, res.inlier_rmse, res.transformation.copy(), np.random.uniform()))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1] and r[2] == runs[0][2]
+        assert np.array_equal(r[3], runs[0][3]) and r[4] == runs[0][4]
 
 
 def test_improve_result_stops_when_thresholds_met(engine):

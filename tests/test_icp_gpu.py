@@ -257,3 +257,30 @@ def test_exhaustive_mode_sweeps_all_pairs_with_identical_results(ctx, oracle):
     assert np.abs(full["T"] - culled["T"]).max() < 1e-9
     assert pairs >= passes * len(scene) * len(f.model_points) > pairs_culled   # padded all-pairs count
     assert 0 < ms < 1000
+
+
+def test_batched_ex_per_pose_radius_and_criteria(ctx, oracle):
+    """pedp_icp_batched_ex: every start pose has its own radius and stops by its own criteria (what
+    improve_result's restarts need); results and iteration counts equal the single calls, which
+    equal the oracle."""
+    from pedp_hip import _lib, synth
+
+    f, scene = _frame_scene(oracle, "parity")
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(11)])
+    radii = 6.0 * np.cumprod(np.random.default_rng(2).uniform(0.8, 1.2, 11))     # a threshold walk like the reference's
+    T, fit, rmse, its = _lib.icp_batched_ex(ctx, src, tgt, radii, inits, max_iteration=30)
+    assert len(set(its.tolist())) > 1 and its.max() <= 30                        # they stop at different iterations
+    for b in range(11):
+        one = _lib.icp(ctx, src, tgt, radii[b], inits[b], max_iteration=30)
+        assert np.array_equal(T[b], one["T"]) and fit[b] == one["fitness"] and rmse[b] == one["inlier_rmse"]
+        assert its[b] == one["iters"]
+    for b in (0, 7):
+        ref = oracle.icp(scene, f.model_points, f.normals, radii[b], inits[b])
+        assert fit[b] == ref["fitness"] and its[b] == ref["iters"] and np.abs(T[b] - ref["T"]).max() < POSE_TOL
+    # a radius too large for the fused pass in the mix: the batch falls back to one-by-one, same answers
+    radii2 = radii.copy()
+    radii2[3] = 500.0
+    T2, fit2, _, its2 = _lib.icp_batched_ex(ctx, src, tgt, radii2, inits, max_iteration=6)
+    one = _lib.icp(ctx, src, tgt, 500.0, inits[3], max_iteration=6)
+    assert np.array_equal(T2[3], one["T"]) and fit2[3] == one["fitness"] and its2[3] == one["iters"]
