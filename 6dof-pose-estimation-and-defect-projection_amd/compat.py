@@ -1,8 +1,8 @@
 """Drop-in surface: `from pedp_hip.compat import *` where run.py says `from src import *`
 (run.py:3, src/__init__.py:1-4), plus the `mycpp` slot (Utils.py:45-48, estimater.py:118).
 
-Only the hot-path names are provided; viewer, sensor and learned-model code
-stay the reference's own.
+Only the hot-path names are provided plus the message format to the viewer
+thread (`update_dash_data`); the Dash app, sensor and learned-model code stay the reference's own.
 """
 import numpy as np
 
@@ -35,6 +35,7 @@ def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
 
 
 from .depth_filters import bilateral_filter_depth, depth2xyzmap, depth2xyzmap_batch, erode_depth  # noqa: E402
+from .viewer_wire import update_dash_data  # noqa: E402  (web_vis.py:203-217: the message to the viewer thread)
 
 
 class _MyCpp:
@@ -57,5 +58,5 @@ __all__ = [
     "registration_icp", "TransformationEstimationPointToPlane", "TransformationEstimationPointToPoint",
     "ICPConvergenceCriteria", "get_rotation_matrix_from_xyz",
     "PointCloud", "TriangleMesh", "LineSet", "PinholeCameraIntrinsic", "RegistrationResult",
-    "cluster_poses", "mycpp",
+    "cluster_poses", "mycpp", "update_dash_data",
 ]

@@ -96,6 +96,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_in.release();
     c->ray_out.release();
     c->ray_aux.release();
+    c->ray_order.release();
     c->icp_ws.release();
     c->proj.release();
     c->ops.release();

@@ -67,6 +67,8 @@ struct pedp_ctx_s {
     pedp_scratch ray_in;     // staging for host-memory calls
     pedp_scratch ray_out;
     pedp_scratch ray_aux;    // shared-origin flag + per-call shared-origin pair records
+    pedp_scratch ray_order;  // direction order of the last frame's rays (kept between calls) + the samples it is checked by
+    int64_t ray_order_n = -1;
     int ray_tri_chunks = 0;  // 0 = auto
     int ray_variant = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // sweep timing

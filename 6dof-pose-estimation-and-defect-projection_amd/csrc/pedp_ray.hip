@@ -423,10 +423,35 @@ __device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y) {
     return d;
 }
 
-// bounds[0..3] = enc(min u), enc(max u), enc(min v), enc(max v); preset by the host memsets
-__global__ void ray_bounds_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
-                                  unsigned *__restrict__ bounds) {
-    if (*shared_flag == 0) return;
+// The direction order of a frame's rays is kept between calls.  A camera sends the same rays every
+// frame, and the order only decides how COMPACT the 64-ray packets are: the culling takes every
+// packet's cone from the rays the packet actually holds, so an order computed for other rays of
+// the same count is merely less efficient, never wrong.  ray_order_check_kernel compares RAY_SAMPLES
+// evenly spaced directions bit for bit with those the kept order was built from; only on a
+// mismatch (`stale`) do the four binning kernels below run, otherwise they return at once.
+constexpr int RAY_SAMPLES = 4096;
+__global__ void ray_order_check_kernel(const float *__restrict__ rays6, int64_t N, float *__restrict__ samples,
+                                       int *__restrict__ stale, unsigned *__restrict__ bounds) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) { bounds[0] = 0xFFFFFFFFu; bounds[1] = 0u; bounds[2] = 0xFFFFFFFFu; bounds[3] = 0u; }
+    if (s >= RAY_SAMPLES) return;
+    const int64_t i = (int64_t)s * N / RAY_SAMPLES;
+    bool diff = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned now = __float_as_uint(rays6[6 * i + 3 + k]), was = __float_as_uint(samples[3 * s + k]);
+        diff |= now != was;
+        samples[3 * s + k] = __uint_as_float(now);
+    }
+    if (__builtin_amdgcn_ballot_w64(diff) != 0ull && (threadIdx.x & 63) == 0) atomicOr(stale, 1);
+}
+
+// bounds[0..3] = enc(min u), enc(max u), enc(min v), enc(max v); preset by ray_order_check_kernel.
+// Also clears the histogram for ray_count_kernel (one word per thread and trip).
+__global__ void ray_bounds_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ stale,
+                                  unsigned *__restrict__ bounds, unsigned *__restrict__ hist) {
+    if (*stale == 0) return;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < BIN_CELLS; k += gridDim.x * blockDim.x) hist[k] = 0u;
     unsigned lo_u = 0xFFFFFFFFu, hi_u = 0u, lo_v = 0xFFFFFFFFu, hi_v = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         float u, v;
@@ -471,16 +496,16 @@ __device__ __forceinline__ unsigned ray_cell(const float *__restrict__ rays6, in
     return hilbert_index((unsigned)qu, (unsigned)qv);
 }
 
-__global__ void ray_count_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
+__global__ void ray_count_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ stale,
                                  const unsigned *__restrict__ bounds, unsigned *__restrict__ hist) {
-    if (*shared_flag == 0) return;
+    if (*stale == 0) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) atomicAdd(&hist[ray_cell(rays6, i, bounds)], 1u);
 }
 
 // exclusive scan of BIN_CELLS counters, one workgroup of 1024 threads (64 cells each)
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const int *__restrict__ shared_flag, unsigned *__restrict__ hist) {
-    if (*shared_flag == 0) return;
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const int *__restrict__ stale, unsigned *__restrict__ hist) {
+    if (*stale == 0) return;
     __shared__ unsigned part[1024];
     constexpr int PER = BIN_CELLS / 1024;
     unsigned loc[PER], sum = 0;
@@ -499,10 +524,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const int *__restrict__ 
     for (int k = 0; k < PER; ++k) { hist[threadIdx.x * PER + k] = run; run += loc[k]; }
 }
 
-__global__ void ray_scatter_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ shared_flag,
+__global__ void ray_scatter_kernel(const float *__restrict__ rays6, int64_t N, const int *__restrict__ stale,
                                    const unsigned *__restrict__ bounds, unsigned *__restrict__ cursor /* scanned */,
                                    unsigned *__restrict__ perm) {
-    if (*shared_flag == 0) return;
+    if (*stale == 0) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) perm[atomicAdd(&cursor[ray_cell(rays6, i, bounds)], 1u)] = (unsigned)i;
 }
@@ -1010,7 +1035,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         const size_t sz_tri3 = align256(sizeof(float) * PAIR_SH * (size_t)(mesh->F_padded / 2));
         const size_t sz_cone = align256(sizeof(float4) * 2 * (size_t)(mesh->n_clusters + mesh->n_super));
         const size_t sz_hist = align256(sizeof(unsigned) * BIN_CELLS);
-        const size_t sz_perm = align256(sizeof(unsigned) * (size_t)N);
+        const size_t sz_perm = 0;  // the direction order lives in its own buffer, kept between calls
         const size_t sz_mask = align256(sizeof(unsigned long long) * (size_t)n_packets * (size_t)n_cwords);
         const size_t sz_pcnt = align256(sizeof(int) * (size_t)n_packets);
         const size_t sz_seg = align256(sizeof(int) * (size_t)max_segs);
@@ -1023,7 +1048,15 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         float *tri3 = (float *)(aux + 256);
         float4 *cones = (float4 *)(aux + 256 + sz_tri3);
         unsigned *hist = (unsigned *)(aux + 256 + sz_tri3 + sz_cone);
-        unsigned *perm = (unsigned *)(aux + 256 + sz_tri3 + sz_cone + sz_hist);
+        // kept direction order: [stale flag: 256 B][samples][perm]; rebuilt when the ray count or the buffer changes
+        const size_t sz_samples = align256(sizeof(float) * 3 * RAY_SAMPLES);
+        const void *order_before = c->ray_order.ptr;
+        st = c->ray_order.reserve(256 + sz_samples + sizeof(unsigned) * (size_t)N);
+        if (st) return st;
+        int *stale = (int *)c->ray_order.ptr;
+        float *samples = (float *)((char *)c->ray_order.ptr + 256);
+        unsigned *perm = (unsigned *)((char *)c->ray_order.ptr + 256 + sz_samples);
+        const bool order_kept = c->ray_order.ptr == order_before && c->ray_order_n == N;
         unsigned long long *pmask = (unsigned long long *)(aux + 256 + sz_tri3 + sz_cone + sz_hist + sz_perm);
         int *pk_cnt = (int *)((char *)pmask + sz_mask);
         int *seg_pk = (int *)((char *)pk_cnt + sz_pcnt);
@@ -1047,19 +1080,21 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
         if (variant == 3) {
             // shared origin: cluster cones, direction binning, culled sweep
-            static const unsigned bounds_init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
-            PEDP_HIP_CHECK(hipMemcpyAsync(bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice, c->stream));
-            PEDP_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned) * BIN_CELLS, c->stream));
+            // 0 = "keep the order unless the sampled directions differ", 1 = rebuild (other ray count or buffer)
+            PEDP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)stale, order_kept ? 0 : 1, 1, c->stream));
+            c->ray_order_n = N;
+            hipLaunchKernelGGL(ray_order_check_kernel, dim3(RAY_SAMPLES / 256), dim3(256), 0, c->stream, d_rays, N, samples, stale,
+                               bounds);
             float4 *scones = cones + 2 * mesh->n_clusters;
             hipLaunchKernelGGL(cluster_cone_kernel, dim3((unsigned)((mesh->n_clusters + 255) / 256)), dim3(256), 0, c->stream,
                                (const float4 *)mesh->spheres, mesh->n_clusters, d_rays, flag, cones);
             hipLaunchKernelGGL(cluster_cone_kernel, dim3((unsigned)((mesh->n_super + 255) / 256)), dim3(256), 0, c->stream,
                                (const float4 *)mesh->super_spheres, mesh->n_super, d_rays, flag, scones);
-            hipLaunchKernelGGL(ray_bounds_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag, bounds);
-            hipLaunchKernelGGL(ray_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
+            hipLaunchKernelGGL(ray_bounds_kernel, dim3(c->num_cus), dim3(256), 0, c->stream, d_rays, N, stale, bounds, hist);
+            hipLaunchKernelGGL(ray_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, stale,
                                bounds, hist);
-            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, flag, hist);
-            hipLaunchKernelGGL(ray_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, flag,
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, stale, hist);
+            hipLaunchKernelGGL(ray_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, stale,
                                bounds, hist, perm);
             hipLaunchKernelGGL(ray_cull_mask_kernel, dim3((unsigned)((n_packets + 3) / 4)), dim3(256), 0, c->stream,
                                (const float4 *)cones, (const float4 *)scones, (int)mesh->n_clusters, n_cwords, d_rays, perm, N,

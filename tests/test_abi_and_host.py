@@ -403,3 +403,25 @@ def test_bench_self_launch_reports_a_failed_rank(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and b'"metric"' not in p.stdout
+
+
+def test_update_dash_data_message_shape():
+    """web_vis.py:203-217: one dict of plain arrays per update, put on the data queue."""
+    import queue
+
+    from pedp_hip import viewer_wire
+    from pedp_hip.compat import PointCloud, TriangleMesh, update_dash_data
+
+    q = queue.Queue()
+    viewer_wire.attach_queues(q)
+    try:
+        a = PointCloud(np.arange(12.0).reshape(4, 3), colors=np.full((4, 3), 0.5))
+        b = PointCloud(np.zeros((0, 3)))
+        mesh = TriangleMesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]])
+        update_dash_data([a, b], mesh)
+        msg = q.get_nowait()
+        assert list(msg) == ["pcds", "vertices", "faces"] and len(msg["pcds"]) == 2
+        assert np.array_equal(msg["pcds"][0]["points"], a.points) and np.array_equal(msg["pcds"][0]["colors"], a.colors)
+        assert msg["pcds"][1]["points"].shape == (0, 3) and msg["faces"].dtype == np.int32 and msg["vertices"].shape == (3, 3)
+    finally:
+        viewer_wire.attach_queues(None)

@@ -155,7 +155,35 @@ def test_cluster_poses_matches_oracle(oracle):
     for k in range(60):
         poses[k, :3, :3] = synth.axis_angle(rng.normal(size=3), rng.uniform(0, np.pi)).astype(np.float32)
     syms = np.stack([np.eye(4), np.diag([-1.0, -1.0, 1.0, 1.0])]).astype(np.float32)
-    assert np.array_equal(_lib.cluster_poses(30, 99999, poses, syms), oracle.cluster_poses(30, 99999, poses, syms))
+    got = _lib.cluster_poses(30, 99999, poses, syms)
+    assert np.array_equal(got, oracle.cluster_poses(30, 99999, poses, syms))
+
+    # and an independent statement of mycpp/src/app/pybind_api.cpp:24-68 in numpy float32 (the product
+    # code and oracle/cluster.c are two short texts by one author: this one shares nothing with them)
+    def restated(angle, dist, ps, tfs):
+        keep = [0]
+        thr = np.float32(angle / 180.0 * np.pi)
+        for i in range(1, len(ps)):
+            old = False
+            for c in keep:
+                if np.linalg.norm(ps[c][:3, 3] - ps[i][:3, 3]) >= dist:
+                    continue
+                for tf in tfs:
+                    R = (ps[i] @ tf)[:3, :3]
+                    cos = np.float32((np.trace(R @ ps[c][:3, :3].T) - 1) / 2.0)
+                    if np.arccos(np.clip(cos, -1, 1)) < thr:
+                        old = True
+                        break
+                if old:
+                    break
+            if not old:
+                keep.append(i)
+        return np.array(keep, np.int32)
+
+    for ang in (30, 61, 95):
+        assert np.array_equal(_lib.cluster_poses(ang, 99999, poses, syms), restated(ang, 99999, poses, syms))
+    poses[::3, :3, 3] = 500.0                       # translation gate: far poses never merge
+    assert np.array_equal(_lib.cluster_poses(61, 10.0, poses, syms), restated(61, 10.0, poses, syms))
 
 
 def test_device_resident_chain_depth_to_registration(ctx, oracle):

@@ -179,3 +179,43 @@ def test_empty_mesh_all_miss(ctx):
     mesh = _lib.Mesh(ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
     r = mesh.cast_rays(np.array([[0, 0, 0, 0, 0, 1]] * 5, np.float32))
     assert np.isinf(r["t_hit"]).all() and (r["primitive_ids"] == 0xFFFFFFFF).all()
+
+
+def test_kept_direction_order_never_changes_results(ctx, oracle):
+    """The culled sweep keeps the direction order of the previous frame's rays while a sample of the
+    directions is unchanged.  The order only shapes the packets (their cones come from the rays they
+    actually hold), so frames that differ from the kept order's -- other rays of the same count,
+    changes between the samples, a shuffled frame -- must still give the oracle's bits."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    own = _lib.Context(0)
+    mesh = _lib.Mesh(own, f.verts_posed, f.tris)
+    _lib.raycast_configure(own, 0, 3)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+
+    def same(rays, want):
+        got = mesh.cast_rays(rays)
+        assert np.array_equal(got["primitive_ids"], want["primitive_ids"])
+        assert np.array_equal(got["t_hit"].view(np.uint32), want["t_hit"].view(np.uint32))
+
+    same(f.rays6, ref)
+    same(f.rays6, ref)                                            # second frame: order kept
+    # changes that the 4,096 samples cannot all see: every ray not sampled gets a new direction
+    rng = np.random.default_rng(1)
+    n = len(f.rays6)
+    sampled = (np.arange(4096, dtype=np.int64) * n) // 4096
+    moved = f.rays6.copy()
+    other = np.setdiff1d(np.arange(n), sampled)
+    d = moved[other, 3:] + rng.normal(0, 0.2, (len(other), 3)).astype(np.float32)
+    moved[other, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    same(moved, oracle.raycast(f.verts_posed, f.tris, moved, bvh=True))      # stale order, kept: still exact
+    # a shuffled frame (samples differ -> rebuilt) and back
+    perm = rng.permutation(n)
+    shuffled = f.rays6[perm]
+    same(shuffled, {"primitive_ids": ref["primitive_ids"][perm], "t_hit": ref["t_hit"][perm]})
+    same(f.rays6, ref)
+    # another ray count invalidates the kept order
+    same(f.rays6[: n - 777], {"primitive_ids": ref["primitive_ids"][: n - 777], "t_hit": ref["t_hit"][: n - 777]})
+    mesh.close()
+    own.close()
