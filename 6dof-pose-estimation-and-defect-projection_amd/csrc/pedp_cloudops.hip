@@ -266,7 +266,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
 // wave-wide argmin -- in ascending order, which is the order the mean is summed in.  The lane that
 // owned an extracted value rescans its share.  Same multiset and same summation order as the grid
 // kernel and the oracle.
-constexpr int KNN_SMALL_MAX = 8192;  // 64 KB of distances per query wave
+constexpr int KNN_SMALL_MAX = 4096;  // 32 KB of distances per query wave; beyond ~4k points the grid walk is faster
 __global__ __launch_bounds__(64) void knn_mean_small_kernel(const double *__restrict__ pts, int N, int k,
                                                             double *__restrict__ avg) {
     extern __shared__ double dist[];  // N squared distances of this query
@@ -632,8 +632,8 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
     unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
     void *d_tmp = cv.take<char>(tmp);
-    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
-    if (normals) PEDP_HIP_CHECK(hipMemcpyAsync(d_nrm, normals, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (normals) { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     const unsigned grid = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
@@ -650,8 +650,8 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     PEDP_REQUIRE(m <= capacity, "pedp_voxel_down_sample: %lld voxels exceed the output capacity %lld", (long long)m,
                  (long long)capacity);
     PEDP_REQUIRE(out_pts && (out_normals || !normals), "pedp_voxel_down_sample: null output arrays");
-    PEDP_HIP_CHECK(hipMemcpyAsync(out_pts, d_out, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-    if (normals) PEDP_HIP_CHECK(hipMemcpyAsync(out_normals, d_outn, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    { int dn_ = pedp_download(c, out_pts, d_out, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
+    if (normals) { int dn_ = pedp_download(c, out_normals, d_outn, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }
@@ -688,7 +688,7 @@ int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, 
     int32_t *d_labels = cv.take<int32_t>(N);
     int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
     void *d_tmp = cv.take<char>(tmp);
-    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
     PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
     const unsigned grid = (unsigned)((N + 255) / 256);
@@ -705,7 +705,7 @@ int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, 
     hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, root,
                        rank, d_labels);
     PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipMemcpyAsync(labels, d_labels, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    { int dn_ = pedp_download(c, labels, d_labels, sizeof(int32_t) * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }
@@ -722,13 +722,13 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
         if (st0) return st0;
         Carver cv0{(char *)c->ops.ptr};
         double *d_pts0 = cv0.take<double>(3 * (size_t)N), *d_avg0 = cv0.take<double>(N);
-        PEDP_HIP_CHECK(hipMemcpyAsync(d_pts0, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+        { int up_ = pedp_upload(c, d_pts0, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
         PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(double) * KNN_SMALL_MAX)));
         hipLaunchKernelGGL(knn_mean_small_kernel, dim3((unsigned)N), dim3(64), sizeof(double) * (size_t)N, c->stream, d_pts0, (int)N,
                            k, d_avg0);
         PEDP_HIP_CHECK(hipGetLastError());
-        PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg0, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        { int dn_ = pedp_download(c, avg, d_avg0, sizeof(double) * (size_t)N); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
         return PEDP_OK;
     }
@@ -759,7 +759,7 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
     int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
     void *d_tmp = cv.take<char>(tmp_sort);
-    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
     PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
     const unsigned grid = (unsigned)((N + 255) / 256);
@@ -771,7 +771,7 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream,
                        g, sp, N, cell_start, cell_end, val_s, k, d_avg);
     PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipMemcpyAsync(avg, d_avg, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    { int dn_ = pedp_download(c, avg, d_avg, sizeof(double) * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }
@@ -806,8 +806,8 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
     int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
     void *d_tmp = cv.take<char>(tmp_sort);
-    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
-    if (prior) PEDP_HIP_CHECK(hipMemcpyAsync(d_prior, prior, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (prior) { int up_ = pedp_upload(c, d_prior, prior, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
     PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
     const unsigned grid = (unsigned)((N + 255) / 256);
@@ -819,7 +819,7 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
     hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((N + NRM_THREADS - 1) / NRM_THREADS)), dim3(NRM_THREADS), lds, c->stream, g,
                        sp, N, cell_start, cell_end, val_s, radius * radius, max_nn, d_pts, prior ? d_prior : nullptr, d_out);
     PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipMemcpyAsync(normals, d_out, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    { int dn_ = pedp_download(c, normals, d_out, sizeof(double) * 3 * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }
@@ -840,7 +840,7 @@ int pedp_segment_plane(pedp_ctx_t c, const double *pts, int64_t N, double distan
     Carver cv{(char *)c->ops.ptr};
     double *d_pts = cv.take<double>(3 * (size_t)N);
     int *d_cnt = cv.take<int>(num_iterations);
-    PEDP_HIP_CHECK(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)num_iterations), dim3(256), 0, c->stream, d_pts, (long long)N,
                        distance_threshold, (unsigned long long)seed, d_cnt);
     PEDP_HIP_CHECK(hipGetLastError());

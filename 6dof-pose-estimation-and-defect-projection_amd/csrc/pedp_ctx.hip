@@ -17,6 +17,63 @@ void pedp_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+namespace { constexpr size_t STAGE_MIN = 256u << 10, STAGE_MAX = 64u << 20; }
+
+// one pinned staging buffer per context and direction, grown on demand up to STAGE_MAX
+static int stage_reserve(pedp_ctx_s *c, int which, size_t bytes) {
+    if (c->stage_cap[which] >= bytes) return PEDP_OK;
+    if (c->stage[which]) {
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        (void)hipHostFree(c->stage[which]);
+        c->stage[which] = nullptr;
+        c->stage_cap[which] = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    if (want > STAGE_MAX) want = STAGE_MAX;
+    PEDP_HIP_CHECK(hipHostMalloc(&c->stage[which], want, hipHostMallocDefault));
+    c->stage_cap[which] = want;
+    return PEDP_OK;
+}
+
+int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return PEDP_OK;
+    if (bytes < STAGE_MIN) {
+        PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return PEDP_OK;
+    }
+    int rc = stage_reserve(c, 0, bytes < STAGE_MAX ? bytes : STAGE_MAX);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += c->stage_cap[0]) {
+        const size_t n = bytes - off < c->stage_cap[0] ? bytes - off : c->stage_cap[0];
+        // the DMA that last read the buffer (an earlier upload on this stream) must be done
+        if (c->stage_busy || off > 0) PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(c->stage[0], (const char *)src + off, n);
+        PEDP_HIP_CHECK(hipMemcpyAsync((char *)dst + off, c->stage[0], n, hipMemcpyHostToDevice, c->stream));
+        c->stage_busy = true;
+    }
+    return PEDP_OK;
+}
+
+int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return PEDP_OK;
+    if (bytes < STAGE_MIN) {
+        PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->stage_busy = false;
+        return PEDP_OK;
+    }
+    int rc = stage_reserve(c, 1, bytes < STAGE_MAX ? bytes : STAGE_MAX);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += c->stage_cap[1]) {
+        const size_t n = bytes - off < c->stage_cap[1] ? bytes - off : c->stage_cap[1];
+        PEDP_HIP_CHECK(hipMemcpyAsync(c->stage[1], (const char *)src + off, n, hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->stage_busy = false;
+        memcpy((char *)dst + off, c->stage[1], n);
+    }
+    return PEDP_OK;
+}
+
 int pedp_scratch::reserve(size_t bytes) {
     if (bytes <= cap) return PEDP_OK;
     release();
@@ -102,6 +159,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ops.release();
     c->proj_out.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int k = 0; k < 2; ++k)
+        if (c->stage[k]) (void)hipHostFree(c->stage[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
@@ -116,6 +175,7 @@ int pedp_ctx_synchronize(pedp_ctx_t c) {
     PEDP_REQUIRE(c, "pedp_ctx_synchronize: null context");
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->stage_busy = false;
     return PEDP_OK;
 }
 
@@ -156,11 +216,12 @@ int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, in
     }
     size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
     hipError_t e = hipMalloc((void **)&cl->pts, bytes);
-    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->pts, pts, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && N > 0 && pedp_upload(c, cl->pts, pts, sizeof(double) * 3 * (size_t)N) != PEDP_OK) e = hipErrorUnknown;
     if (e == hipSuccess && normals) {
         cl->has_normals = true;
         e = hipMalloc((void **)&cl->normals, bytes);
-        if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->normals, normals, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && N > 0 && pedp_upload(c, cl->normals, normals, sizeof(double) * 3 * (size_t)N) != PEDP_OK)
+            e = hipErrorUnknown;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {

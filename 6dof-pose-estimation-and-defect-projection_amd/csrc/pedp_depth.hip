@@ -283,7 +283,7 @@ int stage_in(pedp_ctx_t c, const float *src, size_t n_in, size_t n_out, int mem,
         if (st) return st;
         st = c->ray_out.reserve(sizeof(float) * n_out);
         if (st) return st;
-        PEDP_HIP_CHECK(hipMemcpyAsync(c->ray_in.ptr, src, sizeof(float) * n_in, hipMemcpyHostToDevice, c->stream));
+        { int up_ = pedp_upload(c, c->ray_in.ptr, src, sizeof(float) * n_in); if (up_) return up_; }
         *d_in = (const float *)c->ray_in.ptr;
         *d_out = (float *)c->ray_out.ptr;
     }
@@ -293,7 +293,7 @@ int stage_in(pedp_ctx_t c, const float *src, size_t n_in, size_t n_out, int mem,
 int stage_out(pedp_ctx_t c, float *out, const float *d_out, size_t n_out, int mem) {
     PEDP_HIP_CHECK(hipGetLastError());
     if (mem == PEDP_HOST) {
-        PEDP_HIP_CHECK(hipMemcpyAsync(out, d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, c->stream));
+        { int dn_ = pedp_download(c, out, d_out, sizeof(float) * n_out); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return PEDP_OK;

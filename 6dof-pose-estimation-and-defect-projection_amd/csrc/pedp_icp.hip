@@ -2559,7 +2559,7 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
     PEDP_HIP_CHECK(hipSetDevice(x->device));
     const IcpWorkspace &w = job.w;
     if (corr && job.Ns > 0)
-        PEDP_HIP_CHECK(hipMemcpyAsync(corr, w.idx, sizeof(int32_t) * (size_t)job.Ns, hipMemcpyDeviceToHost, x->stream));
+        { int dn_ = pedp_download(x, corr, w.idx, sizeof(int32_t) * (size_t)job.Ns); if (dn_) return dn_; }
     if (trace)
         PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(job.max_iter + 1), hipMemcpyDeviceToHost, x->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(x->stream));
@@ -2884,8 +2884,8 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     c->nn_pairs = 0;
     rc = enqueue_nn_pass(c, w, source, target, 0, tp, 1e18, c->nn_ev0, c->nn_ev1);
     if (rc) return rc;
-    PEDP_HIP_CHECK(hipMemcpyAsync(idx, w.idx, sizeof(int32_t) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipMemcpyAsync(d2, w.d2, sizeof(double) * (size_t)source->N, hipMemcpyDeviceToHost, c->stream));
+    { int dn_ = pedp_download(c, idx, w.idx, sizeof(int32_t) * (size_t)source->N); if (dn_) return dn_; }
+    { int dn_ = pedp_download(c, d2, w.d2, sizeof(double) * (size_t)source->N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }

@@ -176,7 +176,7 @@ extern "C" int pedp_project_heatmap(pedp_ctx_t c, pedp_mesh_t mesh, const pedp_p
     char *b = (char *)c->proj.ptr;
     const double *d_heat = heatmap;
     if (mem == PEDP_HOST) {
-        PEDP_HIP_CHECK(hipMemcpyAsync(b, heatmap, sizeof(double) * (size_t)n_pix, hipMemcpyHostToDevice, c->stream));
+        { int up_ = pedp_upload(c, b, heatmap, sizeof(double) * (size_t)n_pix); if (up_) return up_; }
         d_heat = (const double *)b;
     }
     int *boff1 = (int *)(b + sz_heat);
@@ -244,10 +244,10 @@ extern "C" int pedp_project_heatmap(pedp_ctx_t c, pedp_mesh_t mesh, const pedp_p
                        boff2, cm, origin[0], origin[1], origin[2], d_pts, d_int, d_pix, d_prim);
     PEDP_HIP_CHECK(hipGetLastError());
     if (mem == PEDP_HOST) {
-        PEDP_HIP_CHECK(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * (size_t)n_hit, hipMemcpyDeviceToHost, c->stream));
-        PEDP_HIP_CHECK(hipMemcpyAsync(intensities, d_int, sizeof(double) * (size_t)n_hit, hipMemcpyDeviceToHost, c->stream));
-        if (pixels) PEDP_HIP_CHECK(hipMemcpyAsync(pixels, d_pix, sizeof(int32_t) * 2 * (size_t)n_hit, hipMemcpyDeviceToHost, c->stream));
-        if (prim_id) PEDP_HIP_CHECK(hipMemcpyAsync(prim_id, d_prim, sizeof(uint32_t) * (size_t)n_hit, hipMemcpyDeviceToHost, c->stream));
+        { int dn_ = pedp_download(c, points, d_pts, sizeof(double) * 3 * (size_t)n_hit); if (dn_) return dn_; }
+        { int dn_ = pedp_download(c, intensities, d_int, sizeof(double) * (size_t)n_hit); if (dn_) return dn_; }
+        if (pixels) { int dn_ = pedp_download(c, pixels, d_pix, sizeof(int32_t) * 2 * (size_t)n_hit); if (dn_) return dn_; }
+        if (prim_id) { int dn_ = pedp_download(c, prim_id, d_prim, sizeof(uint32_t) * (size_t)n_hit); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return PEDP_OK;

@@ -1011,7 +1011,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         if (st) return st;
         st = c->ray_out.reserve(sizeof(float) * 4 * (size_t)N);
         if (st) return st;
-        PEDP_HIP_CHECK(hipMemcpyAsync(c->ray_in.ptr, rays6, sizeof(float) * 6 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+        { int up_ = pedp_upload(c, c->ray_in.ptr, rays6, sizeof(float) * 6 * (size_t)N); if (up_) return up_; }
         d_rays = (const float *)c->ray_in.ptr;
         d_t = (float *)c->ray_out.ptr;
         d_id = (uint32_t *)(d_t + N);
@@ -1136,9 +1136,9 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         PEDP_HIP_CHECK(hipGetLastError());
     }
     if (mem == PEDP_HOST) {
-        PEDP_HIP_CHECK(hipMemcpyAsync(t_hit, d_t, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
-        PEDP_HIP_CHECK(hipMemcpyAsync(prim_id, d_id, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
-        if (uv) PEDP_HIP_CHECK(hipMemcpyAsync(uv, d_uv, sizeof(float) * 2 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+        { int dn_ = pedp_download(c, t_hit, d_t, sizeof(float) * (size_t)N); if (dn_) return dn_; }
+        { int dn_ = pedp_download(c, prim_id, d_id, sizeof(uint32_t) * (size_t)N); if (dn_) return dn_; }
+        if (uv) { int dn_ = pedp_download(c, uv, d_uv, sizeof(float) * 2 * (size_t)N); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return PEDP_OK;

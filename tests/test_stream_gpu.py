@@ -44,6 +44,10 @@ def test_config5_frame_chain_at_camera_resolution(oracle, tmp_path):
     proj = FrameProjector(mesh, intr, color_to_depth)
     q = queue.Queue()
     viewer_wire.attach_queues(q)
+    # the scene cloud comes back to the host (the reference's chain works on host clouds): into a PINNED
+    # buffer that lives across frames.  A pageable destination makes the runtime pin and unpin 9 MB per
+    # frame, which holds up the next submissions by 20-30 ms (DESIGN s6).
+    host_pts = torch.empty((f.width * f.height, 3), dtype=torch.float64, pin_memory=True)
 
     def frame(seed):
         # ---- depth pre-filters and back-projection, device tensors throughout (estimater.py:255-259)
@@ -51,7 +55,9 @@ def test_config5_frame_chain_at_camera_resolution(oracle, tmp_path):
         d = compat.erode_depth(d, radius=2, device="cuda")
         d = compat.bilateral_filter_depth(d, radius=2, device="cuda")
         xyz = compat.depth2xyzmap_batch(d[None], torch.as_tensor(K32, device="cuda")[None], zfar=np.inf)[0]
-        pts = (xyz[xyz[..., 2] >= 0.001].double() * 1000.0).cpu().numpy()      # scene cloud in mm (run.py works in mm)
+        dev_pts = xyz[xyz[..., 2] >= 0.001].double() * 1000.0                  # scene cloud in mm (run.py works in mm)
+        host_pts[: len(dev_pts)].copy_(dev_pts)
+        pts = host_pts[: len(dev_pts)].numpy().copy()
         source = PointCloud(pts)
         # ---- run.py:95-99: start pose (depth-camera frame), refinement
         init = synth.start_pose()
