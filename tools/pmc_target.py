@@ -18,7 +18,7 @@ for _ in range(2):
 _lib.raycast_configure(ctx, 0, 0)
 for _ in range(2):
     mesh.cast_rays(f.rays6, want_uv=False)
-_lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=3, relative_fitness=-1, relative_rmse=-1)
+_lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1)   # 21 fused passes
 big = np.tile(synth.depth_image(512, 512, seed=0, nan=False), (8, 8))
 for _ in range(2):
     compat.erode_depth(big, 2, ctx=ctx)

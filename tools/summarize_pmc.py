@@ -1,12 +1,13 @@
-"""Turns the rocprofv3 --pmc CSVs under profiles/ (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv,
-optional r01_pmc_sq.csv) into profiles/r01_traffic.json: HBM-side bytes per launch for the kernels
+"""Turns the rocprofv3 --pmc CSVs under profiles/ (rNN_pmc_fetch_size.csv, rNN_pmc_write_size.csv,
+optional rNN_pmc_sq.csv; python tools/summarize_pmc.py [rNN], default r02) into profiles/rNN_traffic.json: HBM-side bytes per launch for the kernels
 bench.py and DESIGN.md quote.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
 counts 64 B per 128-B request for wide coalesced streams, so kernels whose reads are vector streams
 are doubled; kernels whose reads are scalar loads (s_load_dwordx16 of triangle records) are left
 as measured (width uncalibrated) and flagged.  WRITE_SIZE is taken as is."""
-import collections, csv, json, os
+import collections, csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def load(name):
@@ -19,7 +20,7 @@ def load(name):
     return d
 
 
-f, w, sq = load("r01_pmc_fetch_size.csv"), load("r01_pmc_write_size.csv"), load("r01_pmc_sq.csv")
+f, w, sq = load(f"{RND}_pmc_fetch_size.csv"), load(f"{RND}_pmc_write_size.csv"), load(f"{RND}_pmc_sq.csv")
 
 
 def pick(d, key, counter):
@@ -32,6 +33,8 @@ def pick(d, key, counter):
 KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector streams)
     ("nn_sweep_kernel<4", "nn_sweep_kernel", True),
     ("nn_sweep_kernel<1", "nn_sweep_kernel_culled", True),
+    ("icp_pass_kernel", "icp_pass_kernel", True),
+    ("icp_finish_kernel", "icp_finish_kernel", True),
     ("ray_sweep_rpl_kernel<true>", "ray_sweep_rpl_kernel", False),
     ("ray_sweep_seg_kernel", "ray_sweep_seg_kernel", False),
     ("ray_cull_mask_kernel", "ray_cull_mask_kernel", True),
@@ -59,5 +62,5 @@ for key, name, stream in KERNELS:
         rec["mfma_util"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         rec["mfma_flop"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
     out[name] = rec
-json.dump(out, open(os.path.join(P, "r01_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, f"{RND}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
