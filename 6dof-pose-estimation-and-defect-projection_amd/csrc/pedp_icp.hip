@@ -958,10 +958,19 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
     static_assert(W * 64 == 4 * CH, "four threads per slot");
     const size_t pose_off = (size_t)blockIdx.y * a0.pose_stride;
     const IcpState *__restrict__ st = pose_ptr(st0, pose_off);
-    PassArgs a = a0;
-    a.Pk = pose_ptr(a0.Pk, pose_off); a.Tprev = pose_ptr(a0.Tprev, pose_off); a.live = pose_ptr(a0.live, pose_off);
-    a.live_list = pose_ptr(a0.live_list, pose_off); a.hist = pose_ptr(a0.hist, pose_off);
-    a.idx_out = pose_ptr(a0.idx_out, pose_off); a.partials = pose_ptr(a0.partials, pose_off);
+    // The argument block (with this pose's pointers) is parked in LDS and read from there where it is
+    // used: held in scalar registers for the whole kernel its 40-odd fields overflow the SGPR file,
+    // and the spills -- executed at entry by EVERY launched workgroup -- left tens of MB of dirty
+    // scratch for the kernel boundary to write back.
+    __shared__ PassArgs sa;
+    if (threadIdx.x == 0) {
+        PassArgs t = a0;
+        t.Pk = pose_ptr(a0.Pk, pose_off); t.Tprev = pose_ptr(a0.Tprev, pose_off); t.live = pose_ptr(a0.live, pose_off);
+        t.live_list = pose_ptr(a0.live_list, pose_off); t.hist = pose_ptr(a0.hist, pose_off);
+        t.idx_out = pose_ptr(a0.idx_out, pose_off); t.partials = pose_ptr(a0.partials, pose_off);
+        sa = t;
+    }
+    const PassArgs &a = sa;
     __shared__ float tri_b1[W][4 * BK_QS];
     __shared__ int tri_t1[W][4 * BK_QS], m2key[4 * BK_QS];
     __shared__ unsigned tl[BK_TL + 8];
@@ -974,21 +983,27 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__r
     __shared__ float4 wsph[BK_WCAP];
     // the first unit's live-list entry is requested together with the state (the list has one entry
     // per chunk, so the index is always inside it; the value is used only when it is valid)
-    int chunk_next = a.live_list[blockIdx.x < (unsigned)a.n_chunks ? blockIdx.x : 0];
+    int chunk_next = pose_ptr(a0.live_list, pose_off)[blockIdx.x < (unsigned)a0.n_chunks ? blockIdx.x : 0];
     if (st->done) return;
+    __syncthreads();  // the argument block is in LDS
     const bool rebuild = st->rebuild != 0;
     const int n_live = st->n_live, pass = st->pass;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int frag_slot = lane & 15, frag_comp = lane >> 4;  // MFMA B fragment: slot in the sub-block, component
-    const int frag = frag_slot * 4 + frag_comp;              // float offset inside a 16-point target tile
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const float inf = __uint_as_float(0x7F800000u);
     const double dinf = __longlong_as_double(0x7FF0000000000000ll);
     const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
     const float r_search = st->r_search;
     // word spheres do not depend on the chunk: requested before anything else, parked in LDS
-    wsph[tid] = a.word_sph[tid < a.n_words ? tid : 0];
+    wsph[threadIdx.x] = a.word_sph[(int)threadIdx.x < a.n_words ? threadIdx.x : 0];
     for (int unit = blockIdx.x;; unit += gridDim.x) {
+        // The thread index is made opaque per chunk: everything derived from it (LDS addresses, lane
+        // masks, role predicates) is then computed where it is used instead of being hoisted out of
+        // this loop and kept alive -- spilled -- through every phase.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int frag_slot = lane & 15, frag_comp = lane >> 4;  // MFMA B fragment: slot in the sub-block, component
+        const int frag = frag_slot * 4 + frag_comp;              // float offset inside a 16-point target tile
+        const unsigned long long lt = (1ull << lane) - 1ull;
         // a rebuild pass visits every chunk (unit = chunk id), other passes the live list (unit = rank);
         // `unit` also indexes the chunk's partial sums (see icp_finish_kernel)
         int chunk;

@@ -353,8 +353,8 @@ def run(args):
                                    "sums)", "region": "headline", "bound": "mfma",
                          "achieved": sweep_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": sweep_tflops / PEAK_FP32_TFLOPS,
-                         "traffic": traffic.get("nn_sweep_kernel_in_step", {}).get("hbm_bytes_per_launch"),
-                         "mfma_util_pmc": traffic.get("nn_sweep_kernel_in_step", {}).get("mfma_util"),
+                         "traffic": traffic.get("icp_pass_kernel", {}).get("hbm_bytes_per_launch"),
+                         "mfma_util_pmc": traffic.get("icp_pass_kernel", {}).get("mfma_util"),
                          "kernel_ms": sweep_ms, "launches_per_step": passes,
                          "kernel_ms_x_launches": sweep_ms * passes, "region_ms_per_step": ms_per_step,
                          "note": f"{FLOP_PER_PAIR} flop x {pairs_pass:.4g} (scene slot, model point) pairs the kernel swept per "
