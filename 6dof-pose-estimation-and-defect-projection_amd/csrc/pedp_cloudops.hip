@@ -260,6 +260,90 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
     avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
+// One WAVE per query on the grid (clouds above KNN_SMALL_MAX points).  The wave walks the same
+// shells as the thread-per-query kernel above, but its 64 lanes fetch a cell's points together and
+// park the squared distances in LDS; it stops after the shell within whose reach at least k of
+// them lie (the same rule: the k-th best is then settled), and extracts the k smallest one by one
+// with a wave-wide argmin, in ascending order -- the order the mean is summed in.  Same multiset,
+// same summation order, same bits as the other two kernels and the oracle.  A query whose shells
+// hold more candidates than the LDS share raises `overflow`; the host then runs the
+// thread-per-query kernel for the cloud.
+constexpr int KNN_WCAP = 2048;  // candidates per query wave (16 KB)
+constexpr int KNN_WPB = 4;      // query waves per workgroup
+__global__ __launch_bounds__(KNN_WPB * 64) void knn_mean_wave_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                    const int *__restrict__ cell_start,
+                                                                    const int *__restrict__ cell_end,
+                                                                    const int *__restrict__ idx_sorted, int k,
+                                                                    double *__restrict__ avg, int *__restrict__ overflow) {
+    __shared__ double cand_all[KNN_WPB][KNN_WCAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * KNN_WPB + wave;
+    if (j >= N) return;  // wave-uniform
+    double *cand = cand_all[wave];
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    const int m = (int)(N < k ? N : k);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
+    const int far = max(max(max(cx, g.dim[0] - 1 - cx), max(cy, g.dim[1] - 1 - cy)), max(cz, g.dim[2] - 1 - cz));
+    int n_c = 0;
+    for (int rho = 0; rho <= far; ++rho) {
+        for (int z = max(cz - rho, 0); z <= min(cz + rho, g.dim[2] - 1); ++z)
+            for (int y = max(cy - rho, 0); y <= min(cy + rho, g.dim[1] - 1); ++y) {
+                const bool face = (abs(z - cz) == rho) || (abs(y - cy) == rho);
+                for (int x = max(cx - rho, 0); x <= min(cx + rho, g.dim[0] - 1); ++x) {
+                    if (!face && abs(x - cx) != rho) continue;  // interior of the cube: visited by an earlier shell
+                    const int c = x + g.dim[0] * (y + g.dim[1] * z);
+                    const int e = cell_end[c];
+                    for (int q0 = cell_start[c]; q0 < e; q0 += 64) {  // wave-uniform bounds
+                        const int q = q0 + lane;
+                        if (q < e && n_c + lane < KNN_WCAP) cand[n_c + lane] = dist2(p, sp + 3 * (size_t)q);
+                        n_c += e - q0 < 64 ? e - q0 : 64;
+                    }
+                }
+            }
+        if (n_c > KNN_WCAP) {  // wave-uniform
+            if (lane == 0) atomicOr(overflow, 1);
+            return;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+        const double reach = (double)rho * g.cell * (1.0 - 1e-9), reach2 = reach * reach;
+        int within = 0;
+        for (int q = lane; q < n_c; q += 64) within += cand[q] <= reach2 ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) within += __shfl_xor(within, off, 64);
+        if (within >= m) break;
+    }
+    double lmin = inf;
+    int lidx = -1;
+    for (int q = lane; q < n_c; q += 64) {
+        const double d = cand[q];
+        if (d < lmin) { lmin = d; lidx = q; }
+    }
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) {
+        double v = lmin;
+        int owner = lane;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int oo = __shfl_xor(owner, off, 64);
+            if (ov < v || (ov == v && oo < owner)) { v = ov; owner = oo; }
+        }
+        s += sqrt(v);  // every lane forms the same sum
+        if (lane == owner) {  // drop the extracted value and find the share's next minimum
+            cand[lidx] = inf;
+            lmin = inf;
+            lidx = -1;
+            for (int q = lane; q < n_c; q += 64) {
+                const double d = cand[q];
+                if (d < lmin) { lmin = d; lidx = q; }
+            }
+        }
+    }
+    if (lane == 0) avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
+}
+
 // Small clouds (the largest cluster that reaches the outlier filter is a few thousand points): one
 // WAVE per query.  The wave writes the squared distances to all N points into LDS, every lane
 // keeps the minimum of its strided share, and the k smallest are extracted one by one with a
@@ -766,11 +850,22 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
     hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
-    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream,
-                       g, sp, N, cell_start, cell_end, val_s, k, d_avg);
+    // a wave per query; a cloud too dense for the LDS share of some query falls back to a thread per query
+    int *d_over = (int *)((char *)d_tmp);  // the sort is done: its scratch is free
+    int *h_over = (int *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(knn_mean_wave_kernel, dim3((unsigned)((N + KNN_WPB - 1) / KNN_WPB)), dim3(KNN_WPB * 64), 0, c->stream, g, sp, N,
+                       cell_start, cell_end, val_s, k, d_avg, d_over);
     PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*h_over) {
+        const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
+        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds,
+                           c->stream, g, sp, N, cell_start, cell_end, val_s, k, d_avg);
+        PEDP_HIP_CHECK(hipGetLastError());
+    }
     { int dn_ = pedp_download(c, avg, d_avg, sizeof(double) * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;

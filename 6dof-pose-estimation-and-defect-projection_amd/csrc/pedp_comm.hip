@@ -10,6 +10,7 @@
 // whatever the host side uses for rendezvous (pedp_hip.dist: torch.distributed's store).
 #include "pedp_internal.h"
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 #include <new>
 
@@ -27,8 +28,10 @@ struct RcclApi {
 };
 
 RcclApi g_rccl;
+std::mutex g_rccl_mutex;  // contexts of different threads may create their communicators at once
 
 int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.ok) return PEDP_OK;
     // a copy the process already holds first (torch's), then the system one
     const char *names[] = {"librccl.so.1", "librccl.so"};

@@ -145,6 +145,18 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     const int x = x0 + lx, ys = y0 + ly * STRIP;
     if (x >= p.W) return;
     const float two_sd2 = __fmul_rn(__fmul_rn(2.0f, p.a), p.a), two_sr2 = __fmul_rn(__fmul_rn(2.0f, p.b), p.b);
+    // The weight is expf(a - b), a = -(du^2 + dv^2) / 2 sigmaD^2 one of a few constants, b = dc^2 / 2 sigmaR^2.
+    // Whenever b is below a quarter of an ulp of a, the float32 subtraction returns a itself and the
+    // weight is the constant expf(a): no division, no exponential -- and the same bits.  With the
+    // reference's sigmaR = 1e5 that is every tap but the centre one (a = 0).
+    constexpr int KMAX = 2 * R * R;
+    float wa[KMAX + 1], ww[KMAX + 1], wthr[KMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) {
+        wa[k] = __fdiv_rn(-(float)k, two_sd2);
+        ww[k] = expf(wa[k]);
+        wthr[k] = two_sr2 * fabsf(wa[k]) * 1.4901161e-8f;  // 2^-26 |a| <= ulp(a) / 4
+    }
     float mean[STRIP];
     int nv[STRIP];
 #pragma unroll
@@ -189,7 +201,10 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
                 if (v < 0 || v >= p.H) continue;
                 const float cur = col[j + dv + R];
                 if (nv[j] && depth_valid(cur, p.zfar) && fabsf(__fsub_rn(cur, mean[j])) < 0.01f) {
-                    const float w = bilateral_weight(du, dv, centre[j], cur, two_sd2, two_sr2);
+                    const int kk = du * du + dv * dv;
+                    const float dc = __fsub_rn(centre[j], cur);
+                    const float w = __fmul_rn(dc, dc) < wthr[kk] ? ww[kk]
+                                                               : bilateral_weight(du, dv, centre[j], cur, two_sd2, two_sr2);
                     sw[j] = __fadd_rn(sw[j], w);
                     sum[j] = __fadd_rn(sum[j], __fmul_rn(w, cur));
                 }

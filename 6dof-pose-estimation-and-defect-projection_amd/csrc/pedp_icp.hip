@@ -1962,6 +1962,7 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
         } else {
             double upd[16];
             ident4(upd);
+            PEDP_STAMP(2, 2, 0);
             if (K > 0.0) {
                 if (estimator == PEDP_POINT_TO_PLANE) {
                     double A[36], nb[6], x[6];
@@ -1972,7 +1973,10 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
                         for (int v = u; v < 6; ++v) { A[6 * u + v] = pk[k]; A[6 * v + u] = pk[k]; ++k; }
 #pragma unroll
                     for (int u = 0; u < 6; ++u) nb[u] = -pk[21 + u];
-                    if (solve6_ldlt_reg(A, nb, x)) vec6_to_T(x, upd);
+                    const bool ok = solve6_ldlt_reg(A, nb, x);
+                    PEDP_STAMP(2, 2, 1);
+                    if (ok) vec6_to_T(x, upd);
+                    PEDP_STAMP(2, 2, 2);
                 } else {
                     const double *c = st->centroid;
                     double ms[3], mt[3], sig[9];
@@ -2019,6 +2023,7 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
             }
             st->rebuild = do_rebuild;
             st->pass = pass + 1;
+            PEDP_STAMP(2, 2, 3);
         }
         PEDP_STAMP(2, 0, 3);
     }

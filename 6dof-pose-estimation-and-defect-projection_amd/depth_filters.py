@@ -85,7 +85,20 @@ def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, d
 
 def depth2xyzmap(depth, K, uvs=None, ctx=None):
     if uvs is not None:
-        raise NotImplementedError("depth2xyzmap(uvs=...) has no caller in the reference and is not provided")
+        # Utils.py:406-409: only the listed pixels (u, v rounded) are back-projected, the rest of the
+        # map stays zero.  A listed pixel's value is the full map's, so the full map comes from the
+        # device and the listed pixels are picked out of it.
+        full = depth2xyzmap(depth, K, None, ctx)
+        on_device = _is_torch(full)
+        arr = full.detach().cpu().numpy() if on_device else np.asarray(full)
+        uv = np.asarray(uvs.detach().cpu().numpy() if _is_torch(uvs) else uvs).round().astype(int)
+        out = np.zeros_like(arr)
+        out[uv[:, 1], uv[:, 0]] = arr[uv[:, 1], uv[:, 0]]
+        if on_device:
+            import torch
+
+            return torch.from_numpy(out).to(full.device)
+        return out
     Kd = np.ascontiguousarray(np.asarray(K.detach().cpu().numpy() if _is_torch(K) else K), dtype=np.float64).reshape(3, 3)
 
     def call(lib, h, src, mem, dst, shape):

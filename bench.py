@@ -154,7 +154,12 @@ def run(args):
     from pedp_hip import _lib, synth
     from pedp_hip import dist as pdist
 
-    rank, world, local = pdist.init_from_env("nccl")
+    # PEDP_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo as the transport -- the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks per device).  A rehearsal, never a measurement: the line says so.
+    rehearsal = os.environ.get("PEDP_BENCH_REHEARSAL") == "1"
+    rank, world, local = pdist.init_from_env("gloo" if rehearsal else "nccl")
+    if rehearsal:
+        local = 0
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong N",
@@ -170,7 +175,7 @@ def run(args):
     ray_be = pdist.HipBackend(local)
     ctx, ray_ctx = icp_be.ctx, ray_be.ctx
     native = False
-    if world > 1:
+    if world > 1 and not rehearsal:
         native = bool(icp_be.init_comm()) & bool(ray_be.init_comm())
 
     frame = synth.Frame(args.config)
@@ -248,18 +253,16 @@ def run(args):
         barrier()
         return max_over_ranks(time.perf_counter() - t0), res, np.array(rows)
 
-    def serial(fn):
+    def step_serial():
         """The same step with the two stages one after the other: the exhaustive region quotes
         kernel rooflines, so its kernels must not share the chip with each other."""
-        def run_step():
-            if mode == "shard":
-                sharded.cast()
-                ray_ctx.synchronize()
-                return sharded.icp(init, radius, max_iteration=ICP_ITERS, rel_fitness=-1.0, rel_rmse=-1.0)
-            cast_full()
+        if mode == "shard":
+            sharded.cast()
             ray_ctx.synchronize()
-            return _lib.icp(ctx, src, tgt, radius, init, **icp_kw)
-        return run_step
+            return sharded.icp(init, radius, max_iteration=ICP_ITERS, rel_fitness=-1.0, rel_rmse=-1.0)
+        cast_full()
+        ray_ctx.synchronize()
+        return _lib.icp(ctx, src, tgt, radius, init, **icp_kw)
 
     step = step_sharded if mode == "shard" else step_whole
     _lib.icp_configure(ctx, exhaustive=False, timed_pass=TIMED_PASS)
@@ -274,7 +277,7 @@ def run(args):
         _lib.raycast_configure(ray_ctx, 0, 1)
         _lib.icp_configure(ctx, exhaustive=True, timed_pass=TIMED_PASS)
         try:
-            ex_elapsed, ex_res, ex_rows = timed_region(serial(step), ex_steps, 1)
+            ex_elapsed, ex_res, ex_rows = timed_region(step_serial, ex_steps, 1)
             ex_passes, ex_pairs, _ = _lib.icp_last_stats(ctx)
         finally:
             _lib.raycast_configure(ray_ctx, 0, 0)
@@ -337,7 +340,7 @@ def run(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak" if mode == "replica" else "strong", "vs_baseline": None,
-            "dtype": "f32 rays / f64 ICP (f32 MFMA filter)", "data": "synthetic",
+            "dtype": "f32 rays / f64 ICP (f32 MFMA filter)", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": f"{args.config}: {frame.width}x{frame.height} frame, {n_rays} rays x {n_tris} "
                                    f"triangles + {ICP_ITERS}-iteration point-to-plane ICP ({n_scene} scene x "
                                    f"{n_model} model points) per step",

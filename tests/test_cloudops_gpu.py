@@ -91,11 +91,15 @@ def test_statistical_outlier_removal(ctx, oracle, k, ratio):
     assert np.array_equal(keep, oracle.remove_statistical_outlier(pts, k, ratio))
     few = pts[:40]                       # fewer points than neighbours: all of them are "the k nearest"
     assert np.array_equal(cloud_ops.knn_mean_distance(few, 75), oracle.knn_mean_distance(few, 75))
-    # both kernels: the wave-per-query one (N <= 8192) and the grid walk (larger clouds)
+    # all three kernels: a wave per query over ALL points (N <= 4096), a wave per query over the grid's
+    # shells (larger clouds), and a thread per query when a query's shells overflow the wave's LDS share
     big, _ = oracle.voxel_down_sample(_scene(n_plane=14000, n_obj=5000, seed=8), 2.5)
     assert len(big) > 8193
-    for sub in (pts[:3000], big[:8192], big[:8193]):
+    for sub in (pts[:3000], big[:4096], big[:4097], big[:8193]):
         assert np.array_equal(cloud_ops.knn_mean_distance(sub, k), oracle.knn_mean_distance(sub, k))
+    rng = np.random.default_rng(3)
+    clump = np.concatenate([big[:6000], big[100] + rng.normal(0, 1e-3, (2600, 3))])   # 2,600 points in one grid cell
+    assert np.array_equal(cloud_ops.knn_mean_distance(clump, k), oracle.knn_mean_distance(clump, k))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 12345])

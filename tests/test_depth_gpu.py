@@ -65,8 +65,8 @@ def test_back_projection_and_chain(ctx, oracle):
     e = compat.erode_depth(d, radius=2, device="cuda")
     b = compat.bilateral_filter_depth(e, radius=2, device="cuda")
     _close(b, oracle.bilateral_filter_depth(oracle.erode_depth(d)))
-    with pytest.raises(NotImplementedError):
-        compat.depth2xyzmap(d, K, uvs=np.zeros((1, 2)))
+    one = compat.depth2xyzmap(d, K, uvs=np.array([[7.4, 11.6]]))       # pixel (7, 12) only
+    assert np.count_nonzero(one.any(axis=2)) <= 1 and np.array_equal(one[12, 7], compat.depth2xyzmap(d, K)[12, 7])
     assert compat.erode_depth(np.zeros((0, 0), np.float32)).shape == (0, 0)
 
 
@@ -87,3 +87,22 @@ def test_device_tensors_stay_on_device(ctx, oracle):
     assert x.is_cuda and tuple(x.shape) == (1, 145, 131, 3)
     _same(x.cpu().numpy(), oracle.depth2xyzmap_batch(d[None], K[None].astype(np.float32), np.inf))
     _same(compat.depth2xyzmap(t, K).cpu().numpy(), oracle.depth2xyzmap(d, K))
+
+
+def test_depth2xyzmap_with_pixel_list(ctx, oracle):
+    """depth2xyzmap(depth, K, uvs) (Utils.py:406-409): only the listed (u, v) pixels, rounded, are
+    back-projected; the reference's numpy statement gives the expected map."""
+    from pedp_hip import compat, synth
+
+    d = synth.depth_image(40, 48, seed=2, nan=False)
+    K = np.array([[50.0, 0, 23.5], [0, 52.0, 19.5], [0, 0, 1]])
+    rng = np.random.default_rng(0)
+    uvs = np.stack([rng.uniform(0, 47, 60), rng.uniform(0, 39, 60)], axis=1)
+    got = compat.depth2xyzmap(d, K, uvs, ctx=ctx)
+    us, vs = uvs.round().astype(int)[:, 0], uvs.round().astype(int)[:, 1]
+    zs = d[vs, us]
+    pts = np.stack(((us - K[0, 2]) * zs / K[0, 0], (vs - K[1, 2]) * zs / K[1, 1], zs), 1)
+    ref = np.zeros((40, 48, 3), np.float32)
+    ref[vs, us] = pts
+    ref[d < 0.001] = 0
+    assert got.shape == ref.shape and np.array_equal(got, ref)

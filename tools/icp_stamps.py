@@ -50,5 +50,7 @@ if len(blk):
     for w in worst:
         print(f"   slowest: total {tot[w]:.2f} us tiles {tiles[w]} words {nsurv[w]} fallback slots {nfb[w]} candidates {ncand[w]}  phases {np.round(d[w],2)}")
     print(f"   tiles/block median {np.median(tiles)} max {tiles.max()}; fallback slots/block max {nfb.max()} sum {nfb.sum()}")
+sv = buf[2][2]
+print("finish, last solving pass: LDLT %.2f  sincos+T %.2f  T update, motion, stores %.2f us" % tuple(np.diff(sv[:4]) * tick))
 fin = buf[2][0]
 print("finish: reduce %.2f solve %.2f tail %.2f us" % tuple(np.diff(fin[:4]) * tick))
