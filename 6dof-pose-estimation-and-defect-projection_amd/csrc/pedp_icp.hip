@@ -953,10 +953,12 @@ __device__ __forceinline__ void scan_near_tiles(unsigned long long near, int uni
     }
 }
 
-template <int W>
+// BATCH: the launch carries several poses (grid.y); a separate instantiation, so that a kernel
+// trace tells the single registration's launches from a batch's
+template <int W, bool BATCH>
 __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__restrict__ st0, const PassArgs a0) {
     static_assert(W * 64 == 4 * CH, "four threads per slot");
-    const size_t pose_off = (size_t)blockIdx.y * a0.pose_stride;
+    const size_t pose_off = BATCH ? (size_t)blockIdx.y * a0.pose_stride : 0;
     const IcpState *__restrict__ st = pose_ptr(st0, pose_off);
     // The argument block (with this pose's pointers) is parked in LDS and read from there where it is
     // used: held in scalar registers for the whole kernel its 40-odd fields overflow the SGPR file,
@@ -2247,7 +2249,10 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
     if (g < 1) g = 1;
     if (ev0) PEDP_HIP_CHECK(hipEventRecord(ev0, c->stream));
-    hipLaunchKernelGGL(icp_pass_kernel<BK_W>, dim3((unsigned)g, (unsigned)poses), dim3(BK_W * 64), 0, c->stream, w.st, pa);
+    if (poses > 1)
+        hipLaunchKernelGGL((icp_pass_kernel<BK_W, true>), dim3((unsigned)g, (unsigned)poses), dim3(BK_W * 64), 0, c->stream, w.st, pa);
+    else
+        hipLaunchKernelGGL((icp_pass_kernel<BK_W, false>), dim3((unsigned)g), dim3(BK_W * 64), 0, c->stream, w.st, pa);
     if (ev1) { PEDP_HIP_CHECK(hipEventRecord(ev1, c->stream)); c->nn_timed = true; }
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;

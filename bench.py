@@ -33,6 +33,7 @@ registration, radius-bounded search) on this host's cores, median of 10 steps af
 rank 0 at N = 1 only.
 """
 import argparse
+import csv
 import json
 import os
 import socket
@@ -324,6 +325,15 @@ def run(args):
                 break
             except OSError:
                 pass
+        trace_us = None     # the same kernel in the committed rocprofv3 kernel trace of this command
+        for name in ("r02_bench_kernel_stats_v2.csv",):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    for row in csv.DictReader(fh):
+                        if "icp_pass_kernel<8, false>" in row["Name"]:
+                            trace_us = float(row["AverageNs"]) / 1e3
+            except (OSError, KeyError, ValueError):
+                pass
         icp_ms, ray_ms, sweep_ms = (float(v) for v in rows.mean(axis=0))
         n_pass = max(passes, 1)
         pairs_pass = pairs_swept / n_pass
@@ -360,9 +370,12 @@ def run(args):
                          "mfma_util_pmc": traffic.get("icp_pass_kernel", {}).get("mfma_util"),
                          "kernel_ms": sweep_ms, "launches_per_step": passes,
                          "kernel_ms_x_launches": sweep_ms * passes, "region_ms_per_step": ms_per_step,
+                         "kernel_us_committed_kernel_trace": trace_us,
                          "note": f"{FLOP_PER_PAIR} flop x {pairs_pass:.4g} (scene slot, model point) pairs the kernel swept per "
                                  "pass (mean over the passes) / mean HIP-event duration of its launches in passes 1, 5, 9, "
-                                 "13, 17 of every registration of the timed loop.  The kernel is one workgroup per "
+                                 "13, 17 of every registration of the timed loop (an event pair brackets the launch with two "
+                                 "barrier packets, several us more than the dispatch-to-completion span a kernel trace "
+                                 "records; kernel_us_committed_kernel_trace is that span from profiles/).  The kernel is one workgroup per "
                                  "live scene chunk and is bound by its chain of dependent memory accesses (DESIGN s4.2), "
                                  "not by the matrix pipe: the MFMA fraction says how little of the pass is arithmetic"},
         }
