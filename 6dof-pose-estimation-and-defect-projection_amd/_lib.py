@@ -67,6 +67,7 @@ PROTOTYPES = {
                                      C.c_void_p, _P(C.c_int64)]),
     "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "pedp_raycast_last_variant": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
     "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "pedp_cloud_create_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "pedp_cloud_destroy": (None, [C.c_void_p]),
@@ -321,6 +322,13 @@ def raycast_last_sweep_ms(ctx):
     ms = C.c_float(0)
     check(load().pedp_raycast_last_sweep_ms(ctx._h, C.byref(ms)), "pedp_raycast_last_sweep_ms")
     return ms.value
+
+
+def raycast_last_variant(ctx):
+    """(variant the last cast ran, grid status of a variant-4 cast: 0 = the grid answered it)."""
+    v, g = C.c_int(0), C.c_int(0)
+    check(load().pedp_raycast_last_variant(ctx._h, C.byref(v), C.byref(g)), "pedp_raycast_last_variant")
+    return v.value, g.value
 
 
 def nn_last_sweep_ms(ctx):

@@ -154,6 +154,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_out.release();
     c->ray_aux.release();
     c->ray_order.release();
+    c->ray_rast.release();
+    if (c->rast_status) (void)hipHostFree(c->rast_status);
     c->icp_ws.release();
     c->proj.release();
     c->ops.release();

@@ -78,6 +78,11 @@ struct pedp_ctx_s {
     pedp_scratch ray_aux;    // shared-origin flag + per-call shared-origin pair records
     pedp_scratch ray_order;  // direction order of the last frame's rays (kept between calls) + the samples it is checked by
     int64_t ray_order_n = -1;
+    pedp_scratch ray_rast;   // variant 4: header, chain heads, nodes, item table
+    void *rast_hdr_ready = nullptr;  // the buffer whose header holds its start values
+    int *rast_status = nullptr;      // pinned, written by the last kernel of a variant-4 cast: [0] why the grid failed (0: it did not), [1] ray count
+    int rast_avoid_n = -2;
+    int ray_last_variant = 0;        // variant the last pedp_raycast ran           // ray count for which the grid is known not to work: variant 3 instead
     int ray_tri_chunks = 0;  // 0 = auto
     int ray_variant = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // sweep timing

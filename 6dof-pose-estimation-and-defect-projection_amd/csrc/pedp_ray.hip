@@ -80,9 +80,12 @@ struct MT {
 };
 
 // The oracle's operation order (oracle/ray.c header comment), verbatim.  rec = 12 floats.
-__device__ __forceinline__ MT mt_eval(const Ray &r, const float *rec) {
-    const float v0x = rec[0], v0y = rec[1], v0z = rec[2], e1x = rec[3], e1y = rec[4], e1z = rec[5];
-    const float e2x = rec[6], e2y = rec[7], e2z = rec[8], mx = rec[9], my = rec[10], mz = rec[11];
+struct TriRec {
+    float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, mx, my, mz;
+};
+__device__ __forceinline__ MT mt_eval(const Ray &r, const TriRec &q) {
+    const float v0x = q.v0x, v0y = q.v0y, v0z = q.v0z, e1x = q.e1x, e1y = q.e1y, e1z = q.e1z;
+    const float e2x = q.e2x, e2y = q.e2y, e2z = q.e2z, mx = q.mx, my = q.my, mz = q.mz;
     MT m;
     m.det = dot3(r.dx, r.dy, r.dz, mx, my, mz);
     const float sx = subr(r.ox, v0x), sy = subr(r.oy, v0y), sz = subr(r.oz, v0z);
@@ -96,6 +99,10 @@ __device__ __forceinline__ MT mt_eval(const Ray &r, const float *rec) {
     m.vn = dot3(r.dx, r.dy, r.dz, bx, by, bz);
     m.tn = -dot3(sx, sy, sz, mx, my, mz);
     return m;
+}
+__device__ __forceinline__ MT mt_eval(const Ray &r, const float *rec) {
+    const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
+    return mt_eval(r, q);
 }
 
 // Exact acceptance predicate of the oracle.
@@ -739,6 +746,337 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
     if (k < N && best != KEY_MISS) atomicMin(&keys[ri], best);
 }
 
+// ------------------------------------------------------------------ sweep, triangle-driven (variant 4)
+// All rays leave one origin O, so a triangle is seen under one fixed solid angle.  Take a frame
+// (A, E1, E2) with A = the mean direction of eight rays spread over the array, map every ray to p = (d.E1, d.E2) / d.A (the
+// plane at unit distance along A: straight lines stay straight, so a triangle in front of O maps
+// to the triangle of its mapped corners) and lay a grid of about N cells over the rays' bounding
+// rectangle.  Rays are threaded into per-cell chains (head[cell] -> node -> node ...; a node is the
+// ray's direction + the next index, the node index IS the ray index, nothing is sorted or moved).
+// Then the TRIANGLES drive the sweep: a thread per triangle maps the three corners, takes their
+// bounding rectangle widened by half a cell on every side (the rays' and the corners' rounding is
+// orders of magnitude below that) and applies the oracle's exact test to the rays in those cells --
+// the same mt_eval / mt_accept / mt_key on the same (ray, triangle) operands as the exhaustive
+// sweep, met in the same 64-bit atomicMin, so t, primitive ids and (u, v) are the same bits.
+// Every ray x triangle pair is still accounted for: a ray can only hit a triangle whose mapped
+// rectangle holds the ray's point.  Work per cast is O(N + F + covered cells) instead of O(N x F).
+//
+//   rast_bounds_kernel   origins equal? rays inside the frame's half space (d.A > 0.17 |d|)?
+//                        bounds of p; clears keys and chain heads
+//   rast_insert_kernel   grid from the bounds; node[i] = (d_i, atomicExch(head[cell_i], i))
+//   rast_tri_kernel      triangle per thread: up to RAST_INLINE cells walked by the thread itself,
+//                        larger rectangles cut into items of <= RAST_ITEM_CELLS cells
+//   rast_item_kernel     a wave per item, a cell per lane
+// Whatever the grid cannot answer -- origins differ, a ray outside the half space, more than
+// RAST_CHAIN_MAX rays in one cell, a full item table -- clears hdr.ok on the device and the
+// general exhaustive kernel (launched behind, gated by that word) completes the cast; the status
+// reaches the host through a pinned word and the next cast of the same ray count takes the cone
+// culling of variant 3 instead.  A triangle that comes within eps of the plane through O
+// perpendicular to A has no bounded image: it is tested against every cell.
+constexpr unsigned RAST_NONE = 0xFFFFFFFFu;
+constexpr int RAST_INLINE = 16;
+constexpr int RAST_ITEM_CELLS = 256;
+constexpr int RAST_ITEM_CAP = 1 << 18;
+constexpr int RAST_CHAIN_MAX = 64;
+constexpr float RAST_COS_MIN = 0.17f;
+constexpr int RAST_ITEM_WAVES = 8192;
+
+struct RastHdr {  // one per context, device memory; put back to its start values by ray_finalize_kernel
+    int ok;       // 1: the grid answers this cast; 0: the exhaustive kernel behind it does
+    int n_items;
+    int reason;   // why ok was cleared: 1 origins differ, 2 ray outside the half space, 4 chain too long, 8 item table full
+    int pad;
+    unsigned bnd[4];  // enc(min u), enc(max u), enc(min v), enc(max v)
+    float O[3], A[3], E1[3], E2[3];
+    float u0, v0, su, sv;
+    int GX, GY;
+};
+struct RastItem { int tri, x0, y0, w, h, pad0, pad1, pad2; };
+
+struct RastFrame { float A[3], E1[3], E2[3]; bool valid; };
+
+__device__ __forceinline__ RastFrame rast_frame(const float *__restrict__ rays6, int64_t N) {
+    // A = the mean of eight rays spread over the array (k (N - 1) / 7: first, last and six between them;
+    // for a row-major pixel grid they fall on different columns, so A points near the middle of the view)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = (N - 1) * k / 7;
+        const float dx = rays6[6 * i + 3], dy = rays6[6 * i + 4], dz = rays6[6 * i + 5];
+        const float l2 = dx * dx + dy * dy + dz * dz;
+        if (l2 > 1e-30f && l2 < 1e30f) {
+            const float inv = 1.0f / sqrtf(l2);
+            sx += dx * inv; sy += dy * inv; sz += dz * inv;
+        }
+    }
+    const float l2 = sx * sx + sy * sy + sz * sz;
+    RastFrame f;
+    f.valid = l2 > 1e-6f;
+    const float inv = 1.0f / sqrtf(f.valid ? l2 : 1.0f);
+    f.A[0] = sx * inv; f.A[1] = sy * inv; f.A[2] = sz * inv;
+    const float ax = fabsf(f.A[0]), ay = fabsf(f.A[1]), az = fabsf(f.A[2]);
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    if (ax <= ay && ax <= az) ex = 1.f; else if (ay <= az) ey = 1.f; else ez = 1.f;
+    float cx = ey * f.A[2] - ez * f.A[1], cy = ez * f.A[0] - ex * f.A[2], cz = ex * f.A[1] - ey * f.A[0];
+    const float ci = 1.0f / sqrtf(fmaxf(cx * cx + cy * cy + cz * cz, 1e-30f));
+    f.E1[0] = cx * ci; f.E1[1] = cy * ci; f.E1[2] = cz * ci;
+    f.E2[0] = f.A[1] * f.E1[2] - f.A[2] * f.E1[1];
+    f.E2[1] = f.A[2] * f.E1[0] - f.A[0] * f.E1[2];
+    f.E2[2] = f.A[0] * f.E1[1] - f.A[1] * f.E1[0];
+    return f;
+}
+
+// 0: no direction (zero or NaN: such a ray hits nothing in the exhaustive sweep either), 1: mapped, 2: outside the half space
+__device__ __forceinline__ int rast_map(float dx, float dy, float dz, const float *A, const float *E1, const float *E2,
+                                        float &u, float &v) {
+    const float l2 = dx * dx + dy * dy + dz * dz;
+    if (!(l2 > 0.f)) return 0;            // zero, or NaN
+    if (!(l2 < 3e38f)) return 2;          // infinite components: leave them to the exhaustive sweep
+    const float w = dx * A[0] + dy * A[1] + dz * A[2];
+    if (!(w * fabsf(w) > RAST_COS_MIN * RAST_COS_MIN * l2)) return 2;
+    const float iw = 1.0f / w;
+    u = (dx * E1[0] + dy * E1[1] + dz * E1[2]) * iw;
+    v = (dx * E2[0] + dy * E2[1] + dz * E2[2]) * iw;
+    return 1;
+}
+
+__global__ __launch_bounds__(256) void rast_bounds_kernel(const float *__restrict__ rays6, int64_t N, RastHdr *__restrict__ h,
+                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ head) {
+    const RastFrame f = rast_frame(rays6, N);
+    const unsigned ox = __float_as_uint(rays6[0]), oy = __float_as_uint(rays6[1]), oz = __float_as_uint(rays6[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { h->O[k] = rays6[k]; h->A[k] = f.A[k]; h->E1[k] = f.E1[k]; h->E2[k] = f.E2[k]; }
+        if (!f.valid) { atomicAnd(&h->ok, 0); atomicOr(&h->reason, 2); }
+    }
+    unsigned lo_u = 0xFFFFFFFFu, hi_u = 0u, lo_v = 0xFFFFFFFFu, hi_v = 0u;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = KEY_MISS;
+        head[i] = RAST_NONE;
+        if (__float_as_uint(rays6[6 * i]) != ox || __float_as_uint(rays6[6 * i + 1]) != oy || __float_as_uint(rays6[6 * i + 2]) != oz)
+            bad |= 1;
+        float u, v;
+        const int kind = rast_map(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], f.A, f.E1, f.E2, u, v);
+        if (kind == 2) bad |= 2;
+        if (kind == 1) {
+            const unsigned eu = enc_f(u), ev = enc_f(v);
+            lo_u = eu < lo_u ? eu : lo_u; hi_u = eu > hi_u ? eu : hi_u;
+            lo_v = ev < lo_v ? ev : lo_v; hi_v = ev > hi_v ? ev : hi_v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned t;
+        t = __shfl_xor(lo_u, off, 64); lo_u = t < lo_u ? t : lo_u;
+        t = __shfl_xor(hi_u, off, 64); hi_u = t > hi_u ? t : hi_u;
+        t = __shfl_xor(lo_v, off, 64); lo_v = t < lo_v ? t : lo_v;
+        t = __shfl_xor(hi_v, off, 64); hi_v = t > hi_v ? t : hi_v;
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    __shared__ unsigned red[4][4];
+    __shared__ int badw[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = lo_u; red[wave][1] = hi_u; red[wave][2] = lo_v; red[wave][3] = hi_v; badw[wave] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo_u = red[w][0] < lo_u ? red[w][0] : lo_u; hi_u = red[w][1] > hi_u ? red[w][1] : hi_u;
+            lo_v = red[w][2] < lo_v ? red[w][2] : lo_v; hi_v = red[w][3] > hi_v ? red[w][3] : hi_v;
+            bad |= badw[w];
+        }
+        atomicMin(&h->bnd[0], lo_u); atomicMax(&h->bnd[1], hi_u);
+        atomicMin(&h->bnd[2], lo_v); atomicMax(&h->bnd[3], hi_v);
+        if (bad) { atomicAnd(&h->ok, 0); atomicOr(&h->reason, bad); }
+    }
+}
+
+struct RastGrid { float u0, v0, su, sv; int GX, GY; };
+
+// the grid over [u0, u1] x [v0, v1]: about one cell per ray, never finer than 1e-4 (the mapped
+// coordinates carry ~1e-7 of rounding)
+__device__ __forceinline__ RastGrid rast_grid(const unsigned *bnd, int64_t N) {
+    RastGrid g;
+    const bool any = bnd[0] <= bnd[1] && bnd[2] <= bnd[3];
+    const float u0 = any ? dec_f(bnd[0]) : 0.f, u1 = any ? dec_f(bnd[1]) : 0.f;
+    const float v0 = any ? dec_f(bnd[2]) : 0.f, v1 = any ? dec_f(bnd[3]) : 0.f;
+    const float du = fmaxf(u1 - u0, 1e-6f), dv = fmaxf(v1 - v0, 1e-6f);
+    const float aspect = fminf(fmaxf(du / dv, 1.0f / 64.0f), 64.0f);
+    const float n = (float)(N < (int64_t)1 << 30 ? N : (int64_t)1 << 30);
+    float gx = floorf(sqrtf(n * aspect));
+    gx = fminf(fmaxf(gx, 1.0f), fminf(n, du * 1e4f + 1.0f));
+    float gy = floorf(n / gx);
+    gy = fminf(fmaxf(gy, 1.0f), dv * 1e4f + 1.0f);
+    g.GX = (int)gx; g.GY = (int)gy;
+    g.u0 = u0; g.v0 = v0;
+    g.su = gx / du; g.sv = gy / dv;
+    return g;
+}
+
+__device__ __forceinline__ int rast_clampi(float x, int hi) {  // floor(x) clamped to [0, hi]
+    const float c = fminf(fmaxf(floorf(x), 0.0f), (float)hi);
+    return (int)c;
+}
+
+__global__ __launch_bounds__(256) void rast_insert_kernel(const float *__restrict__ rays6, int64_t N, RastHdr *__restrict__ h,
+                                                         unsigned *__restrict__ head, float4 *__restrict__ nodes) {
+    if (h->ok == 0) return;
+    const RastGrid g = rast_grid(h->bnd, N);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { h->u0 = g.u0; h->v0 = g.v0; h->su = g.su; h->sv = g.sv; h->GX = g.GX; h->GY = g.GY; }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float dx = rays6[6 * i + 3], dy = rays6[6 * i + 4], dz = rays6[6 * i + 5];
+    float A[3], E1[3], E2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
+    float u, v;
+    if (rast_map(dx, dy, dz, A, E1, E2, u, v) != 1) return;
+    const int cx = rast_clampi((u - g.u0) * g.su, g.GX - 1), cy = rast_clampi((v - g.v0) * g.sv, g.GY - 1);
+    const unsigned nxt = atomicExch(&head[(size_t)cy * g.GX + cx], (unsigned)i);
+    nodes[i] = make_float4(dx, dy, dz, __uint_as_float(nxt));
+}
+
+// the rays of one chain against one triangle
+__device__ __forceinline__ void rast_fail(RastHdr *h, int why) {
+    atomicAnd(&h->ok, 0);
+    atomicOr(&h->reason, why);
+}
+
+__device__ __forceinline__ void rast_test(const float4 nd, unsigned ray, const float *O, const TriRec &q, unsigned f,
+                                          unsigned long long *__restrict__ keys) {
+    Ray r;
+    r.ox = O[0]; r.oy = O[1]; r.oz = O[2];
+    r.dx = nd.x; r.dy = nd.y; r.dz = nd.z;
+    const MT m = mt_eval(r, q);
+    if (mt_accept(m)) atomicMin(&keys[ray], mt_key(m, f));
+}
+
+__global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__ aos, int64_t F, RastHdr *__restrict__ h,
+                                                      const unsigned *__restrict__ head, const float4 *__restrict__ nodes,
+                                                      RastItem *__restrict__ items, unsigned long long *__restrict__ keys) {
+    if (h->ok == 0) return;
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float *rec = aos + f * PEDP_TRI_STRIDE;
+    const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
+    float O[3], A[3], E1[3], E2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { O[k] = h->O[k]; A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
+    const int GX = h->GX, GY = h->GY;
+    const float u0 = h->u0, v0 = h->v0, su = h->su, sv = h->sv;
+    // corners relative to O (v1, v2 re-derived from the record's edges: one more rounding, far below the margins)
+    float X[3][3];
+    X[0][0] = q.v0x - O[0]; X[0][1] = q.v0y - O[1]; X[0][2] = q.v0z - O[2];
+    X[1][0] = X[0][0] + q.e1x; X[1][1] = X[0][1] + q.e1y; X[1][2] = X[0][2] + q.e1z;
+    X[2][0] = X[0][0] + q.e2x; X[2][1] = X[0][1] + q.e2y; X[2][2] = X[0][2] + q.e2z;
+    float wmin = 3e38f, wmax = -3e38f, scale = fabsf(O[0]) + fabsf(O[1]) + fabsf(O[2]);
+    float pu[3], pv[3], pw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pw[k] = X[k][0] * A[0] + X[k][1] * A[1] + X[k][2] * A[2];
+        pu[k] = X[k][0] * E1[0] + X[k][1] * E1[1] + X[k][2] * E1[2];
+        pv[k] = X[k][0] * E2[0] + X[k][1] * E2[1] + X[k][2] * E2[2];
+        wmin = fminf(wmin, pw[k]); wmax = fmaxf(wmax, pw[k]);
+        scale = fmaxf(scale, fabsf(X[k][0]) + fabsf(X[k][1]) + fabsf(X[k][2]));
+    }
+    const float eps = 1e-5f * scale;
+    if (wmax < -eps) return;  // wholly behind the plane through O: t . (d.A) = w > 0 is impossible
+    int x0, x1, y0, y1;
+    if (!(wmin > eps) || !(scale < 3e38f)) {  // reaches the plane (or has a NaN / infinite corner): no bounded image
+        x0 = 0; x1 = GX - 1; y0 = 0; y1 = GY - 1;
+    } else {
+        float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float iw = 1.0f / pw[k];
+            const float a = pu[k] * iw, b = pv[k] * iw;
+            umin = fminf(umin, a); umax = fmaxf(umax, a);
+            vmin = fminf(vmin, b); vmax = fmaxf(vmax, b);
+        }
+        const float fx0 = (umin - u0) * su - 0.5f, fx1 = (umax - u0) * su + 0.5f;
+        const float fy0 = (vmin - v0) * sv - 0.5f, fy1 = (vmax - v0) * sv + 0.5f;
+        if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 < (float)GX) || !(fy0 < (float)GY)) return;  // beside the rays' rectangle
+        x0 = rast_clampi(fx0, GX - 1); x1 = rast_clampi(fx1, GX - 1);
+        y0 = rast_clampi(fy0, GY - 1); y1 = rast_clampi(fy1, GY - 1);
+    }
+    const int w = x1 - x0 + 1, hh = y1 - y0 + 1;
+    const long long ncell = (long long)w * hh;
+    if (ncell > RAST_INLINE) {
+        const int tw = w < RAST_ITEM_CELLS ? w : RAST_ITEM_CELLS;
+        const int th = RAST_ITEM_CELLS / tw > 0 ? RAST_ITEM_CELLS / tw : 1;
+        const int ntx = (w + tw - 1) / tw, nty = (hh + th - 1) / th;
+        const long long n = (long long)ntx * nty;
+        if (n > RAST_ITEM_CAP) { rast_fail(h, 8); return; }
+        const int base = atomicAdd(&h->n_items, (int)n);
+        if ((long long)base + n > RAST_ITEM_CAP) { rast_fail(h, 8); return; }
+        int at = base;
+        for (int ty = 0; ty < nty; ++ty)
+            for (int tx = 0; tx < ntx; ++tx) {
+                RastItem it;
+                it.tri = (int)f;
+                it.x0 = x0 + tx * tw; it.y0 = y0 + ty * th;
+                it.w = (x1 + 1 - it.x0) < tw ? (x1 + 1 - it.x0) : tw;
+                it.h = (y1 + 1 - it.y0) < th ? (y1 + 1 - it.y0) : th;
+                it.pad0 = it.pad1 = it.pad2 = 0;
+                items[at++] = it;
+            }
+        return;
+    }
+    const int nc = (int)ncell;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        unsigned idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const int yy = c / w, xx = c - yy * w;
+            idx[j] = c < nc ? head[(size_t)(y0 + yy) * GX + (x0 + xx)] : RAST_NONE;
+        }
+        int steps = 0;
+        while ((idx[0] & idx[1] & idx[2] & idx[3]) != RAST_NONE) {
+            float4 nd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nd[j] = nodes[idx[j] != RAST_NONE ? idx[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (idx[j] != RAST_NONE) {
+                    rast_test(nd[j], idx[j], O, q, (unsigned)f, keys);
+                    idx[j] = __float_as_uint(nd[j].w);
+                }
+            if (++steps > RAST_CHAIN_MAX) { rast_fail(h, 4); break; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rast_item_kernel(const float *__restrict__ aos, RastHdr *__restrict__ h,
+                                                       const unsigned *__restrict__ head, const float4 *__restrict__ nodes,
+                                                       const RastItem *__restrict__ items, unsigned long long *__restrict__ keys) {
+    if (h->ok == 0) return;
+    const int n_items = h->n_items < RAST_ITEM_CAP ? h->n_items : RAST_ITEM_CAP;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    float O[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) O[k] = h->O[k];
+    const int GX = h->GX;
+    for (int it = wave0; it < n_items; it += n_waves) {  // wave-uniform
+        const RastItem I = items[it];
+        const float *rec = aos + (size_t)I.tri * PEDP_TRI_STRIDE;
+        const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
+        const int nc = I.w * I.h;
+        for (int c = lane; c < nc; c += 64) {
+            const int yy = c / I.w, xx = c - yy * I.w;
+            unsigned idx = head[(size_t)(I.y0 + yy) * GX + (I.x0 + xx)];
+            int steps = 0;
+            while (idx != RAST_NONE) {
+                const float4 nd = nodes[idx];
+                rast_test(nd, idx, O, q, (unsigned)I.tri, keys);
+                idx = __float_as_uint(nd.w);
+                if (++steps > RAST_CHAIN_MAX) { rast_fail(h, 4); break; }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ sweep, triangle per lane
 constexpr int TPL_BLOCK = 256;
 constexpr int TPL_RAYS = 4;
@@ -799,8 +1137,15 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
 __global__ void ray_finalize_kernel(const float *__restrict__ aos, const float *__restrict__ rays6,
                                     int64_t N, const unsigned long long *__restrict__ keys,
                                     float *__restrict__ t_hit, uint32_t *__restrict__ prim_id,
-                                    float *__restrict__ uv) {
+                                    float *__restrict__ uv, RastHdr *__restrict__ rast, int *__restrict__ rast_status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && rast) {  // variant 4: how the cast went, for the host's choice next time; header back to its start values
+        rast_status[1] = (int)(N & 0x7FFFFFFF);
+        rast_status[0] = rast->ok ? 0 : rast->reason;
+        __threadfence_system();
+        rast->ok = 1; rast->n_items = 0; rast->reason = 0;
+        rast->bnd[0] = 0xFFFFFFFFu; rast->bnd[1] = 0u; rast->bnd[2] = 0xFFFFFFFFu; rast->bnd[3] = 0u;
+    }
     if (i >= N) return;
     unsigned long long key = keys[i];
     unsigned id = (unsigned)(key & 0xFFFFFFFFull);
@@ -987,7 +1332,7 @@ int pedp_mesh_size(pedp_mesh_t m, int64_t *V, int64_t *F) {
 int pedp_raycast_configure(pedp_ctx_t c, int tri_chunks, int variant) {
     PEDP_REQUIRE(c, "pedp_raycast_configure: null context");
     PEDP_REQUIRE(tri_chunks >= 0 && tri_chunks % 8 == 0, "pedp_raycast_configure: tri_chunks must be a multiple of 8");
-    PEDP_REQUIRE(variant >= 0 && variant <= 3, "pedp_raycast_configure: variant must be 0..3");
+    PEDP_REQUIRE(variant >= 0 && variant <= 4, "pedp_raycast_configure: variant must be 0..4");
     c->ray_tri_chunks = tri_chunks;
     c->ray_variant = variant;
     return PEDP_OK;
@@ -1020,11 +1365,75 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
     int st = c->ray_keys.reserve(sizeof(unsigned long long) * (size_t)N);
     if (st) return st;
     unsigned long long *keys = (unsigned long long *)c->ray_keys.ptr;
-    PEDP_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)N, c->stream));
 
     int variant = c->ray_variant;
-    if (variant == 0) variant = (N < 16384) ? 2 : 3;
-    if (variant == 1 || variant == 3) {
+    if (variant == 0) {
+        variant = 2;
+        if (N >= 16384) {
+            // the grid of variant 4 unless an earlier cast of this many rays reported that it could not
+            // answer them (rays behind the frame's plane, crowded cells, a full item table)
+            if (c->rast_status && (((volatile int *)c->rast_status)[0] & (2 | 4 | 8))) c->rast_avoid_n = ((volatile int *)c->rast_status)[1];
+            variant = (c->rast_avoid_n == (int)(N & 0x7FFFFFFF)) ? 3 : 4;
+        }
+    }
+    RastHdr *rast = nullptr;
+    c->ray_last_variant = variant;
+    if (variant != 4) PEDP_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)N, c->stream));
+    if (variant == 4) {
+        PEDP_REQUIRE(N < (int64_t)0x7FFFFFF0 && mesh->F < (int64_t)0x7FFFFFF0, "pedp_raycast: variant 4 takes fewer than 2^31 rays / triangles");
+        if (!c->rast_status) {
+            PEDP_HIP_CHECK(hipHostMalloc((void **)&c->rast_status, 64, hipHostMallocMapped));
+            c->rast_status[0] = 0; c->rast_status[1] = -1;
+        }
+        int *d_status = nullptr;
+        PEDP_HIP_CHECK(hipHostGetDevicePointer((void **)&d_status, c->rast_status, 0));
+        const size_t sz_head = align256(sizeof(unsigned) * (size_t)N), sz_nodes = align256(sizeof(float4) * (size_t)N);
+        st = c->ray_rast.reserve(256 + sz_head + sz_nodes + sizeof(RastItem) * (size_t)RAST_ITEM_CAP);
+        if (st) return st;
+        char *base = (char *)c->ray_rast.ptr;
+        rast = (RastHdr *)base;
+        unsigned *head = (unsigned *)(base + 256);
+        float4 *nodes = (float4 *)(base + 256 + sz_head);
+        RastItem *items = (RastItem *)(base + 256 + sz_head + sz_nodes);
+        if (c->rast_hdr_ready != (void *)rast) {  // new buffer, or a cast that did not reach its last kernel
+            RastHdr h0;
+            memset(&h0, 0, sizeof(h0));
+            h0.ok = 1;
+            h0.bnd[0] = 0xFFFFFFFFu; h0.bnd[2] = 0xFFFFFFFFu;
+            PEDP_HIP_CHECK(hipMemcpyAsync(rast, &h0, sizeof(h0), hipMemcpyHostToDevice, c->stream));
+            PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        c->rast_hdr_ready = nullptr;
+        // the exhaustive kernel behind the grid (runs only when hdr.ok was cleared)
+        int64_t ray_blocks = (N + RPL_BLOCK - 1) / RPL_BLOCK;
+        int groups_total = (int)(mesh->F_padded / (2 * RPL_PAIRS));
+        int n_chunks = c->ray_tri_chunks;
+        if (n_chunks == 0) {
+            n_chunks = 8;
+            while (ray_blocks * n_chunks < 4 * 8 * (int64_t)c->num_cus && groups_total / (n_chunks * 2) >= 512) n_chunks *= 2;
+        }
+        int gpc = (groups_total + n_chunks - 1) / n_chunks;
+        int64_t grid = ray_blocks * n_chunks;
+        PEDP_REQUIRE(grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
+        PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(rast_bounds_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, rast, keys, head);
+        hipLaunchKernelGGL(rast_insert_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, rast, head,
+                           nodes);
+        if (mesh->F > 0)
+            hipLaunchKernelGGL(rast_tri_kernel, dim3((unsigned)((mesh->F + 255) / 256)), dim3(256), 0, c->stream, mesh->tri,
+                               mesh->F, rast, head, nodes, items, keys);
+        hipLaunchKernelGGL(rast_item_kernel, dim3(RAST_ITEM_WAVES / 4), dim3(256), 0, c->stream, mesh->tri, rast, head, nodes,
+                           items, keys);
+        hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
+                           (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, &rast->ok);
+        PEDP_HIP_CHECK(hipGetLastError());
+        PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        c->ray_timed = true;
+        hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
+                           keys, d_t, d_id, d_uv, rast, d_status);
+        PEDP_HIP_CHECK(hipGetLastError());
+        c->rast_hdr_ready = (void *)rast;
+    } else if (variant == 1 || variant == 3) {
         // aux layout: [flag + bounds + seg info: 256 B][shared pair records][cone records][hist][perm]
         //             [packet masks][packet counts][segment table]
         const int64_t n_packets = (N + 63) / 64;
@@ -1126,13 +1535,13 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         hipLaunchKernelGGL(ray_sweep_tpl_kernel, dim3((unsigned)grid), dim3(TPL_BLOCK), 0, c->stream,
                            (const float4 *)mesh->tri, mesh->F_padded, tpc, n_chunks, d_rays, N, keys);
     }
-    PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
-    c->ray_timed = true;
-    {
+    if (variant != 4) {
+        PEDP_HIP_CHECK(hipGetLastError());
+        PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        c->ray_timed = true;
         int64_t grid = (N + 255) / 256;
         hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
-                           keys, d_t, d_id, d_uv);
+                           keys, d_t, d_id, d_uv, (RastHdr *)nullptr, (int *)nullptr);
         PEDP_HIP_CHECK(hipGetLastError());
     }
     if (mem == PEDP_HOST) {
@@ -1141,6 +1550,16 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         if (uv) { int dn_ = pedp_download(c, uv, d_uv, sizeof(float) * 2 * (size_t)N); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return PEDP_OK;
+}
+
+int pedp_raycast_last_variant(pedp_ctx_t c, int *variant, int *grid_status) {
+    PEDP_REQUIRE(c && variant && grid_status, "pedp_raycast_last_variant: null argument");
+    PEDP_REQUIRE(c->ray_last_variant > 0, "pedp_raycast_last_variant: no cast has run on this context");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *variant = c->ray_last_variant;
+    *grid_status = (c->ray_last_variant == 4 && c->rast_status) ? ((volatile int *)c->rast_status)[0] : 0;
     return PEDP_OK;
 }
 

@@ -75,12 +75,22 @@ int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N
 
 /* Tuning knobs of the sweep (0 = keep default): triangle chunks per ray block
  * (multiple of 8: chunk c is served by XCD c % 8) and sweep variant:
- *   0 auto (2 below 16,384 rays, else 3)
+ *   0 auto (2 below 16,384 rays, else 4; 3 for a ray count whose last variant-4 cast had to be
+ *     completed by the exhaustive sweep)
  *   1 ray-per-lane, every ray tested against every triangle
  *   2 triangle-per-lane with a wavefront-wide min-t reduction
  *   3 ray-per-lane with conservative cluster culling when all rays share one origin
- *     (falls back to 1 on the device otherwise).  All variants return identical bits. */
+ *     (falls back to 1 on the device otherwise)
+ *   4 triangle-driven: rays of one origin threaded into a grid of directions, every triangle
+ *     tested against the rays in the cells its image covers (completed by 1 on the device when
+ *     the rays do not share an origin, leave the grid's half space or crowd a cell).
+ * All variants return identical bits. */
 int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
+
+/* Which variant the last pedp_raycast of this context ran and, for variant 4, whether the grid
+ * answered the cast (grid_status 0) or the exhaustive sweep had to (bit 0 origins differ, 1 a ray
+ * outside the half space, 2 a crowded cell, 3 item table full).  Synchronises the stream. */
+int pedp_raycast_last_variant(pedp_ctx_t ctx, int *variant, int *grid_status);
 
 /* Milliseconds the last pedp_raycast spent in its sweep stage -- for variant 3 the direction
  * binning, cull masks, segment table and the sweep itself (HIP events on the context's stream,

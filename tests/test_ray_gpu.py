@@ -13,7 +13,7 @@ def _same(res, ref):
 
 
 @pytest.mark.parametrize("config", ["tiny", "parity"])
-@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 64), (2, 0), (2, 16), (3, 0)])
+@pytest.mark.parametrize("variant,chunks", [(1, 0), (1, 8), (1, 64), (2, 0), (2, 16), (3, 0), (4, 0)])
 def test_frame_bit_exact(ctx, oracle, config, variant, chunks):
     from pedp_hip import _lib, synth
 
@@ -54,7 +54,7 @@ def test_general_origins_and_unnormalised_directions(ctx, oracle):
     d = (tgt - o) * rng.uniform(0.01, 3.0, size=(n, 1))
     rays = np.hstack([o, d]).astype(np.float32)
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         _lib.raycast_configure(ctx, 0, variant)
         try:
             _same(mesh.cast_rays(rays), oracle.raycast(f.verts_posed, f.tris, rays))
@@ -103,7 +103,7 @@ def test_tie_takes_lowest_triangle_index(ctx, oracle):
     t = np.vstack([filler, [[3, 4, 5]], filler, [[6, 7, 8]]]).astype(np.uint32)
     rays = np.tile(np.array([[0.2, 0.3, 0, 0, 0, 1]], np.float32), (130, 1))
     mesh = _lib.Mesh(ctx, v, t)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         _lib.raycast_configure(ctx, 8, variant)
         try:
             r = mesh.cast_rays(rays)
@@ -126,7 +126,7 @@ def test_shared_and_mixed_origins_same_bits(ctx, oracle):
     mixed[-1, 0] = np.nextafter(mixed[-1, 0], np.float32(10))   # one ulp off in the last ray
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
     ref_a, ref_b = oracle.raycast(f.verts_posed, f.tris, rays), oracle.raycast(f.verts_posed, f.tris, mixed)
-    for variant in (1, 3):
+    for variant in (1, 3, 4):
         _lib.raycast_configure(ctx, 0, variant)
         try:
             a, b = mesh.cast_rays(rays), mesh.cast_rays(mixed)
@@ -154,14 +154,15 @@ def test_culling_is_conservative_on_hard_packets(ctx, oracle):
         d[50:60] = np.nan
         d[5000:10000] = f.verts_posed[rng.integers(0, len(f.verts_posed), 5000)] - origin
         rays = np.hstack([np.tile(origin, (n, 1)), d]).astype(np.float32)
-        _lib.raycast_configure(ctx, 0, 3)
-        try:
-            got = mesh.cast_rays(rays)
-        finally:
-            _lib.raycast_configure(ctx, 0, 0)
         ref = oracle.raycast(f.verts_posed, f.tris, rays)
         assert np.isfinite(ref["t_hit"]).sum() > 1000
-        _same(got, ref)
+        for variant in (3, 4):     # 4: rays in all directions leave the grid's half space -> completed exhaustively
+            _lib.raycast_configure(ctx, 0, variant)
+            try:
+                got = mesh.cast_rays(rays)
+            finally:
+                _lib.raycast_configure(ctx, 0, 0)
+            _same(got, ref)
 
 
 def test_bad_arguments_raise(ctx):
@@ -219,3 +220,127 @@ def test_kept_direction_order_never_changes_results(ctx, oracle):
     same(f.rays6[: n - 777], {"primitive_ids": ref["primitive_ids"][: n - 777], "t_hit": ref["t_hit"][: n - 777]})
     mesh.close()
     own.close()
+
+
+def _grid_cast(ctx, mesh, rays, want_status=None):
+    from pedp_hip import _lib
+
+    _lib.raycast_configure(ctx, 0, 4)
+    try:
+        got = mesh.cast_rays(rays)
+        variant, status = _lib.raycast_last_variant(ctx)
+    finally:
+        _lib.raycast_configure(ctx, 0, 0)
+    assert variant == 4
+    if want_status is not None:
+        assert status == want_status, f"grid status {status}, expected {want_status}"
+    return got
+
+
+def test_grid_sweep_answers_camera_frames_itself(ctx, oracle):
+    """Variant 4 (triangle-driven sweep over a grid of directions) on pinhole frames: the grid -- not
+    the exhaustive kernel behind it -- answers the cast (status 0), bit for bit the oracle's hits.
+    Sub-sets of a frame's rays (what the fused projection casts: the hot pixels only) leave cells
+    empty; a frame seen from inside the mesh has triangles behind and across the frame's plane."""
+    from pedp_hip import _lib, synth
+
+    for config in ("tiny", "parity"):
+        f = synth.Frame(config)
+        mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+        ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+        _same(_grid_cast(ctx, mesh, f.rays6, 0), ref)
+        rng = np.random.default_rng(3)
+        sub = np.sort(rng.choice(f.n_rays, f.n_rays // 7, replace=False))
+        _same(_grid_cast(ctx, mesh, f.rays6[sub], 0), oracle.raycast(f.verts_posed, f.tris, f.rays6[sub], bvh=True))
+    # camera inside the tube, looking along it: triangles all around, behind and across the plane through the origin
+    f = synth.Frame("parity")
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    centre = f.T_gt[:3, 3]
+    hits = 0
+    R = f.T_gt[:3, :3]
+    for origin in (centre, centre + R @ [60.0, 0.0, 0.0], centre + R @ [0.0, 0.0, 35.0], centre + R @ [45.0, 20.0, -10.0]):
+        for turn in (np.eye(3), R, R[:, [2, 0, 1]]):      # the frame's rays as they are, and turned along the object's axes
+            rays = f.rays6.copy()
+            rays[:, :3] = origin.astype(np.float32)
+            rays[:, 3:] = (f.rays6[:, 3:].astype(np.float64) @ turn.T).astype(np.float32)
+            ref = oracle.raycast(f.verts_posed, f.tris, rays)
+            hits += int(np.isfinite(ref["t_hit"]).sum())
+            _same(_grid_cast(ctx, mesh, rays, 0), ref)
+    assert hits > 20000
+
+
+def test_grid_sweep_large_small_and_degenerate_triangles(ctx, oracle):
+    """Triangles far larger than a cell (a two-triangle floor across the whole view: cut into wave
+    items), slivers, zero-area triangles, triangles in a plane through the origin (edge-on from every
+    ray), rays aimed exactly at vertices and along shared edges."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    rng = np.random.default_rng(9)
+    z = float(f.verts_posed[:, 2].max()) + 40.0
+    floor_v = np.array([[-4000, -4000, z], [4000, -4000, z], [4000, 4000, z], [-4000, 4000, z]], np.float64)
+    nv = len(f.verts_posed)
+    extra_v = [floor_v]
+    extra_t = [np.array([[0, 1, 2], [0, 2, 3]]) + nv]
+    # slivers and zero-area triangles between existing vertices
+    a = rng.integers(0, nv, 300)
+    sl = np.stack([a, (a + 1) % nv, a], axis=1)                       # zero area
+    sl2 = np.stack([a, (a + 1) % nv, (a + 2) % nv], axis=1)           # arbitrary thin ones
+    # triangles in planes through the origin
+    p = rng.normal(0, 1, (50, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    q = rng.normal(0, 1, (50, 3)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    through = np.stack([300.0 * p, 600.0 * p + 5.0 * q, 600.0 * p - 5.0 * q], axis=1).reshape(-1, 3)
+    through[:, 2] = np.abs(through[:, 2])
+    extra_v.append(through)
+    extra_t.append(np.arange(150).reshape(50, 3) + nv + 4)
+    verts = np.vstack([f.verts_posed] + extra_v)
+    tris = np.vstack([f.tris, extra_t[0], sl, sl2, extra_t[1]]).astype(np.uint32)
+    mesh = _lib.Mesh(ctx, verts, tris)
+    rays = f.rays6.copy()
+    at = rng.integers(0, nv, 4000)
+    rays[:4000, 3:] = f.verts_posed[at].astype(np.float32)            # exactly at vertices (origin is 0)
+    mid = 0.5 * (f.verts_posed[f.tris[:4000, 0]] + f.verts_posed[f.tris[:4000, 1]])
+    rays[4000:8000, 3:] = mid.astype(np.float32)                      # along shared edges
+    ref = oracle.raycast(verts, tris, rays)
+    assert np.isfinite(ref["t_hit"]).mean() > 0.9                     # the floor catches what misses the object
+    _same(_grid_cast(ctx, mesh, rays, 0), ref)
+
+
+def test_grid_sweep_hands_over_what_it_cannot_answer(ctx, oracle):
+    """Rays the grid cannot hold -- differing origins (status 1), directions behind the frame's plane or
+    infinite (2), more than 64 rays in one cell (4) -- are completed by the exhaustive kernel in the
+    same call, and the automatic choice then takes the cone culling for that ray count."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    own = _lib.Context(0)
+    mesh = _lib.Mesh(own, f.verts_posed, f.tris)
+    n = 20000
+    base = f.rays6[:: max(1, f.n_rays // n)][:n].copy()
+
+    def check(rays, status):
+        _same(_grid_cast(own, mesh, rays, status), oracle.raycast(f.verts_posed, f.tris, rays))
+
+    check(base, 0)
+    mixed = base.copy(); mixed[77, 1] += 0.5
+    check(mixed, 1)
+    back = base.copy(); back[5, 3:] = -back[5, 3:]
+    check(back, 2)
+    inf = base.copy(); inf[9, 3] = np.inf
+    check(inf, 2)
+    hit = int(np.flatnonzero(np.isfinite(oracle.raycast(f.verts_posed, f.tris, base)["t_hit"]))[0])
+    crowd = base.copy(); crowd[100:400] = crowd[hit]                  # 300 rays in a cell that triangles visit
+    check(crowd, 4)
+    lonely = base.copy(); lonely[100:400] = lonely[0]                 # ... and in a corner cell nothing maps to: never walked
+    assert not np.isfinite(oracle.raycast(f.verts_posed, f.tris, base[:1])["t_hit"][0])
+    check(lonely, 0)
+    odd = base.copy(); odd[:40, 3:] = 0.0; odd[40:60, 3:] = np.nan   # no direction: never a hit, not a reason to hand over
+    check(odd, 0)
+    # automatic choice: grid first, cone culling after a cast of this count that the grid handed over
+    assert _lib.raycast_last_variant(own)[0] == 4
+    _same(mesh.cast_rays(crowd), oracle.raycast(f.verts_posed, f.tris, crowd))
+    assert _lib.raycast_last_variant(own) == (4, 4)
+    _same(mesh.cast_rays(crowd), oracle.raycast(f.verts_posed, f.tris, crowd))
+    assert _lib.raycast_last_variant(own)[0] == 3
+    _same(mesh.cast_rays(base[:18000]), oracle.raycast(f.verts_posed, f.tris, base[:18000]))   # another count: the grid again
+    assert _lib.raycast_last_variant(own) == (4, 0)
