@@ -81,6 +81,7 @@ struct pedp_ctx_s {
     pedp_scratch ray_rast;   // variant 4: header, chain heads, nodes, item table
     void *rast_hdr_ready = nullptr;  // the buffer whose header holds its start values
     int *rast_status = nullptr;      // pinned, written by the last kernel of a variant-4 cast: [0] why the grid failed (0: it did not), [1] ray count
+    unsigned rast_seq = 0;           // casts enqueued: picks one of the two headers
     int rast_avoid_n = -2;
     int ray_last_variant = 0;        // variant the last pedp_raycast ran           // ray count for which the grid is known not to work: variant 3 instead
     int ray_tri_chunks = 0;  // 0 = auto

@@ -247,26 +247,11 @@ __device__ __forceinline__ f2 inside_score(const MT2 &m) {
 constexpr int RPL_BLOCK = 256;
 constexpr int RPL_PAIRS = 2;  // pair records per loop iteration (4 triangles)
 
-// The two instantiations are launched back to back; the device flag lets exactly one work.
+// the sweep loop: ray r against the 4-triangle groups [g0, g1)
 template <bool SHARED>
-__global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
-    const f2 *__restrict__ rec, const float *__restrict__ aos, int groups_total, int groups_per_chunk, int n_chunks,
-    const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys,
-    const int *__restrict__ shared_flag) {
-    if ((*shared_flag != 0) != SHARED) return;
+__device__ __forceinline__ unsigned long long sweep_groups(const Ray &r, const f2 *__restrict__ rec, const float *__restrict__ aos,
+                                                           int g0, int g1, unsigned long long best) {
     constexpr int PF = (SHARED ? PAIR_SH : PAIR_GEN) / 2;  // f2 per pair record
-    const int b = blockIdx.x;
-    const int chunk = b % n_chunks;  // n_chunks % 8 == 0: chunk % 8 == b % 8, one XCD per chunk
-    const int64_t rb = b / n_chunks;
-    const int64_t ray = rb * RPL_BLOCK + threadIdx.x;
-    const int64_t rl = ray < N ? ray : N - 1;  // tail lanes re-run the last ray, never store
-    Ray r;
-    r.ox = rays6[6 * rl + 0]; r.oy = rays6[6 * rl + 1]; r.oz = rays6[6 * rl + 2];
-    r.dx = rays6[6 * rl + 3]; r.dy = rays6[6 * rl + 4]; r.dz = rays6[6 * rl + 5];
-    int g0 = chunk * groups_per_chunk;
-    int g1 = g0 + groups_per_chunk;
-    if (g1 > groups_total) g1 = groups_total;
-    unsigned long long best = KEY_MISS;
     for (int g = g0; g < g1; ++g) {
         const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
         f2 sc[RPL_PAIRS];
@@ -290,6 +275,28 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
             }
         }
     }
+    return best;
+}
+
+// The two instantiations are launched back to back; the device flag lets exactly one work.
+template <bool SHARED>
+__global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
+    const f2 *__restrict__ rec, const float *__restrict__ aos, int groups_total, int groups_per_chunk, int n_chunks,
+    const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys,
+    const int *__restrict__ shared_flag) {
+    if ((*shared_flag != 0) != SHARED) return;
+    const int b = blockIdx.x;
+    const int chunk = b % n_chunks;  // n_chunks % 8 == 0: chunk % 8 == b % 8, one XCD per chunk
+    const int64_t rb = b / n_chunks;
+    const int64_t ray = rb * RPL_BLOCK + threadIdx.x;
+    const int64_t rl = ray < N ? ray : N - 1;  // tail lanes re-run the last ray, never store
+    Ray r;
+    r.ox = rays6[6 * rl + 0]; r.oy = rays6[6 * rl + 1]; r.oz = rays6[6 * rl + 2];
+    r.dx = rays6[6 * rl + 3]; r.dy = rays6[6 * rl + 4]; r.dz = rays6[6 * rl + 5];
+    int g0 = chunk * groups_per_chunk;
+    int g1 = g0 + groups_per_chunk;
+    if (g1 > groups_total) g1 = groups_total;
+    const unsigned long long best = sweep_groups<SHARED>(r, rec, aos, g0, g1, KEY_MISS);
     if (ray < N && best != KEY_MISS) atomicMin(&keys[ray], best);
 }
 
@@ -754,8 +761,8 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
 // rectangle.  Rays are threaded into per-cell chains (head[cell] -> node -> node ...; a node is the
 // ray's direction + the next index, the node index IS the ray index, nothing is sorted or moved).
 // Then the TRIANGLES drive the sweep: a thread per triangle maps the three corners, takes their
-// bounding rectangle widened by half a cell on every side (the rays' and the corners' rounding is
-// orders of magnitude below that) and applies the oracle's exact test to the rays in those cells --
+// bounding rectangle widened by a margin (an eighth of a cell + sixteen times the dilation the fp32
+// test's own rounding can give the triangle) and applies the oracle's exact test to the rays in those cells --
 // the same mt_eval / mt_accept / mt_key on the same (ray, triangle) operands as the exhaustive
 // sweep, met in the same 64-bit atomicMin, so t, primitive ids and (u, v) are the same bits.
 // Every ray x triangle pair is still accounted for: a ray can only hit a triangle whose mapped
@@ -765,28 +772,28 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
 //                        bounds of p; clears keys and chain heads
 //   rast_insert_kernel   grid from the bounds; node[i] = (d_i, atomicExch(head[cell_i], i))
 //   rast_tri_kernel      triangle per thread: up to RAST_INLINE cells walked by the thread itself,
-//                        larger rectangles cut into items of <= RAST_ITEM_CELLS cells
+//                        larger rectangles cut into tiles of RAST_TILE x RAST_TILE cells
 //   rast_item_kernel     a wave per item, a cell per lane
 // Whatever the grid cannot answer -- origins differ, a ray outside the half space, more than
-// RAST_CHAIN_MAX rays in one cell, a full item table -- clears hdr.ok on the device and the
-// general exhaustive kernel (launched behind, gated by that word) completes the cast; the status
-// reaches the host through a pinned word and the next cast of the same ray count takes the cone
-// culling of variant 3 instead.  A triangle that comes within eps of the plane through O
-// perpendicular to A has no bounded image: it is tested against every cell.
+// RAST_CHAIN_MAX rays in one cell, a full item table -- clears hdr.ok on the device, and the last
+// kernel of the cast (ray_finalize_kernel) then runs the general exhaustive loop for every ray before
+// it writes the results; the status reaches the host through a pinned word and the next cast of the
+// same ray count takes the cone culling of variant 3 instead.  A triangle that comes within eps of
+// the plane through O perpendicular to A has no bounded image: it is tested against every cell.
 constexpr unsigned RAST_NONE = 0xFFFFFFFFu;
 constexpr int RAST_INLINE = 16;
-constexpr int RAST_ITEM_CELLS = 256;
+constexpr int RAST_TILE = 16;          // larger rectangles are cut into tiles of 16 x 16 cells, one wave each
 constexpr int RAST_ITEM_CAP = 1 << 18;
 constexpr int RAST_CHAIN_MAX = 64;
 constexpr float RAST_COS_MIN = 0.17f;
-constexpr int RAST_ITEM_WAVES = 8192;
+constexpr int RAST_ITEM_WAVES = 2048;
+constexpr float RAST_DILATE_MAX = 64.0f;
 
-struct RastHdr {  // one per context, device memory; put back to its start values by ray_finalize_kernel
-    int ok;       // 1: the grid answers this cast; 0: the exhaustive kernel behind it does
+struct RastHdr {  // two per context (used in turn), device memory; ray_finalize_kernel puts the other one back to its start values
+    int ok;       // 1: the grid answers this cast; 0: the exhaustive loop in ray_finalize_kernel does
     int n_items;
     int reason;   // why ok was cleared: 1 origins differ, 2 ray outside the half space, 4 chain too long, 8 item table full
     int pad;
-    unsigned bnd[4];  // enc(min u), enc(max u), enc(min v), enc(max v)
     float O[3], A[3], E1[3], E2[3];
     float u0, v0, su, sv;
     int GX, GY;
@@ -840,8 +847,12 @@ __device__ __forceinline__ int rast_map(float dx, float dy, float dz, const floa
     return 1;
 }
 
+constexpr int RAST_BBLOCKS = 256;   // workgroups of rast_bounds_kernel = partial bounds the insert kernel folds
+constexpr int RAST_BUNROLL = 4;
+
 __global__ __launch_bounds__(256) void rast_bounds_kernel(const float *__restrict__ rays6, int64_t N, RastHdr *__restrict__ h,
-                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ head) {
+                                                         unsigned long long *__restrict__ keys, unsigned *__restrict__ head,
+                                                         uint4 *__restrict__ part) {
     const RastFrame f = rast_frame(rays6, N);
     const unsigned ox = __float_as_uint(rays6[0]), oy = __float_as_uint(rays6[1]), oz = __float_as_uint(rays6[2]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -851,18 +862,30 @@ __global__ __launch_bounds__(256) void rast_bounds_kernel(const float *__restric
     }
     unsigned lo_u = 0xFFFFFFFFu, hi_u = 0u, lo_v = 0xFFFFFFFFu, hi_v = 0u;
     int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        keys[i] = KEY_MISS;
-        head[i] = RAST_NONE;
-        if (__float_as_uint(rays6[6 * i]) != ox || __float_as_uint(rays6[6 * i + 1]) != oy || __float_as_uint(rays6[6 * i + 2]) != oz)
-            bad |= 1;
-        float u, v;
-        const int kind = rast_map(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], f.A, f.E1, f.E2, u, v);
-        if (kind == 2) bad |= 2;
-        if (kind == 1) {
-            const unsigned eu = enc_f(u), ev = enc_f(v);
-            lo_u = eu < lo_u ? eu : lo_u; hi_u = eu > hi_u ? eu : hi_u;
-            lo_v = ev < lo_v ? ev : lo_v; hi_v = ev > hi_v ? ev : hi_v;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < N; i0 += RAST_BUNROLL * stride) {
+        float r[RAST_BUNROLL][6];
+#pragma unroll
+        for (int k = 0; k < RAST_BUNROLL; ++k) {  // all loads of the trip first
+            const int64_t i = i0 + k * stride < N ? i0 + k * stride : i0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) r[k][c] = rays6[6 * i + c];
+        }
+#pragma unroll
+        for (int k = 0; k < RAST_BUNROLL; ++k) {
+            const int64_t i = i0 + k * stride;
+            if (i >= N) break;
+            keys[i] = KEY_MISS;
+            head[i] = RAST_NONE;
+            if (__float_as_uint(r[k][0]) != ox || __float_as_uint(r[k][1]) != oy || __float_as_uint(r[k][2]) != oz) bad |= 1;
+            float u, v;
+            const int kind = rast_map(r[k][3], r[k][4], r[k][5], f.A, f.E1, f.E2, u, v);
+            if (kind == 2) bad |= 2;
+            if (kind == 1) {
+                const unsigned eu = enc_f(u), ev = enc_f(v);
+                lo_u = eu < lo_u ? eu : lo_u; hi_u = eu > hi_u ? eu : hi_u;
+                lo_v = ev < lo_v ? ev : lo_v; hi_v = ev > hi_v ? ev : hi_v;
+            }
         }
     }
 #pragma unroll
@@ -885,10 +908,39 @@ __global__ __launch_bounds__(256) void rast_bounds_kernel(const float *__restric
             lo_v = red[w][2] < lo_v ? red[w][2] : lo_v; hi_v = red[w][3] > hi_v ? red[w][3] : hi_v;
             bad |= badw[w];
         }
-        atomicMin(&h->bnd[0], lo_u); atomicMax(&h->bnd[1], hi_u);
-        atomicMin(&h->bnd[2], lo_v); atomicMax(&h->bnd[3], hi_v);
+        part[blockIdx.x] = make_uint4(lo_u, hi_u, lo_v, hi_v);
         if (bad) { atomicAnd(&h->ok, 0); atomicOr(&h->reason, bad); }
     }
+}
+
+// fold of the RAST_BBLOCKS partial bounds; every workgroup that needs the grid does it for itself
+__device__ __forceinline__ void rast_fold_bounds(const uint4 *__restrict__ part, unsigned *bnd /* LDS, 4 words */) {
+    __shared__ unsigned fred[4][4];
+    unsigned lo_u = 0xFFFFFFFFu, hi_u = 0u, lo_v = 0xFFFFFFFFu, hi_v = 0u;
+    for (int k = threadIdx.x; k < RAST_BBLOCKS; k += blockDim.x) {
+        const uint4 q = part[k];
+        lo_u = q.x < lo_u ? q.x : lo_u; hi_u = q.y > hi_u ? q.y : hi_u;
+        lo_v = q.z < lo_v ? q.z : lo_v; hi_v = q.w > hi_v ? q.w : hi_v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned t;
+        t = __shfl_xor(lo_u, off, 64); lo_u = t < lo_u ? t : lo_u;
+        t = __shfl_xor(hi_u, off, 64); hi_u = t > hi_u ? t : hi_u;
+        t = __shfl_xor(lo_v, off, 64); lo_v = t < lo_v ? t : lo_v;
+        t = __shfl_xor(hi_v, off, 64); hi_v = t > hi_v ? t : hi_v;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { fred[wave][0] = lo_u; fred[wave][1] = hi_u; fred[wave][2] = lo_v; fred[wave][3] = hi_v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            lo_u = fred[w][0] < lo_u ? fred[w][0] : lo_u; hi_u = fred[w][1] > hi_u ? fred[w][1] : hi_u;
+            lo_v = fred[w][2] < lo_v ? fred[w][2] : lo_v; hi_v = fred[w][3] > hi_v ? fred[w][3] : hi_v;
+        }
+        bnd[0] = lo_u; bnd[1] = hi_u; bnd[2] = lo_v; bnd[3] = hi_v;
+    }
+    __syncthreads();
 }
 
 struct RastGrid { float u0, v0, su, sv; int GX, GY; };
@@ -919,9 +971,12 @@ __device__ __forceinline__ int rast_clampi(float x, int hi) {  // floor(x) clamp
 }
 
 __global__ __launch_bounds__(256) void rast_insert_kernel(const float *__restrict__ rays6, int64_t N, RastHdr *__restrict__ h,
-                                                         unsigned *__restrict__ head, float4 *__restrict__ nodes) {
+                                                         unsigned *__restrict__ head, float4 *__restrict__ nodes,
+                                                         const uint4 *__restrict__ part) {
     if (h->ok == 0) return;
-    const RastGrid g = rast_grid(h->bnd, N);
+    __shared__ unsigned bnd[4];
+    rast_fold_bounds(part, bnd);
+    const RastGrid g = rast_grid(bnd, N);
     if (blockIdx.x == 0 && threadIdx.x == 0) { h->u0 = g.u0; h->v0 = g.v0; h->su = g.su; h->sv = g.sv; h->GX = g.GX; h->GY = g.GY; }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -955,9 +1010,10 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
                                                       const unsigned *__restrict__ head, const float4 *__restrict__ nodes,
                                                       RastItem *__restrict__ items, unsigned long long *__restrict__ keys) {
     if (h->ok == 0) return;
+    const int lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const float *rec = aos + f * PEDP_TRI_STRIDE;
+    const int64_t fl = f < F ? f : F - 1;  // tail lanes re-run the last triangle and drop it below
+    const float *rec = aos + fl * PEDP_TRI_STRIDE;
     const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
     float O[3], A[3], E1[3], E2[3];
 #pragma unroll
@@ -980,11 +1036,9 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
         scale = fmaxf(scale, fabsf(X[k][0]) + fabsf(X[k][1]) + fabsf(X[k][2]));
     }
     const float eps = 1e-5f * scale;
-    if (wmax < -eps) return;  // wholly behind the plane through O: t . (d.A) = w > 0 is impossible
-    int x0, x1, y0, y1;
-    if (!(wmin > eps) || !(scale < 3e38f)) {  // reaches the plane (or has a NaN / infinite corner): no bounded image
-        x0 = 0; x1 = GX - 1; y0 = 0; y1 = GY - 1;
-    } else {
+    bool live = f < F && !(wmax < -eps);  // wholly behind the plane through O: t . (d.A) = w > 0 is impossible
+    int x0 = 0, x1 = GX - 1, y0 = 0, y1 = GY - 1;
+    if ((wmin > eps) && (scale < 3e38f)) {  // otherwise it reaches the plane (or has a NaN / infinite corner): no bounded image
         float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -993,35 +1047,66 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
             umin = fminf(umin, a); umax = fmaxf(umax, a);
             vmin = fminf(vmin, b); vmax = fmaxf(vmax, b);
         }
-        const float fx0 = (umin - u0) * su - 0.5f, fx1 = (umax - u0) * su + 0.5f;
-        const float fy0 = (vmin - v0) * sv - 0.5f, fy1 = (vmax - v0) * sv + 0.5f;
-        if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 < (float)GX) || !(fy0 < (float)GY)) return;  // beside the rays' rectangle
+        // Margin.  The oracle's fp32 test accepts a ray whose exact point lies outside the exact triangle by
+        // at most the rounding of un, vn, det against |det| -- in mapped coordinates a dilation of
+        // about g / (sin phi cos theta), g ~ 2^-22, phi the corner angle, theta the viewing angle; with
+        // s = v0 - O that is g |e1| |e2| |s| / |s . m|.  Sixteen times that, plus an eighth of a cell
+        // (capped at RAST_DILATE_MAX cells: beyond that the origin lies within ~1e-4 rad of the triangle's
+        // plane, every ray that reaches the triangle does so at |det| of rounding size).
+        const float l1 = sqrtf(q.e1x * q.e1x + q.e1y * q.e1y + q.e1z * q.e1z), l2 = sqrtf(q.e2x * q.e2x + q.e2y * q.e2y + q.e2z * q.e2z);
+        const float ls = sqrtf(X[0][0] * X[0][0] + X[0][1] * X[0][1] + X[0][2] * X[0][2]);
+        const float sm = fabsf(X[0][0] * q.mx + X[0][1] * q.my + X[0][2] * q.mz);
+        const float dil = fminf(3.8e-6f * l1 * l2 * ls / fmaxf(sm, 1e-30f), 1e6f);
+        const float mx_ = 0.125f + fminf(dil * su, RAST_DILATE_MAX), my_ = 0.125f + fminf(dil * sv, RAST_DILATE_MAX);
+        const float fx0 = (umin - u0) * su - mx_, fx1 = (umax - u0) * su + mx_;
+        const float fy0 = (vmin - v0) * sv - my_, fy1 = (vmax - v0) * sv + my_;
+        if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 < (float)GX) || !(fy0 < (float)GY)) live = false;  // beside the rays' rectangle
         x0 = rast_clampi(fx0, GX - 1); x1 = rast_clampi(fx1, GX - 1);
         y0 = rast_clampi(fy0, GY - 1); y1 = rast_clampi(fy1, GY - 1);
     }
     const int w = x1 - x0 + 1, hh = y1 - y0 + 1;
-    const long long ncell = (long long)w * hh;
-    if (ncell > RAST_INLINE) {
-        const int tw = w < RAST_ITEM_CELLS ? w : RAST_ITEM_CELLS;
-        const int th = RAST_ITEM_CELLS / tw > 0 ? RAST_ITEM_CELLS / tw : 1;
-        const int ntx = (w + tw - 1) / tw, nty = (hh + th - 1) / th;
-        const long long n = (long long)ntx * nty;
-        if (n > RAST_ITEM_CAP) { rast_fail(h, 8); return; }
-        const int base = atomicAdd(&h->n_items, (int)n);
-        if ((long long)base + n > RAST_ITEM_CAP) { rast_fail(h, 8); return; }
-        int at = base;
-        for (int ty = 0; ty < nty; ++ty)
-            for (int tx = 0; tx < ntx; ++tx) {
+    const long long ncell = live ? (long long)w * hh : 0;
+    // larger rectangles: cut into tiles of RAST_TILE x RAST_TILE cells.  One reservation in the item
+    // table per wave (exclusive scan of the lanes' tile counts), the tiles written by the whole wave.
+    const bool big = ncell > RAST_INLINE;
+    unsigned long long bigm = __builtin_amdgcn_ballot_w64(big);
+    if (bigm != 0ull) {  // wave-uniform
+        const int ntx_l = (w + RAST_TILE - 1) / RAST_TILE, nty_l = (hh + RAST_TILE - 1) / RAST_TILE;
+        const int n_l = big ? ntx_l * nty_l : 0;  // <= (N / 256 + ...) tiles: fits an int
+        int incl = n_l;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&h->n_items, total);
+        base = __shfl(base, 0, 64);
+        if ((long long)base + total > RAST_ITEM_CAP) {
+            if (lane == 0) rast_fail(h, 8);
+            bigm = 0ull;
+        }
+        const int mine = base + incl - n_l;
+        while (bigm != 0ull) {
+            const int src = __builtin_ctzll(bigm);
+            bigm &= bigm - 1ull;
+            const int tf = __shfl((int)fl, src, 64), tx0 = __shfl(x0, src, 64), ty0 = __shfl(y0, src, 64);
+            const int tw = __shfl(w, src, 64), th = __shfl(hh, src, 64), at = __shfl(mine, src, 64);
+            const int ntx = __shfl(ntx_l, src, 64), n = __shfl(n_l, src, 64);
+            for (int j = lane; j < n; j += 64) {
+                const int ty = j / ntx, tx = j - ty * ntx;
                 RastItem it;
-                it.tri = (int)f;
-                it.x0 = x0 + tx * tw; it.y0 = y0 + ty * th;
-                it.w = (x1 + 1 - it.x0) < tw ? (x1 + 1 - it.x0) : tw;
-                it.h = (y1 + 1 - it.y0) < th ? (y1 + 1 - it.y0) : th;
+                it.tri = tf;
+                it.x0 = tx0 + tx * RAST_TILE; it.y0 = ty0 + ty * RAST_TILE;
+                it.w = (tx0 + tw - it.x0) < RAST_TILE ? (tx0 + tw - it.x0) : RAST_TILE;
+                it.h = (ty0 + th - it.y0) < RAST_TILE ? (ty0 + th - it.y0) : RAST_TILE;
                 it.pad0 = it.pad1 = it.pad2 = 0;
-                items[at++] = it;
+                items[at + j] = it;
             }
-        return;
+        }
     }
+    if (ncell == 0 || ncell > RAST_INLINE) return;
     const int nc = (int)ncell;
     for (int c0 = 0; c0 < nc; c0 += 4) {
         unsigned idx[4];
@@ -1058,21 +1143,31 @@ __global__ __launch_bounds__(256) void rast_item_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < 3; ++k) O[k] = h->O[k];
     const int GX = h->GX;
+    static_assert(RAST_TILE * RAST_TILE == 4 * 64, "a tile is four cells per lane");
     for (int it = wave0; it < n_items; it += n_waves) {  // wave-uniform
         const RastItem I = items[it];
         const float *rec = aos + (size_t)I.tri * PEDP_TRI_STRIDE;
         const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
         const int nc = I.w * I.h;
-        for (int c = lane; c < nc; c += 64) {
+        unsigned idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // the lane's four cells: all heads first, then the chains side by side
+            const int c = lane + 64 * j;
             const int yy = c / I.w, xx = c - yy * I.w;
-            unsigned idx = head[(size_t)(I.y0 + yy) * GX + (I.x0 + xx)];
-            int steps = 0;
-            while (idx != RAST_NONE) {
-                const float4 nd = nodes[idx];
-                rast_test(nd, idx, O, q, (unsigned)I.tri, keys);
-                idx = __float_as_uint(nd.w);
-                if (++steps > RAST_CHAIN_MAX) { rast_fail(h, 4); break; }
-            }
+            idx[j] = c < nc ? head[(size_t)(I.y0 + yy) * GX + (I.x0 + xx)] : RAST_NONE;
+        }
+        int steps = 0;
+        while ((idx[0] & idx[1] & idx[2] & idx[3]) != RAST_NONE) {
+            float4 nd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nd[j] = nodes[idx[j] != RAST_NONE ? idx[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (idx[j] != RAST_NONE) {
+                    rast_test(nd[j], idx[j], O, q, (unsigned)I.tri, keys);
+                    idx[j] = __float_as_uint(nd[j].w);
+                }
+            if (++steps > RAST_CHAIN_MAX) { rast_fail(h, 4); break; }
         }
     }
 }
@@ -1134,17 +1229,26 @@ __global__ __launch_bounds__(TPL_BLOCK) void ray_sweep_tpl_kernel(
 }
 
 // ------------------------------------------------------------------ finalize
-__global__ void ray_finalize_kernel(const float *__restrict__ aos, const float *__restrict__ rays6,
-                                    int64_t N, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(256) void ray_finalize_kernel(const float *__restrict__ aos, const float *__restrict__ rays6,
+                                    int64_t N, unsigned long long *__restrict__ keys,
                                     float *__restrict__ t_hit, uint32_t *__restrict__ prim_id,
-                                    float *__restrict__ uv, RastHdr *__restrict__ rast, int *__restrict__ rast_status) {
+                                    float *__restrict__ uv, const RastHdr *__restrict__ rast, RastHdr *__restrict__ rast_next,
+                                    int *__restrict__ rast_status, const f2 *__restrict__ pairs, int groups_total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && rast) {  // variant 4: how the cast went, for the host's choice next time; header back to its start values
+    if (i == 0 && rast) {  // variant 4: how the cast went, for the host's choice next time; the other header gets its start values
         rast_status[1] = (int)(N & 0x7FFFFFFF);
         rast_status[0] = rast->ok ? 0 : rast->reason;
         __threadfence_system();
-        rast->ok = 1; rast->n_items = 0; rast->reason = 0;
-        rast->bnd[0] = 0xFFFFFFFFu; rast->bnd[1] = 0u; rast->bnd[2] = 0xFFFFFFFFu; rast->bnd[3] = 0u;
+        rast_next->ok = 1; rast_next->n_items = 0; rast_next->reason = 0;
+    }
+    if (i >= N) return;
+    if (rast && rast->ok == 0) {
+        // the grid could not answer this cast: every triangle for this ray, the exhaustive sweep's loop
+        // (what the grid did find is kept: a minimum over more candidates)
+        Ray r;
+        r.ox = rays6[6 * i + 0]; r.oy = rays6[6 * i + 1]; r.oz = rays6[6 * i + 2];
+        r.dx = rays6[6 * i + 3]; r.dy = rays6[6 * i + 4]; r.dz = rays6[6 * i + 5];
+        keys[i] = sweep_groups<false>(r, pairs, aos, 0, groups_total, keys[i]);
     }
     if (i >= N) return;
     unsigned long long key = keys[i];
@@ -1388,51 +1492,45 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         int *d_status = nullptr;
         PEDP_HIP_CHECK(hipHostGetDevicePointer((void **)&d_status, c->rast_status, 0));
         const size_t sz_head = align256(sizeof(unsigned) * (size_t)N), sz_nodes = align256(sizeof(float4) * (size_t)N);
-        st = c->ray_rast.reserve(256 + sz_head + sz_nodes + sizeof(RastItem) * (size_t)RAST_ITEM_CAP);
+        const size_t sz_part = align256(sizeof(uint4) * RAST_BBLOCKS);
+        st = c->ray_rast.reserve(512 + sz_part + sz_head + sz_nodes + sizeof(RastItem) * (size_t)RAST_ITEM_CAP);
         if (st) return st;
         char *base = (char *)c->ray_rast.ptr;
-        rast = (RastHdr *)base;
-        unsigned *head = (unsigned *)(base + 256);
-        float4 *nodes = (float4 *)(base + 256 + sz_head);
-        RastItem *items = (RastItem *)(base + 256 + sz_head + sz_nodes);
-        if (c->rast_hdr_ready != (void *)rast) {  // new buffer, or a cast that did not reach its last kernel
+        // two headers, used in turn: the last kernel of a cast puts the OTHER one back to its start values
+        // (it still reads its own), so no kernel ever resets a word that workgroups of the same launch test
+        static_assert(sizeof(RastHdr) <= 256, "header slot");
+        rast = (RastHdr *)(base + 256 * (c->rast_seq & 1));
+        RastHdr *rast_next = (RastHdr *)(base + 256 * ((c->rast_seq + 1) & 1));
+        uint4 *part = (uint4 *)(base + 512);
+        unsigned *head = (unsigned *)(base + 512 + sz_part);
+        float4 *nodes = (float4 *)(base + 512 + sz_part + sz_head);
+        RastItem *items = (RastItem *)(base + 512 + sz_part + sz_head + sz_nodes);
+        if (c->rast_hdr_ready != (void *)base) {  // new buffer, or a cast that did not reach its last kernel
             RastHdr h0;
             memset(&h0, 0, sizeof(h0));
             h0.ok = 1;
-            h0.bnd[0] = 0xFFFFFFFFu; h0.bnd[2] = 0xFFFFFFFFu;
             PEDP_HIP_CHECK(hipMemcpyAsync(rast, &h0, sizeof(h0), hipMemcpyHostToDevice, c->stream));
             PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
         }
         c->rast_hdr_ready = nullptr;
-        // the exhaustive kernel behind the grid (runs only when hdr.ok was cleared)
-        int64_t ray_blocks = (N + RPL_BLOCK - 1) / RPL_BLOCK;
-        int groups_total = (int)(mesh->F_padded / (2 * RPL_PAIRS));
-        int n_chunks = c->ray_tri_chunks;
-        if (n_chunks == 0) {
-            n_chunks = 8;
-            while (ray_blocks * n_chunks < 4 * 8 * (int64_t)c->num_cus && groups_total / (n_chunks * 2) >= 512) n_chunks *= 2;
-        }
-        int gpc = (groups_total + n_chunks - 1) / n_chunks;
-        int64_t grid = ray_blocks * n_chunks;
-        PEDP_REQUIRE(grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
         PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(rast_bounds_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, rast, keys, head);
+        hipLaunchKernelGGL(rast_bounds_kernel, dim3(RAST_BBLOCKS), dim3(256), 0, c->stream, d_rays, N, rast, keys, head, part);
         hipLaunchKernelGGL(rast_insert_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_rays, N, rast, head,
-                           nodes);
+                           nodes, (const uint4 *)part);
         if (mesh->F > 0)
             hipLaunchKernelGGL(rast_tri_kernel, dim3((unsigned)((mesh->F + 255) / 256)), dim3(256), 0, c->stream, mesh->tri,
                                mesh->F, rast, head, nodes, items, keys);
         hipLaunchKernelGGL(rast_item_kernel, dim3(RAST_ITEM_WAVES / 4), dim3(256), 0, c->stream, mesh->tri, rast, head, nodes,
                            items, keys);
-        hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
-                           (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, &rast->ok);
         PEDP_HIP_CHECK(hipGetLastError());
         PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
         c->ray_timed = true;
         hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
-                           keys, d_t, d_id, d_uv, rast, d_status);
+                           keys, d_t, d_id, d_uv, (const RastHdr *)rast, rast_next, d_status, (const f2 *)mesh->tri2,
+                           (int)(mesh->F_padded / (2 * RPL_PAIRS)));
         PEDP_HIP_CHECK(hipGetLastError());
-        c->rast_hdr_ready = (void *)rast;
+        c->rast_hdr_ready = (void *)base;
+        c->rast_seq += 1;
     } else if (variant == 1 || variant == 3) {
         // aux layout: [flag + bounds + seg info: 256 B][shared pair records][cone records][hist][perm]
         //             [packet masks][packet counts][segment table]
@@ -1541,7 +1639,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         c->ray_timed = true;
         int64_t grid = (N + 255) / 256;
         hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
-                           keys, d_t, d_id, d_uv, (RastHdr *)nullptr, (int *)nullptr);
+                           keys, d_t, d_id, d_uv, (const RastHdr *)nullptr, (RastHdr *)nullptr, (int *)nullptr, (const f2 *)nullptr, 0);
         PEDP_HIP_CHECK(hipGetLastError());
     }
     if (mem == PEDP_HOST) {
