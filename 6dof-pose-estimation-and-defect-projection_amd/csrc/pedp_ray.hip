@@ -1108,21 +1108,26 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
     }
     if (ncell == 0 || ncell > RAST_INLINE) return;
     const int nc = (int)ncell;
-    for (int c0 = 0; c0 < nc; c0 += 4) {
-        unsigned idx[4];
+    constexpr int U = 8;  // cells in flight: all their heads are requested first, then the nodes side by side
+    for (int c0 = 0; c0 < nc; c0 += U) {
+        unsigned idx[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < U; ++j) {
             const int c = c0 + j;
             const int yy = c / w, xx = c - yy * w;
             idx[j] = c < nc ? head[(size_t)(y0 + yy) * GX + (x0 + xx)] : RAST_NONE;
         }
         int steps = 0;
-        while ((idx[0] & idx[1] & idx[2] & idx[3]) != RAST_NONE) {
-            float4 nd[4];
+        for (;;) {
+            unsigned all = idx[0];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nd[j] = nodes[idx[j] != RAST_NONE ? idx[j] : 0u];
+            for (int j = 1; j < U; ++j) all &= idx[j];
+            if (all == RAST_NONE) break;
+            float4 nd[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < U; ++j) nd[j] = nodes[idx[j] != RAST_NONE ? idx[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < U; ++j)
                 if (idx[j] != RAST_NONE) {
                     rast_test(nd[j], idx[j], O, q, (unsigned)f, keys);
                     idx[j] = __float_as_uint(nd[j].w);
