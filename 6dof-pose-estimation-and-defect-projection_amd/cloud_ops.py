@@ -94,3 +94,30 @@ def estimate_normals(points, radius, max_nn, prior=None, ctx=None):
     _lib.check(_lib.load().pedp_estimate_normals(ctx._h, _lib._ptr(p), len(p), float(radius), int(max_nn), _lib._ptr(pr),
                                                  _lib._ptr(out)), "pedp_estimate_normals")
     return out
+
+
+def compute_fpfh(points, normals, radius, max_nn, ctx=None):
+    """FPFH features of a cloud with normals, N x 33 float64 (row i = column i of Open3D's
+    Feature.data); hybrid neighbourhood (radius, max_nn) as compute_fpfh_feature takes it
+    (pose_estimation.py:132-137)."""
+    ctx = ctx or _lib.default_context()
+    p, n = _pts(points), _pts(normals)
+    if len(p) != len(n):
+        raise RuntimeError("compute_fpfh_feature needs a normal for every point")
+    out = np.empty((len(p), 33), np.float64)
+    _lib.check(_lib.load().pedp_fpfh(ctx._h, _lib._ptr(p), _lib._ptr(n), len(p), float(radius), int(max_nn), _lib._ptr(out)),
+               "pedp_fpfh")
+    return out
+
+
+def match_features(source_features, target_features, ctx=None):
+    """idx[i] = the target feature (row) nearest to source feature i, squared L2 over 33 float64
+    components, ties to the lower index -- the correspondences registration_ransac_based_on_feature_matching
+    starts from."""
+    ctx = ctx or _lib.default_context()
+    fs = np.ascontiguousarray(source_features, np.float64).reshape(-1, 33)
+    ft = np.ascontiguousarray(target_features, np.float64).reshape(-1, 33)
+    idx = np.empty(len(fs), np.int32)
+    _lib.check(_lib.load().pedp_feature_match(ctx._h, _lib._ptr(fs), len(fs), _lib._ptr(ft), len(ft), _lib._ptr(idx)),
+               "pedp_feature_match")
+    return idx

@@ -488,19 +488,13 @@ __device__ void smallest_eigenvector(const double cov[9], double out[3]) {
 }
 
 constexpr int NRM_THREADS = 64;
-__global__ __launch_bounds__(NRM_THREADS) void normals_kernel(Grid g, const double *__restrict__ sp, int64_t N,
-                                                              const int *__restrict__ cell_start,
-                                                              const int *__restrict__ cell_end,
-                                                              const int *__restrict__ idx_sorted, double r2, int max_nn,
-                                                              const double *__restrict__ pts /* original order */,
-                                                              const double *__restrict__ prior, double *__restrict__ out) {
-    extern __shared__ double lds[];  // [max_nn][64] squared distances, then [max_nn][64] indices
-    double *top_d = lds;
-    int *top_j = (int *)(lds + (size_t)max_nn * NRM_THREADS);
-    const int t = threadIdx.x;
-    const int64_t j = (int64_t)blockIdx.x * NRM_THREADS + t;
-    if (j >= N) return;
-    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+// KDTreeSearchParamHybrid(radius, max_nn): the max_nn nearest of the points closer than the radius
+// (strictly, like nanoflann's radius search), sorted by (d^2, original index), kept per thread in LDS
+// columns top_d / top_j [rank][64].  Returns how many there are.
+__device__ __forceinline__ int hybrid_collect(const Grid &g, const double *p, const double *__restrict__ sp,
+                                              const int *__restrict__ cell_start, const int *__restrict__ cell_end,
+                                              const int *__restrict__ idx_sorted, double r2, int max_nn, double *top_d, int *top_j,
+                                              int t) {
     int have = 0;
     for_neighbours(g, p, cell_start, cell_end, [&](int q) {
         const double d = dist2(p, sp + 3 * (size_t)q);
@@ -523,6 +517,23 @@ __global__ __launch_bounds__(NRM_THREADS) void normals_kernel(Grid g, const doub
         top_j[r * NRM_THREADS + t] = jq;
         if (have < max_nn) ++have;
     });
+    return have;
+}
+
+__global__ __launch_bounds__(NRM_THREADS) void normals_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                              const int *__restrict__ cell_start,
+                                                              const int *__restrict__ cell_end,
+                                                              const int *__restrict__ idx_sorted, double r2, int max_nn,
+                                                              const double *__restrict__ pts /* original order */,
+                                                              const double *__restrict__ prior, double *__restrict__ out) {
+    extern __shared__ double lds[];  // [max_nn][64] squared distances, then [max_nn][64] indices
+    double *top_d = lds;
+    int *top_j = (int *)(lds + (size_t)max_nn * NRM_THREADS);
+    const int t = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * NRM_THREADS + t;
+    if (j >= N) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    const int have = hybrid_collect(g, p, sp, cell_start, cell_end, idx_sorted, r2, max_nn, top_d, top_j, t);
     double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (have >= 3) {
         double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -547,6 +558,156 @@ __global__ __launch_bounds__(NRM_THREADS) void normals_kernel(Grid g, const doub
     }
     if (prior && dot3(n, prior + 3 * i) < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
     out[3 * i] = n[0]; out[3 * i + 1] = n[1]; out[3 * i + 2] = n[2];
+}
+
+// ------------------------------------------------------------------ FPFH (compute_fpfh_feature)
+// Open3D 0.18 Feature.cpp: per point the SPFH histogram (3 x 11 bins of the Darboux-frame angles to
+// the hybrid-search neighbours, the point itself skipped), then FPFH = own SPFH + the neighbours'
+// SPFH weighted by 1 / squared distance, each third rescaled to 100.  Neighbour lists are written
+// once ([rank][N], nearest first, ties by index) and read by both passes.
+__global__ __launch_bounds__(NRM_THREADS) void hybrid_list_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                  const int *__restrict__ cell_start,
+                                                                  const int *__restrict__ cell_end,
+                                                                  const int *__restrict__ idx_sorted, double r2, int max_nn,
+                                                                  int *__restrict__ nbr_j, double *__restrict__ nbr_d,
+                                                                  int *__restrict__ nbr_n) {
+    extern __shared__ double lds[];
+    double *top_d = lds;
+    int *top_j = (int *)(lds + (size_t)max_nn * NRM_THREADS);
+    const int t = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * NRM_THREADS + t;
+    if (j >= N) return;
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    const int have = hybrid_collect(g, p, sp, cell_start, cell_end, idx_sorted, r2, max_nn, top_d, top_j, t);
+    const int64_t i = idx_sorted[j];
+    nbr_n[i] = have;
+    for (int k = 0; k < have; ++k) {
+        nbr_j[(size_t)k * N + i] = top_j[k * NRM_THREADS + t];
+        nbr_d[(size_t)k * N + i] = top_d[k * NRM_THREADS + t];
+    }
+}
+
+// Feature.cpp ComputePairFeatures, operation for operation (oracle/features.c pair_features)
+__device__ __forceinline__ void pair_features_dev(const double *p1, const double *n1, const double *p2, const double *n2,
+                                                  double r[4]) {
+    double dp[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    r[0] = r[1] = r[2] = 0.0;
+    r[3] = sqrt(dot3(dp, dp));
+    if (r[3] == 0.0) return;
+    double a[3] = {n1[0], n1[1], n1[2]}, b[3] = {n2[0], n2[1], n2[2]};
+    const double angle1 = dot3(a, dp) / r[3], angle2 = dot3(b, dp) / r[3];
+    if (acos(fabs(angle1)) > acos(fabs(angle2))) {
+        for (int k = 0; k < 3; ++k) { a[k] = n2[k]; b[k] = n1[k]; dp[k] = -dp[k]; }
+        r[2] = -angle2;
+    } else {
+        r[2] = angle1;
+    }
+    double v[3], w[3];
+    cross3(dp, a, v);
+    const double vn = sqrt(dot3(v, v));
+    if (vn == 0.0) { r[0] = r[1] = r[2] = r[3] = 0.0; return; }
+    for (int k = 0; k < 3; ++k) v[k] /= vn;
+    cross3(a, v, w);
+    r[1] = dot3(v, b);
+    r[0] = atan2(dot3(w, b), dot3(a, b));
+}
+
+__device__ __forceinline__ int bin11(double x) {
+    int h = (int)floor(x);
+    return h < 0 ? 0 : (h >= 11 ? 10 : h);
+}
+
+__global__ __launch_bounds__(NRM_THREADS) void spfh_kernel(const double *__restrict__ pts, const double *__restrict__ nrm,
+                                                           int64_t N, const int *__restrict__ nbr_j,
+                                                           const int *__restrict__ nbr_n, double *__restrict__ spfh) {
+    __shared__ double hist[33][NRM_THREADS];
+    const int t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * NRM_THREADS + t;
+    if (i >= N) return;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) hist[k][t] = 0.0;
+    const int n = nbr_n[i];
+    if (n > 1) {
+        const double incr = 100.0 / (double)(n - 1);
+        const double p1[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, n1[3] = {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]};
+        for (int k = 1; k < n; ++k) {
+            const size_t q = (size_t)nbr_j[(size_t)k * N + i];
+            double pf[4];
+            pair_features_dev(p1, n1, pts + 3 * q, nrm + 3 * q, pf);
+            hist[bin11(11.0 * (pf[0] + 3.14159265358979323846) / (2.0 * 3.14159265358979323846))][t] += incr;
+            hist[11 + bin11(11.0 * (pf[1] + 1.0) * 0.5)][t] += incr;
+            hist[22 + bin11(11.0 * (pf[2] + 1.0) * 0.5)][t] += incr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 33; ++k) spfh[33 * i + k] = hist[k][t];
+}
+
+__global__ __launch_bounds__(NRM_THREADS) void fpfh_kernel(int64_t N, const int *__restrict__ nbr_j, const double *__restrict__ nbr_d,
+                                                           const int *__restrict__ nbr_n, const double *__restrict__ spfh,
+                                                           double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * NRM_THREADS + threadIdx.x;
+    if (i >= N) return;
+    double f[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) f[k] = 0.0;
+    const int n = nbr_n[i];
+    if (n > 1) {
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (int k = 1; k < n; ++k) {
+            const double dist = nbr_d[(size_t)k * N + i];
+            if (dist == 0.0) continue;
+            const double *h = spfh + 33 * (size_t)nbr_j[(size_t)k * N + i];
+#pragma unroll
+            for (int j = 0; j < 33; ++j) {
+                const double val = h[j] / dist;
+                sum[j / 11] += val;
+                f[j] += val;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+#pragma unroll
+        for (int j = 0; j < 33; ++j) {
+            f[j] *= sum[j / 11];
+            f[j] += spfh[33 * i + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 33; ++j) out[33 * i + j] = f[j];
+}
+
+// nearest target feature of every source feature: squared L2 over the 33 components summed in order
+// (float64, as KDTreeFlann::SearchKNN on the Feature matrix), ties to the lower index.  A workgroup
+// holds 64 source features in registers (one per thread) and streams the target features through LDS.
+constexpr int FM_TILE = 64;
+__global__ __launch_bounds__(64) void feature_match_kernel(const double *__restrict__ fs, int64_t Ns, const double *__restrict__ ft,
+                                                           int64_t Nt, int32_t *__restrict__ idx) {
+    __shared__ double tile[FM_TILE][33];
+    const int t = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + t;
+    double a[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) a[k] = i < Ns ? fs[33 * i + k] : 0.0;
+    double best = __longlong_as_double(0x7FF0000000000000ll);
+    int bj = -1;
+    for (int64_t j0 = 0; j0 < Nt; j0 += FM_TILE) {
+        const int m = (int)(Nt - j0 < FM_TILE ? Nt - j0 : FM_TILE);
+        __syncthreads();
+        for (int e = t; e < m * 33; e += 64) tile[e / 33][e % 33] = ft[33 * j0 + e];
+        __syncthreads();
+        for (int jj = 0; jj < m; ++jj) {
+            double d = 0.0;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) {
+                const double e = a[k] - tile[jj][k];
+                d += e * e;
+            }
+            if (d < best) { best = d; bj = (int)(j0 + jj); }
+        }
+    }
+    if (i < Ns) idx[i] = bj;
 }
 
 // ------------------------------------------------------------------ plane RANSAC
@@ -915,6 +1076,79 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
                        sp, N, cell_start, cell_end, val_s, radius * radius, max_nn, d_pts, prior ? d_prior : nullptr, d_out);
     PEDP_HIP_CHECK(hipGetLastError());
     { int dn_ = pedp_download(c, normals, d_out, sizeof(double) * 3 * (size_t)N); if (dn_) return dn_; }
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double radius, int max_nn, double *out) {
+    int rc = check_cloud(c, pts, N, "pedp_fpfh");
+    if (rc) return rc;
+    PEDP_REQUIRE(radius > 0.0 && std::isfinite(radius), "pedp_fpfh: radius must be positive and finite");
+    PEDP_REQUIRE(max_nn >= 1 && max_nn <= 128, "pedp_fpfh: max_nn must be in 1..128");
+    if (N == 0) return PEDP_OK;
+    PEDP_REQUIRE(normals && out, "pedp_fpfh: null normals / output (FPFH needs the cloud's normals)");
+    PEDP_REQUIRE(N * (int64_t)max_nn < (int64_t)1 << 31, "pedp_fpfh: neighbour table too large");
+    double lo[3], hi[3];
+    bounds(pts, N, lo, hi);
+    Grid g;
+    int64_t n_cells = 0;
+    rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_fpfh");
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
+                                           (int *)nullptr, n, 0, 32, c->stream));
+    const size_t need = a256(sizeof(double) * 3 * N) * 3 + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 3 +
+                        a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + a256(sizeof(int) * (size_t)N * max_nn) +
+                        a256(sizeof(double) * (size_t)N * max_nn) + a256(sizeof(double) * 33 * N) * 2 + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_nrm = cv.take<double>(3 * (size_t)N);
+    unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N), *nbr_n = cv.take<int>(N);
+    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
+    void *d_tmp = cv.take<char>(tmp_sort);
+    int *nbr_j = cv.take<int>((size_t)N * max_nn);
+    double *nbr_d = cv.take<double>((size_t)N * max_nn);
+    double *spfh = cv.take<double>(33 * (size_t)N), *d_out = cv.take<double>(33 * (size_t)N);
+    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256), grid64 = (unsigned)((N + NRM_THREADS - 1) / NRM_THREADS);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
+    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
+    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)hybrid_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hybrid_list_kernel, dim3(grid64), dim3(NRM_THREADS), lds, c->stream, g, sp, N, cell_start, cell_end, val_s,
+                       radius * radius, max_nn, nbr_j, nbr_d, nbr_n);
+    hipLaunchKernelGGL(spfh_kernel, dim3(grid64), dim3(NRM_THREADS), 0, c->stream, d_pts, d_nrm, N, nbr_j, nbr_n, spfh);
+    hipLaunchKernelGGL(fpfh_kernel, dim3(grid64), dim3(NRM_THREADS), 0, c->stream, N, nbr_j, nbr_d, nbr_n, spfh, d_out);
+    PEDP_HIP_CHECK(hipGetLastError());
+    { int dn_ = pedp_download(c, out, d_out, sizeof(double) * 33 * (size_t)N); if (dn_) return dn_; }
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_feature_match(pedp_ctx_t c, const double *fs, int64_t Ns, const double *ft, int64_t Nt, int32_t *idx) {
+    PEDP_REQUIRE(c, "pedp_feature_match: null context");
+    PEDP_REQUIRE(Ns >= 0 && Nt >= 0 && Ns < (int64_t)1 << 31 && Nt < (int64_t)1 << 31, "pedp_feature_match: sizes out of range");
+    if (Ns == 0) return PEDP_OK;
+    PEDP_REQUIRE(fs && idx && (ft || Nt == 0), "pedp_feature_match: null arrays");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    int st = c->ops.reserve(a256(sizeof(double) * 33 * Ns) + a256(sizeof(double) * 33 * (Nt > 0 ? Nt : 1)) + a256(sizeof(int32_t) * Ns) + 1024);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_fs = cv.take<double>(33 * (size_t)Ns), *d_ft = cv.take<double>(33 * (size_t)(Nt > 0 ? Nt : 1));
+    int32_t *d_idx = cv.take<int32_t>(Ns);
+    { int up_ = pedp_upload(c, d_fs, fs, sizeof(double) * 33 * (size_t)Ns); if (up_) return up_; }
+    if (Nt > 0) { int up_ = pedp_upload(c, d_ft, ft, sizeof(double) * 33 * (size_t)Nt); if (up_) return up_; }
+    hipLaunchKernelGGL(feature_match_kernel, dim3((unsigned)((Ns + 63) / 64)), dim3(64), 0, c->stream, d_fs, Ns, d_ft, Nt, d_idx);
+    PEDP_HIP_CHECK(hipGetLastError());
+    { int dn_ = pedp_download(c, idx, d_idx, sizeof(int32_t) * (size_t)Ns); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }

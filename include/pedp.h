@@ -187,6 +187,17 @@ int pedp_knn_mean_distance(pedp_ctx_t ctx, const double *pts, int64_t N, int k, 
  * N x 3): existing normals; the result is flipped to agree with them, as Open3D does. */
 int pedp_estimate_normals(pedp_ctx_t ctx, const double *pts, int64_t N, double radius, int max_nn, const double *prior,
                           double *normals);
+
+/* o3d.pipelines.registration.compute_fpfh_feature(cloud, KDTreeSearchParamHybrid(radius, max_nn))
+ * (src/pose_estimation.py:132-137, :175-180, :255-260): out = N x 33 float64 (row i = column i of
+ * Open3D's Feature.data).  The cloud's normals are required.  Restated from the published
+ * open3d==0.18.0 Feature.cpp (parity unpinned); max_nn <= 128. */
+int pedp_fpfh(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N, double radius, int max_nn, double *out);
+
+/* The correspondences of registration_ransac_based_on_feature_matching (src/pose_estimation.py:482-501):
+ * idx[i] = the target feature nearest to source feature i (squared L2 over the 33 components in
+ * float64, ties to the lower index; -1 when there is no target). */
+int pedp_feature_match(pedp_ctx_t ctx, const double *fs, int64_t Ns, const double *ft, int64_t Nt, int32_t *idx);
 /* segment_plane with ransac_n = 3 (:323-329).  Iteration t samples three distinct indices from a
  * counter-based generator of (seed, t); plane through them; inliers |n.p + d| < threshold; the best
  * iteration has the most inliers (earliest on ties); all iterations are evaluated (Open3D:

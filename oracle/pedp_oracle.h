@@ -99,6 +99,15 @@ void pedp_oracle_smallest_eigenvector(const double cov[9], double out[3]);
 void pedp_oracle_estimate_normals(const double *pts, int64_t N, double radius, int max_nn, const double *prior,
                                   double *out);
 
+/* feature-based global registration (features.c): src/pose_estimation.py:132-137, :467-503 */
+void pedp_oracle_fpfh(const double *pts, const double *nrm, int64_t N, double radius, int max_nn, double *out);
+void pedp_oracle_feature_match(const double *fs, int64_t Ns, const double *ft, int64_t Nt, int32_t *idx);
+int pedp_oracle_ransac_hypothesis(uint64_t seed, int64_t itr, const double *src, const double *src_nrm, int64_t Ns,
+                                  const double *tgt, const double *tgt_nrm, const int32_t *corr, double edge,
+                                  double dist, double angle, double T[16]);
+double pedp_oracle_corres_inlier_ratio(const double *src, int64_t Ns, const double *tgt, const int32_t *corr,
+                                       const double T[16], double max_dist);
+
 /* depth pre-filters (depth.c): Utils.py:304-442 */
 void pedp_oracle_erode_depth(const float *depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                              float zfar, float *out, int nthreads);

@@ -237,6 +237,48 @@ def estimate_normals(points, radius, max_nn, prior=None):
     return out
 
 
+def fpfh(points, normals, radius, max_nn):
+    """N x 33 FPFH features (the transpose of Open3D's Feature.data)."""
+    p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    n = np.ascontiguousarray(normals, np.float64).reshape(-1, 3)
+    out = np.empty((len(p), 33), np.float64)
+    lib().pedp_oracle_fpfh(_p(p), _p(n), C.c_int64(len(p)), C.c_double(radius), C.c_int(max_nn), _p(out))
+    return out
+
+
+def feature_match(fs, ft):
+    fs = np.ascontiguousarray(fs, np.float64).reshape(-1, 33)
+    ft = np.ascontiguousarray(ft, np.float64).reshape(-1, 33)
+    idx = np.empty(len(fs), np.int32)
+    lib().pedp_oracle_feature_match(_p(fs), C.c_int64(len(fs)), _p(ft), C.c_int64(len(ft)), _p(idx))
+    return idx
+
+
+def ransac_hypothesis(seed, itr, src, src_nrm, tgt, tgt_nrm, corr, edge, dist, angle):
+    """(accepted, T) of RANSAC draw `itr`."""
+    s = np.ascontiguousarray(src, np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(tgt, np.float64).reshape(-1, 3)
+    sn = None if src_nrm is None else np.ascontiguousarray(src_nrm, np.float64).reshape(-1, 3)
+    tn = None if tgt_nrm is None else np.ascontiguousarray(tgt_nrm, np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(corr, np.int32)
+    T = np.empty(16, np.float64)
+    fn = lib().pedp_oracle_ransac_hypothesis
+    fn.restype = C.c_int
+    ok = fn(C.c_uint64(seed), C.c_int64(itr), _p(s), _p(sn), C.c_int64(len(s)), _p(t), _p(tn), _p(c), C.c_double(edge),
+            C.c_double(dist), C.c_double(angle), _p(T))
+    return bool(ok), T.reshape(4, 4)
+
+
+def corres_inlier_ratio(src, tgt, corr, T, max_dist):
+    s = np.ascontiguousarray(src, np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(tgt, np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(corr, np.int32)
+    Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+    fn = lib().pedp_oracle_corres_inlier_ratio
+    fn.restype = C.c_double
+    return fn(_p(s), C.c_int64(len(s)), _p(t), _p(c), _p(Tm), C.c_double(max_dist))
+
+
 def smallest_eigenvector(cov):
     c = np.ascontiguousarray(cov, np.float64).reshape(9)
     out = np.zeros(3)

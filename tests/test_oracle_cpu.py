@@ -415,3 +415,112 @@ def test_cloud_ops_golden_and_independent_statements(oracle):
         w, V = np.linalg.eigh(np.cov(pts[jj].T, bias=True))
         if w[1] - w[0] > 1e-6 * w[2]:
             assert abs(abs(est[i] @ V[:, 0]) - 1) < 1e-6
+
+
+# ---------------------------------------------------------------- FPFH / feature matching (features.c)
+
+def _fpfh_numpy(pts, nrm, radius, max_nn):
+    """Independent restatement of Open3D's ComputeFPFHFeature (vector form, numpy's acos / arctan2)."""
+    n = len(pts)
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    lists = []
+    for i in range(n):
+        cand = np.flatnonzero(d2[i] < radius * radius)
+        cand = cand[np.lexsort((cand, d2[i, cand]))][:max_nn]
+        lists.append(cand)
+    spfh = np.zeros((n, 33))
+    for i, cand in enumerate(lists):
+        if len(cand) <= 1:
+            continue
+        incr = 100.0 / (len(cand) - 1)
+        for j in cand[1:]:
+            dp = pts[j] - pts[i]
+            dist = np.sqrt(dp @ dp)
+            f = np.zeros(3)
+            if dist != 0.0:
+                a, b = nrm[i], nrm[j]
+                a1, a2 = a @ dp / dist, b @ dp / dist
+                if np.arccos(abs(a1)) > np.arccos(abs(a2)):
+                    a, b, dp, f[2] = nrm[j], nrm[i], -dp, -a2
+                else:
+                    f[2] = a1
+                v = np.cross(dp, a)
+                vn = np.sqrt(v @ v)
+                if vn == 0.0:
+                    f[:] = 0.0
+                else:
+                    v = v / vn
+                    w = np.cross(a, v)
+                    f[1] = v @ b
+                    f[0] = np.arctan2(w @ b, a @ b)
+            for k, x in enumerate((11 * (f[0] + np.pi) / (2 * np.pi), 11 * (f[1] + 1) * 0.5, 11 * (f[2] + 1) * 0.5)):
+                spfh[i, 11 * k + min(max(int(np.floor(x)), 0), 10)] += incr
+    out = np.zeros((n, 33))
+    for i, cand in enumerate(lists):
+        if len(cand) <= 1:
+            continue
+        s = np.zeros(3)
+        for j in cand[1:]:
+            if d2[i, j] == 0.0:
+                continue
+            val = spfh[j] / d2[i, j]
+            out[i] += val
+            s += val.reshape(3, 11).sum(1)
+        s = np.where(s != 0.0, 100.0 / np.where(s != 0.0, s, 1.0), 0.0)
+        out[i] = out[i] * np.repeat(s, 11) + spfh[i]
+    return out
+
+
+def test_fpfh_against_numpy_restatement_and_invariants(oracle):
+    rng = np.random.default_rng(4)
+    pts = rng.normal(0, 3.0, (90, 3)) * [1.0, 1.0, 0.15]          # a thick sheet
+    pts[7] = pts[3]                                               # a duplicated point: zero distance is skipped
+    nrm = rng.normal(size=pts.shape) * [0.3, 0.3, 1.0]
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for radius, max_nn in ((2.5, 100), (2.5, 6), (0.4, 100)):
+        got = oracle.fpfh(pts, nrm, radius, max_nn)
+        ref = _fpfh_numpy(pts, nrm, radius, max_nn)
+        assert got.shape == (90, 33)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-9)
+        thirds = got.reshape(90, 3, 11).sum(2)
+        lonely = (thirds == 0).all(1)                             # no neighbour inside the radius: all zero
+        assert np.allclose(thirds[~lonely], 200.0) or max_nn == 6 or radius == 0.4
+        assert (got >= 0).all()
+    # rigid motion of cloud and normals leaves the features unchanged (up to rounding in the bins)
+    R = Rotation.from_euler("xyz", [0.3, -0.7, 1.1]).as_matrix()
+    a = oracle.fpfh(pts, nrm, 2.5, 100)
+    b = oracle.fpfh(pts @ R.T + [5.0, -2.0, 9.0], nrm @ R.T, 2.5, 100)
+    assert np.mean(np.abs(a - b) > 1e-6) < 0.02
+
+
+def test_feature_match_and_ransac_draw(oracle):
+    rng = np.random.default_rng(6)
+    ft = rng.uniform(0, 100, (400, 33))
+    fs = ft[rng.integers(0, 400, 150)] + rng.normal(0, 1e-3, (150, 33))
+    fs[10] = 0.5 * (ft[3] + ft[9])                                # equidistant from two targets: the lower index
+    idx = oracle.feature_match(fs, ft)
+    d = ((fs[:, None, :] - ft[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(idx, d.argmin(1)) or np.allclose(d[np.arange(150), idx], d.min(1), rtol=1e-12)
+    assert oracle.feature_match(fs, ft[:0]).tolist() == [-1] * 150
+    # a RANSAC draw: exact correspondences under a rigid motion pass every checker and recover the motion
+    src = rng.normal(0, 20, (300, 3))
+    sn = rng.normal(size=(300, 3)); sn /= np.linalg.norm(sn, axis=1, keepdims=True)
+    R = Rotation.from_euler("xyz", [0.4, 0.2, -0.9]).as_matrix()
+    t = np.array([3.0, -8.0, 12.0])
+    tgt, tn = src @ R.T + t, sn @ R.T
+    corr = np.arange(300, dtype=np.int32)
+    hits = 0
+    for itr in range(40):
+        ok, T = oracle.ransac_hypothesis(11, itr, src, sn, tgt, tn, corr, 0.9, 1.5, 0.5)
+        if ok:
+            hits += 1
+            assert np.allclose(T[:3, :3], R, atol=1e-7) and np.allclose(T[:3, 3], t, atol=1e-6)
+    assert hits >= 30                                            # (a draw with a repeated point may fail the fit)
+    assert oracle.ransac_hypothesis(11, 5, src, sn, tgt, tn, corr, 0.9, 1.5, 0.5)[1].tolist() == \
+        oracle.ransac_hypothesis(11, 5, src, sn, tgt, tn, corr, 0.9, 1.5, 0.5)[1].tolist()
+    wrong = corr.copy(); wrong[::2] = rng.permutation(300)[:150]   # half the correspondences scrambled
+    rejected = sum(not oracle.ransac_hypothesis(11, i, src, sn, tgt, tn, wrong, 0.9, 1.5, 0.5)[0] for i in range(200))
+    assert rejected > 120
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    assert oracle.corres_inlier_ratio(src, tgt, corr, T, 0.01) == 1.0
+    assert abs(oracle.corres_inlier_ratio(src, tgt, wrong, T, 0.01) - 0.5) < 0.02
