@@ -63,6 +63,8 @@ PROTOTYPES = {
     "pedp_cluster_dbscan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
     "pedp_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pedp_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "pedp_ransac_hypotheses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int,
+                                         C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "pedp_fpfh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
     "pedp_feature_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "pedp_segment_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_uint64, C.c_void_p,
@@ -324,6 +326,17 @@ def raycast_last_sweep_ms(ctx):
     ms = C.c_float(0)
     check(load().pedp_raycast_last_sweep_ms(ctx._h, C.byref(ms)), "pedp_raycast_last_sweep_ms")
     return ms.value
+
+
+def ransac_hypotheses(ctx, src, tgt, corr, seed, itr0, count, edge_similarity, max_distance, normal_angle):
+    """(accepted[count] bool, T[count, 4, 4]) of RANSAC draws itr0 .. itr0 + count - 1 (pedp_ransac_hypotheses)."""
+    c = np.ascontiguousarray(corr, np.int32)
+    ok = np.empty(int(count), np.uint8)
+    T = np.empty((int(count), 4, 4), np.float64)
+    check(load().pedp_ransac_hypotheses(ctx._h, src._h, tgt._h, _ptr(c), C.c_uint64(int(seed)), int(itr0), int(count),
+                                        float(edge_similarity), float(max_distance), float(normal_angle), _ptr(ok), _ptr(T)),
+          "pedp_ransac_hypotheses")
+    return ok.astype(bool), T
 
 
 def raycast_last_variant(ctx):

@@ -1741,6 +1741,93 @@ __global__ __launch_bounds__(256) void icp_solve_kernel(IcpState *__restrict__ s
     mat4_mul_dev(upd, st->T, st->T);
 }
 
+// ---- RANSAC draws of registration_ransac_based_on_feature_matching (src/pose_estimation.py:482-501)
+// One thread per iteration: three correspondences corres[rand()] (with replacement, Open3D's
+// Registration.cpp), Umeyama without scaling over the three pairs, then the reference's checkers in
+// its order: edge length, distance, normal.  The draw is a counter-based function of (seed,
+// iteration) -- Open3D's per-thread mt19937 engines seeded by random_device are not recoverable --
+// operation for operation oracle/features.c pedp_oracle_ransac_hypothesis.
+__device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ void kabsch3_dev(const double *S, const double *G, double *T) {  // oracle/icp.c pedp_oracle_kabsch, K = 3
+    ident4(T);
+    double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) { ms[k] += S[3 * i + k]; mt[k] += G[3 * i + k]; }
+    for (int k = 0; k < 3; ++k) { ms[k] /= 3.0; mt[k] /= 3.0; }
+    double sig[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) sig[3 * a + b] += (G[3 * i + a] - mt[a]) * (S[3 * i + b] - ms[b]);
+    for (int k = 0; k < 9; ++k) sig[k] /= 3.0;
+    double U[9], w[3], V[9];
+    svd3_dev(sig, U, w, V);
+    const double sgn = (det3_dev(U) * det3_dev(V) < 0.0) ? -1.0 : 1.0;
+    double R[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            R[3 * a + b] = U[3 * a + 0] * V[3 * b + 0] + U[3 * a + 1] * V[3 * b + 1] + sgn * U[3 * a + 2] * V[3 * b + 2];
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) T[4 * a + b] = R[3 * a + b];
+        T[4 * a + 3] = mt[a] - (R[3 * a] * ms[0] + R[3 * a + 1] * ms[1] + R[3 * a + 2] * ms[2]);
+    }
+}
+
+__device__ __forceinline__ double sqd3(const double *a, const double *b) {
+    const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+    return (x * x + y * y) + z * z;
+}
+
+__global__ __launch_bounds__(64) void ransac_hypothesis_kernel(unsigned long long seed, long long itr0, int count,
+                                                               const double *__restrict__ src, const double *__restrict__ src_nrm,
+                                                               long long Ns, const double *__restrict__ tgt,
+                                                               const double *__restrict__ tgt_nrm, const int32_t *__restrict__ corr,
+                                                               double edge, double dist, double cos_thr,
+                                                               unsigned char *__restrict__ flags, double *__restrict__ Ts) {
+    const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= count) return;
+    unsigned long long s = splitmix64_dev(seed ^ splitmix64_dev((unsigned long long)(itr0 + k0)));
+    long long pick[3];
+    double S[9], G[9];
+    for (int k = 0; k < 3; ++k) {
+        s = splitmix64_dev(s);
+        pick[k] = (long long)(s % (unsigned long long)Ns);
+        for (int a = 0; a < 3; ++a) {
+            S[3 * k + a] = src[3 * pick[k] + a];
+            G[3 * k + a] = tgt[3 * (long long)corr[pick[k]] + a];
+        }
+    }
+    double T[16];
+    kabsch3_dev(S, G, T);
+    bool ok = true;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j) {
+            const double ds = sqrt(sqd3(S + 3 * i, S + 3 * j)), dt = sqrt(sqd3(G + 3 * i, G + 3 * j));
+            if (ds < dt * edge || dt < ds * edge) ok = false;
+        }
+    for (int k = 0; k < 3 && ok; ++k) {
+        double p[3];
+        for (int a = 0; a < 3; ++a)
+            p[a] = ((T[4 * a] * S[3 * k] + T[4 * a + 1] * S[3 * k + 1]) + T[4 * a + 2] * S[3 * k + 2]) + T[4 * a + 3];
+        if (sqrt(sqd3(p, G + 3 * k)) > dist) ok = false;
+    }
+    if (ok && src_nrm && tgt_nrm) {
+        for (int k = 0; k < 3; ++k) {
+            const double *n = src_nrm + 3 * pick[k], *m = tgt_nrm + 3 * (long long)corr[pick[k]];
+            double rn[3];
+            for (int a = 0; a < 3; ++a) rn[a] = (T[4 * a] * n[0] + T[4 * a + 1] * n[1]) + T[4 * a + 2] * n[2];
+            if ((rn[0] * m[0] + rn[1] * m[1]) + rn[2] * m[2] < cos_thr) ok = false;
+        }
+    }
+    flags[k0] = ok ? 1 : 0;
+    for (int k = 0; k < 16; ++k) Ts[16 * (size_t)k0 + k] = T[k];
+}
+
 // ---- fused pass, third launch
 // The same pivoted LDLT as solve6_ldlt (and oracle/icp.c), operation for operation, with the
 // matrix in registers: every index is a compile-time constant after unrolling and the pivot
@@ -2911,6 +2998,38 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     if (rc) return rc;
     { int dn_ = pedp_download(c, idx, w.idx, sizeof(int32_t) * (size_t)source->N); if (dn_) return dn_; }
     { int dn_ = pedp_download(c, d2, w.d2, sizeof(double) * (size_t)source->N); if (dn_) return dn_; }
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
+
+int pedp_ransac_hypotheses(pedp_ctx_t c, pedp_cloud_t src, pedp_cloud_t tgt, const int32_t *corr, uint64_t seed, int64_t itr0,
+                           int count, double edge_similarity, double max_distance, double normal_angle, uint8_t *accepted,
+                           double *T) {
+    PEDP_REQUIRE(c && src && tgt, "pedp_ransac_hypotheses: null context / cloud");
+    PEDP_REQUIRE(src->ctx == c && tgt->ctx == c, "pedp_ransac_hypotheses: clouds belong to another context");
+    PEDP_REQUIRE(count >= 0 && count <= (1 << 22) && itr0 >= 0, "pedp_ransac_hypotheses: count must be in 0..2^22");
+    if (count == 0) return PEDP_OK;
+    PEDP_REQUIRE(corr && accepted && T, "pedp_ransac_hypotheses: null arrays");
+    PEDP_REQUIRE(src->N > 0 && tgt->N > 0, "pedp_ransac_hypotheses: empty cloud");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const size_t sz_corr = align_up(sizeof(int32_t) * (size_t)src->N, 256), sz_flag = align_up((size_t)count, 256);
+    int st = c->ops.reserve(sz_corr + sz_flag + sizeof(double) * 16 * (size_t)count + 256);
+    if (st) return st;
+    int32_t *d_corr = (int32_t *)c->ops.ptr;
+    unsigned char *d_flag = (unsigned char *)c->ops.ptr + sz_corr;
+    double *d_T = (double *)((char *)c->ops.ptr + sz_corr + sz_flag);
+    // correspondences must point inside the target (checked on the host: they index device memory)
+    for (int64_t i = 0; i < src->N; ++i)
+        PEDP_REQUIRE(corr[i] >= 0 && corr[i] < tgt->N, "pedp_ransac_hypotheses: correspondence %lld -> %d outside the target",
+                     (long long)i, (int)corr[i]);
+    { int up_ = pedp_upload(c, d_corr, corr, sizeof(int32_t) * (size_t)src->N); if (up_) return up_; }
+    hipLaunchKernelGGL(ransac_hypothesis_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream,
+                       (unsigned long long)seed, (long long)itr0, count, (const double *)src->pts, (const double *)src->normals,
+                       (long long)src->N, (const double *)tgt->pts, (const double *)tgt->normals, (const int32_t *)d_corr,
+                       edge_similarity, max_distance, cos(normal_angle), d_flag, d_T);
+    PEDP_HIP_CHECK(hipGetLastError());
+    { int dn_ = pedp_download(c, accepted, d_flag, (size_t)count); if (dn_) return dn_; }
+    { int dn_ = pedp_download(c, T, d_T, sizeof(double) * 16 * (size_t)count); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }

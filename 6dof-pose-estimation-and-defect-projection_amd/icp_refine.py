@@ -10,6 +10,9 @@ registration_icp call running on the GPU through libpedp_hip.so.
     preprocess_target            :141-183   (random subsample to max_pcd; keeps normals)
     preprocess_source            :186-268   (voxel grid, table plane, DBSCAN, outlier filter and
                                              normals on the GPU through pedp_hip.cloud_ops)
+    execute_global_registration  :467-503   (FPFH + RANSAC global registration on the GPU)
+    run_icp                      :524-545
+    determine_pose               :686-747   (icp=False: the FoundationPose chain; icp=True: run_icp)
 
 Units are millimetres, transformations are 4x4 float64; `*.transformation` of a result maps
 scene -> model, exactly like the reference's RegistrationResult.
@@ -55,8 +58,9 @@ def preprocess_target(pcd, param):
     (np.random.choice(..., replace=False), pose_estimation.py:159-169), then re-estimate its normals
     like the reference (:174; radius 2, max_nn 5 -- a model sampled more coarsely than ~1 unit gets
     (0, 0, 1) everywhere, in Open3D too).  `"keep_normals": True` in the preprocess_target section
-    (not a reference key) keeps the model's own normals instead.  FPFH features (:175-179) are only
-    read by the global-registration path: the slot is None."""
+    (not a reference key) keeps the model's own normals instead.  FPFH features (:175-179) are computed
+    when the section names `fpfh_radius` / `fpfh_max_nn` (the reference's configuration always does; only
+    the global-registration path reads them), else the slot is None."""
     section = param["preprocess_target"]
     cap = section["max_pcd"]
     pts, nrm = points_of(pcd), normals_of(pcd)
@@ -83,7 +87,15 @@ def preprocess_target(pcd, param):
                 out = holder
         else:
             estimate_normals(out, section)
-    return out, None
+    return out, fpfh_of(out, section)
+
+
+def fpfh_of(pcd, section):
+    """compute_fpfh_feature with the section's hybrid search (pose_estimation.py:175-180, :255-260); None when the
+    section does not ask for features."""
+    if pcd is None or "fpfh_radius" not in section:
+        return None
+    return reg.compute_fpfh_feature(pcd, KDTreeSearchParamHybrid(radius=section["fpfh_radius"], max_nn=section["fpfh_max_nn"]))
 
 
 def perform_plane_segmentation(pcd, param):
@@ -178,11 +190,13 @@ def preprocess_source(pcd, background, param, i=0):
         raise NotImplementedError("preprocess_source: param['mesh'] (Poisson re-meshing) is not part of this build")
     source_processed = filter_largest_cluster(source_processed)
     source_processed = remove_statistical_outliers(source_processed, nb_neighbors=75, std_ratio=0.01)
+    source_fpfh = 0
     if i == 0:
         if background is not None:
             estimate_normals(background, params)
         estimate_normals(source_processed, params)
-    return source_processed, source_processed, (None if i == 0 else 0)
+        source_fpfh = fpfh_of(source_processed, params)
+    return source_processed, source_processed, source_fpfh
 
 
 def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, max_adjustment=50,
@@ -347,12 +361,64 @@ def refine_pose_with_icp(source, target, background, initial_fp_transformation, 
     return target_transformed, best, z_adjustment, target_processed
 
 
+def execute_global_registration(source_processed, target_processed, source_fpfh, target_fpfh, param):
+    """RANSAC on feature matches with the reference's three checkers (pose_estimation.py:467-503)."""
+    params = param["execute_global_registration"]
+    return reg.registration_ransac_based_on_feature_matching(
+        source_processed, target_processed, source_fpfh, target_fpfh, False, params["distance_threshold"],
+        reg.TransformationEstimationPointToPoint(False), 3,
+        [reg.CorrespondenceCheckerBasedOnEdgeLength(params["correspondence_checkers"][0]["value"]),
+         reg.CorrespondenceCheckerBasedOnDistance(params["distance_threshold"]),
+         reg.CorrespondenceCheckerBasedOnNormal(params["angle_threshold"])],
+        reg.RANSACConvergenceCriteria(params["ransac_criteria"]["iterations"], params["ransac_criteria"]["confidence"]))
+
+
+def run_icp(source_processed, target_processed, source_fpfh, target_fpfh, param):
+    """Global registration, then one point-to-plane refinement from it (pose_estimation.py:524-545).
+    Returns (result_icp, result_ransac)."""
+    result_ransac = execute_global_registration(source_processed, target_processed, source_fpfh, target_fpfh, param)
+    result_icp = refine_registration(source_processed, target_processed, result_ransac.transformation, param)
+    return result_icp, result_ransac
+
+
+MAX_GLOBAL_ATTEMPTS = 1000   # the reference loops without a bound (pose_estimation.py:702-710)
+
+
 def determine_pose(source, target, background, initial_fp_transformation, parameters, icp=False):
-    """pose_estimation.py:686-747.  With icp=False (the only form run.py's callers use) this is
-    the same chain as refine_pose_with_icp: preprocess, z search, in-place z adjustment,
-    improve_result.  icp=True starts from run_icp's FPFH + RANSAC global registration
-    (pose_estimation.py:411-503), which is outside the hot path and not provided."""
-    if icp:
-        raise NotImplementedError("determine_pose(icp=True): global registration (run_icp, FPFH + RANSAC) is not part "
-                                  "of this build; pass the FoundationPose estimate with icp=False")
-    return refine_pose_with_icp(source, target, background, initial_fp_transformation, parameters)
+    """pose_estimation.py:686-747.  icp=False (what run.py's callers use) is the chain of
+    refine_pose_with_icp: preprocess, z search, in-place z adjustment, improve_result.  icp=True starts
+    from run_icp -- FPFH features, RANSAC global registration, one refinement -- repeated until the
+    refined result meets run_icp's fitness / rmse thresholds (:698-710; the reference repeats without a
+    bound, here MAX_GLOBAL_ATTEMPTS attempts raise), then inverts the transformation (:711) and hands it
+    to improve_result like the other branch.  Returns (model moved into the scene, result, z adjustment,
+    preprocessed target)."""
+    if not icp:
+        return refine_pose_with_icp(source, target, background, initial_fp_transformation, parameters)
+    param = copy.deepcopy(parameters)
+    if hasattr(source, "paint_uniform_color"):
+        source.paint_uniform_color([1, 0, 0])
+    if hasattr(target, "paint_uniform_color"):
+        target.paint_uniform_color([0, 0, 1])
+    target_processed, target_fpfh = preprocess_target(target, param)
+    source_processed, _, source_fpfh = preprocess_source(source, background, param)
+    if target_fpfh is None or source_fpfh is None:
+        raise KeyError("determine_pose(icp=True): the preprocess_target / preprocess_source sections need fpfh_radius and fpfh_max_nn")
+    result_icp, result_ransac = run_icp(source_processed, target_processed, source_fpfh, target_fpfh, param)
+    logging.info(f"-- Initial Attempt\n:: Global registeration results: Inlier_rmse: {result_ransac.inlier_rmse:.4f}, "
+                 f"Fitness: {result_ransac.fitness:.4f}\n:: Refine registeration results: Inlier_rmse: "
+                 f"{result_icp.inlier_rmse:.4f}, Fitness: {result_icp.fitness:.4f}")
+    attempts = 1
+    while result_icp.fitness < param["run_icp"]["fitness_threshold"] or result_icp.inlier_rmse > param["run_icp"]["rmse_threshold"]:
+        if attempts >= MAX_GLOBAL_ATTEMPTS:
+            raise RuntimeError(f"determine_pose(icp=True): {attempts} global registrations did not reach the run_icp thresholds")
+        result_icp, result_ransac = run_icp(source_processed, target_processed, source_fpfh, target_fpfh, param)
+        logging.info(f"-- Attempt {attempts}\n:: Global registeration results: Inlier_rmse: {result_ransac.inlier_rmse:.4f}, "
+                     f"Fitness: {result_ransac.fitness:.4f}\n:: Refine registeration results: Inlier_rmse: "
+                     f"{result_icp.inlier_rmse:.4f}, Fitness: {result_icp.fitness:.4f}")
+        attempts += 1
+    result_icp.transformation = np.linalg.inv(result_icp.transformation)
+    best = improve_result(source_processed, target_processed, result_icp, param)
+    model_in_scene = np.linalg.inv(best.transformation)
+    logging.info(f"-- Final Results\n:: Refine registration results: Inlier_rmse: {best.inlier_rmse:.4f}, "
+                 f"Fitness: {best.fitness:.4f}\n:: Final Transformation Matrix:\n{model_in_scene}")
+    return transform_object(target, model_in_scene), best, 0, target_processed

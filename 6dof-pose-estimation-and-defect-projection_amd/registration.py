@@ -5,6 +5,11 @@ Reference call sites (src/pose_estimation.py):
                                TransformationEstimationPointToPlane())
     :654-660  ... same with ICPConvergenceCriteria(max_iteration=1)
     :584      o3d.geometry.get_rotation_matrix_from_xyz([a, b, c])
+    :132-137  compute_fpfh_feature(cloud, KDTreeSearchParamHybrid(radius, max_nn))
+    :482-501  registration_ransac_based_on_feature_matching(source, target, source_fpfh, target_fpfh, False,
+                  distance_threshold, TransformationEstimationPointToPoint(False), 3,
+                  [CorrespondenceCheckerBasedOnEdgeLength, ...BasedOnDistance, ...BasedOnNormal],
+                  RANSACConvergenceCriteria(iterations, confidence))
 Names, argument order and defaults are Open3D 0.18's; errors are RuntimeError like
 Open3D's (a target without normals under point-to-plane).
 """
@@ -111,3 +116,143 @@ def registration_icp_batch(source, target, radii, inits, estimation_method=None,
         res.fitness, res.inlier_rmse, res.iterations = float(fit[b]), float(rmse[b]), int(its[b])
         out.append(res)
     return out
+
+
+# ---------------------------------------------------------------- feature-based global registration
+
+class Feature:
+    """o3d.pipelines.registration.Feature: `data` is dimension x N (33 x N for FPFH), like Open3D's."""
+
+    def __init__(self, rows=None):
+        self._rows = np.zeros((0, 33)) if rows is None else np.ascontiguousarray(rows, np.float64)
+
+    @property
+    def data(self):
+        return self._rows.T
+
+    def dimension(self):
+        return self._rows.shape[1]
+
+    def num(self):
+        return self._rows.shape[0]
+
+
+def compute_fpfh_feature(input, search_param, ctx=None):
+    """FPFH features of a cloud with normals (pose_estimation.py:132-137, :175-180, :255-260)."""
+    from . import cloud_ops
+
+    if normals_of(input) is None or len(normals_of(input)) != len(points_of(input)):
+        raise RuntimeError("compute_fpfh_feature: the cloud has no normals")
+    return Feature(cloud_ops.compute_fpfh(points_of(input), normals_of(input), search_param.radius, search_param.max_nn, ctx=ctx))
+
+
+class CorrespondenceCheckerBasedOnEdgeLength:
+    def __init__(self, similarity_threshold=0.9):
+        self.similarity_threshold = float(similarity_threshold)
+
+
+class CorrespondenceCheckerBasedOnDistance:
+    def __init__(self, distance_threshold):
+        self.distance_threshold = float(distance_threshold)
+
+
+class CorrespondenceCheckerBasedOnNormal:
+    def __init__(self, normal_angle_threshold):
+        self.normal_angle_threshold = float(normal_angle_threshold)
+
+
+class RANSACConvergenceCriteria:
+    def __init__(self, max_iteration=100000, confidence=0.999):
+        self.max_iteration, self.confidence = int(max_iteration), float(confidence)
+
+
+_ransac_seed = [None]
+RANSAC_CHUNK = 16384      # draws generated per launch
+RANSAC_BATCH = 32         # accepted draws validated at once (they share the launches of pedp_icp_batched)
+
+
+def set_ransac_seed(seed):
+    """Seed of the RANSAC draws (o3d.utility.random.seed): the first call after this uses `seed`, the next
+    `seed + 1`, ... (every registration draws afresh, a seeded program repeats); None: taken from numpy's
+    global RNG per call."""
+    _ransac_seed[0] = None if seed is None else int(seed)
+
+
+def registration_ransac_based_on_feature_matching(source, target, source_feature, target_feature, mutual_filter,
+                                                  max_correspondence_distance, estimation_method=None, ransac_n=3,
+                                                  checkers=(), criteria=None, ctx=None):
+    """RANSAC over nearest-feature correspondences (Open3D 0.18 Registration.cpp, restated; pose_estimation.py:482-501).
+
+    Every source point is paired with the target point whose feature is nearest.  An iteration draws
+    ransac_n = 3 pairs, fits Umeyama without scaling and applies the checkers; a draw that passes is
+    VALIDATED like one ICP correspondence pass (fitness = share of the transformed source within
+    max_correspondence_distance of its nearest target point, inlier rmse); the best validated draw
+    wins (fitness, then rmse) and tightens the iteration budget:
+    k = log(1 - confidence) / log(1 - ratio^3), ratio = share of the PAIRS that are inliers under it.
+    Open3D walks the iterations under OpenMP with random_device-seeded engines; here they are taken
+    in order (the single-thread semantics), the draws are a counter-based function of (seed,
+    iteration), generated RANSAC_CHUNK at a time on the GPU, and the accepted ones are validated
+    RANSAC_BATCH at a time (results used in order, those behind a tightened budget dropped)."""
+    from . import cloud_ops
+
+    est = estimation_method if estimation_method is not None else TransformationEstimationPointToPoint()
+    if est.code != _lib.POINT_TO_POINT:
+        raise NotImplementedError("registration_ransac_based_on_feature_matching: the reference fits point to point")
+    if ransac_n != 3:
+        raise NotImplementedError("registration_ransac_based_on_feature_matching: ransac_n = 3 (the reference's)")
+    if mutual_filter:
+        raise NotImplementedError("registration_ransac_based_on_feature_matching: mutual_filter=False (the reference's)")
+    crit = criteria if criteria is not None else RANSACConvergenceCriteria()
+    best = RegistrationResult(np.eye(4))
+    best.fitness, best.inlier_rmse = 0.0, 0.0
+    n_src = len(points_of(source))
+    if max_correspondence_distance <= 0.0 or n_src < ransac_n or len(points_of(target)) == 0:
+        return best
+    ctx = ctx or _lib.default_context()
+    edge, dist, angle = 0.0, float("inf"), np.pi         # a missing checker never rejects
+    for ch in checkers:
+        if isinstance(ch, CorrespondenceCheckerBasedOnEdgeLength):
+            edge = ch.similarity_threshold
+        elif isinstance(ch, CorrespondenceCheckerBasedOnDistance):
+            dist = ch.distance_threshold
+        elif isinstance(ch, CorrespondenceCheckerBasedOnNormal):
+            angle = ch.normal_angle_threshold
+        else:
+            raise NotImplementedError(f"correspondence checker {type(ch).__name__} is not built")
+    corr = cloud_ops.match_features(source_feature.data.T, target_feature.data.T, ctx=ctx)
+    d_src, d_tgt = upload(source, ctx), upload(target, ctx)
+    src_pts, tgt_pts = points_of(source), points_of(target)
+    if _ransac_seed[0] is not None:
+        seed = _ransac_seed[0]
+        _ransac_seed[0] += 1
+    else:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    evaluate = ICPConvergenceCriteria(max_iteration=0)
+    budget, itr, validated = crit.max_iteration, 0, 0
+    while itr < budget:
+        count = min(RANSAC_CHUNK, budget - itr)
+        ok, T = _lib.ransac_hypotheses(ctx, d_src, d_tgt, corr, seed, itr, count, edge, dist, angle)
+        passed = np.flatnonzero(ok)
+        for b0 in range(0, len(passed), RANSAC_BATCH):
+            batch = passed[b0:b0 + RANSAC_BATCH]
+            batch = batch[itr + batch < budget]
+            if len(batch) == 0:
+                break
+            results = registration_icp_batch(d_src, d_tgt, [max_correspondence_distance] * len(batch), T[batch], est, evaluate)
+            for k, res in zip(batch, results):
+                if itr + k >= budget:
+                    break
+                validated += 1
+                if res.fitness > best.fitness or (res.fitness == best.fitness and res.inlier_rmse < best.inlier_rmse):
+                    best = res
+                    moved = src_pts @ T[k][:3, :3].T + T[k][:3, 3]
+                    ratio = float(np.mean(((moved - tgt_pts[corr]) ** 2).sum(1) < max_correspondence_distance ** 2))
+                    if 0.0 < ratio < 1.0 and crit.confidence < 1.0:
+                        k_est = np.log(1.0 - crit.confidence) / np.log(1.0 - ratio ** ransac_n)
+                        if k_est < budget:
+                            budget = int(np.ceil(k_est))
+                    elif ratio >= 1.0:
+                        budget = min(budget, itr + int(k) + 1)
+        itr += count
+    best.validated_draws = validated
+    return best

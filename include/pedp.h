@@ -279,6 +279,19 @@ int pedp_nn(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const doub
  * directly around the kernel): the sweep of pedp_nn, or of the pass selected by pedp_icp_configure. */
 int pedp_nn_last_sweep_ms(pedp_ctx_t ctx, float *ms);
 
+/* RANSAC draws of registration_ransac_based_on_feature_matching (src/pose_estimation.py:482-501,
+ * ransac_n = 3): iteration itr0 + k, k = 0 .. count-1, takes three correspondences
+ * (corr[i] = target point of source point i, e.g. from pedp_feature_match) with replacement, fits
+ * Umeyama without scaling and applies the reference's three checkers in its order
+ * (CorrespondenceCheckerBasedOnEdgeLength(edge_similarity), ...BasedOnDistance(max_distance),
+ * ...BasedOnNormal(normal_angle, radians; skipped when a cloud has no normals)).  accepted[k] = 1 when
+ * all pass; T[16 k ..] = the fitted source -> target transformation either way.  The draw is a
+ * counter-based function of (seed, iteration) (Open3D's random_device-seeded engines are not
+ * recoverable); count <= 2^22 per call. */
+int pedp_ransac_hypotheses(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const int32_t *corr, uint64_t seed,
+                           int64_t itr0, int count, double edge_similarity, double max_distance, double normal_angle,
+                           uint8_t *accepted, double *T);
+
 /* Measurement knobs of pedp_icp / pedp_icp_batched on this context.
  *   exhaustive = 1: no culling -- every scene point stays a candidate and the MFMA kernel sweeps
  *     every (scene point, target point) pair in every pass (the all-pairs workload of SURVEY s8d);

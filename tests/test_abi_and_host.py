@@ -268,14 +268,14 @@ def test_refine_pose_with_icp_mutations_and_return_shape(engine):
     assert np.allclose(moved.points, np.asarray(tgt.points) @ np.linalg.inv(best.transformation)[:3, :3].T
                        + np.linalg.inv(best.transformation)[:3, 3])
     assert params["refine_registration"]["distance_threshold"] == 8.0
-    # determine_pose(icp=False) is the same chain (pose_estimation.py:686-747); icp=True is not built
+    # determine_pose(icp=False) is the same chain (pose_estimation.py:686-747)
     from pedp_hip.compat import determine_pose
 
     init2 = before.copy()
     np.random.seed(1)
     _, best2, z2, _ = determine_pose(src, tgt, None, init2, params)
     assert z2 == z and np.array_equal(best2.transformation, best.transformation)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError, match="fpfh_radius"):      # icp=True needs the feature sections (tests/test_features_gpu.py runs it)
         determine_pose(src, tgt, None, init2, params, icp=True)
 
 

@@ -64,3 +64,146 @@ def test_feature_match_bit_exact(ctx, oracle):
     assert cloud_ops.match_features(fs[:0], ft, ctx=ctx).shape == (0,)
     assert cloud_ops.match_features(fs[:5], ft[:0], ctx=ctx).tolist() == [-1] * 5
     assert np.array_equal(cloud_ops.match_features(fs[:65], ft[:1], ctx=ctx), np.zeros(65, np.int32))
+
+
+def _pair(n_src, n_tgt, seed, noise=0.05):
+    """A target surface with normals and a source = part of the same surface in another pose."""
+    from scipy.spatial.transform import Rotation
+
+    tp, tn = _surface(n_tgt, seed)
+    rng = np.random.default_rng(seed + 100)
+    keep = np.flatnonzero(tp[:, 2] > -6.0)                        # the camera sees the upper part
+    keep = rng.choice(keep, min(n_src, len(keep)), replace=False)
+    R = Rotation.from_euler("xyz", [0.5, -0.3, 0.8]).as_matrix()
+    t = np.array([25.0, -40.0, 320.0])
+    sp = (tp[keep] + rng.normal(0, noise, (len(keep), 3))) @ R.T + t      # model -> scene
+    sn = tn[keep] @ R.T
+    T_scene_to_model = np.eye(4)
+    T_scene_to_model[:3, :3], T_scene_to_model[:3, 3] = R.T, -R.T @ t
+    return sp, sn, tp, tn, T_scene_to_model
+
+
+def test_ransac_draws_match_oracle(ctx, oracle):
+    from pedp_hip import _lib
+
+    sp, sn, tp, tn, _ = _pair(700, 2000, seed=5)
+    rng = np.random.default_rng(0)
+    fs, ft = oracle.fpfh(sp, sn, 9.0, 100), oracle.fpfh(tp, tn, 9.0, 100)
+    corr = oracle.feature_match(fs, ft)
+    d_src, d_tgt = _lib.Cloud(ctx, sp, sn), _lib.Cloud(ctx, tp, tn)
+    for with_normals in (True, False):
+        a, b = (d_src, d_tgt) if with_normals else (_lib.Cloud(ctx, sp, None), _lib.Cloud(ctx, tp, None))
+        ok, T = _lib.ransac_hypotheses(ctx, a, b, corr, 99, 1000, 3000, 0.9, 4.0, 0.6)
+        assert 0 < ok.sum() < 3000
+        for k in list(range(0, 3000, 37)) + list(np.flatnonzero(ok)[:60]):
+            ok_ref, T_ref = oracle.ransac_hypothesis(99, 1000 + k, sp, sn if with_normals else None, tp,
+                                                     tn if with_normals else None, corr, 0.9, 4.0, 0.6)
+            assert bool(ok[k]) == ok_ref, k
+            assert np.allclose(T[k], T_ref, rtol=0, atol=1e-9 * (1 + np.abs(T_ref).max())), k
+    with pytest.raises(_lib.PedpError, match="outside the target"):
+        bad = corr.copy(); bad[3] = len(tp)
+        _lib.ransac_hypotheses(ctx, d_src, d_tgt, bad, 1, 0, 10, 0.9, 4.0, 0.6)
+    assert _lib.ransac_hypotheses(ctx, d_src, d_tgt, corr, 1, 0, 0, 0.9, 4.0, 0.6)[0].shape == (0,)
+    del rng
+
+
+def _oracle_global_registration(oracle, sp, sn, tp, tn, fs, ft, max_dist, edge, angle, iters, conf, seed):
+    """The sequential statement of registration_ransac_based_on_feature_matching on the oracle's pieces."""
+    corr = oracle.feature_match(fs, ft)
+    best = (0.0, 0.0, np.eye(4))
+    budget, itr = iters, 0
+    while itr < budget:
+        ok, T = oracle.ransac_hypothesis(seed, itr, sp, sn, tp, tn, corr, edge, max_dist, angle)
+        if ok:
+            ev = oracle.icp(sp, tp, None, max_dist, T, estimator=oracle.P2POINT, max_iter=0, want_trace=False)
+            if ev["fitness"] > best[0] or (ev["fitness"] == best[0] and ev["inlier_rmse"] < best[1]):
+                best = (ev["fitness"], ev["inlier_rmse"], T)
+                ratio = oracle.corres_inlier_ratio(sp, tp, corr, T, max_dist)
+                if 0.0 < ratio < 1.0 and conf < 1.0:
+                    k_est = np.log(1.0 - conf) / np.log(1.0 - ratio ** 3)
+                    if k_est < budget:
+                        budget = int(np.ceil(k_est))
+                elif ratio >= 1.0:
+                    budget = min(budget, itr + 1)
+        itr += 1
+    return best
+
+
+def test_global_registration_flow_matches_oracle_and_finds_the_pose(ctx, oracle):
+    from pedp_hip import compat
+    from pedp_hip import registration as reg
+
+    sp, sn, tp, tn, T_true = _pair(600, 1800, seed=8)
+    src, tgt = compat.PointCloud(sp, normals=sn), compat.PointCloud(tp, normals=tn)
+    search = compat.KDTreeSearchParamHybrid(radius=10.0, max_nn=100)
+    fs, ft = compat.compute_fpfh_feature(src, search, ctx=ctx), compat.compute_fpfh_feature(tgt, search, ctx=ctx)
+    assert fs.data.shape == (33, len(sp)) and fs.dimension() == 33 and ft.num() == len(tp)
+    checkers = [compat.CorrespondenceCheckerBasedOnEdgeLength(0.9), compat.CorrespondenceCheckerBasedOnDistance(3.0),
+                compat.CorrespondenceCheckerBasedOnNormal(0.5)]
+    reg.set_ransac_seed(1234)
+    try:
+        res = compat.registration_ransac_based_on_feature_matching(
+            src, tgt, fs, ft, False, 3.0, compat.TransformationEstimationPointToPoint(False), 3, checkers,
+            compat.RANSACConvergenceCriteria(20000, 0.999), ctx=ctx)
+        reg.set_ransac_seed(1234)
+        again = compat.registration_ransac_based_on_feature_matching(
+            src, tgt, fs, ft, False, 3.0, compat.TransformationEstimationPointToPoint(False), 3, checkers,
+            compat.RANSACConvergenceCriteria(20000, 0.999), ctx=ctx)
+    finally:
+        reg.set_ransac_seed(None)
+    assert np.array_equal(res.transformation, again.transformation) and res.fitness == again.fitness   # a seeded run repeats
+    fit, rmse, T = _oracle_global_registration(oracle, sp, sn, tp, tn, fs.data.T, ft.data.T, 3.0, 0.9, 0.5, 20000, 0.999, 1234)
+    assert res.fitness == fit and abs(res.inlier_rmse - rmse) < 1e-9 and np.allclose(res.transformation, T, atol=1e-8)
+    # and it is the pose: the bulk of the scene lands on the model, close to the truth
+    assert res.fitness > 0.8
+    err = res.transformation @ np.linalg.inv(T_true)
+    assert np.abs(err[:3, 3]).max() < 3.0 and np.abs(err[:3, :3] - np.eye(3)).max() < 0.08
+    assert 0 < res.validated_draws < 20000
+    # degenerate calls give the empty result like Open3D
+    none = compat.registration_ransac_based_on_feature_matching(src, tgt, fs, ft, False, 0.0)
+    assert none.fitness == 0.0 and np.array_equal(none.transformation, np.eye(4))
+
+
+def test_determine_pose_with_global_registration(ctx, oracle):
+    """determine_pose(icp=True) (pose_estimation.py:686-747) on a raw scene (object in front of a back
+    plane) WITHOUT any start pose: preprocess with FPFH features in both sections, RANSAC global
+    registration, one refinement, repeated until run_icp's thresholds hold, then the randomised
+    restarts -- the model lands on the object.  (The scene cloud carries normals towards the camera:
+    estimate_normals keeps the side of normals that are already there, so the re-estimated scene normals
+    face outwards like the model's.)"""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+
+    from pedp_hip import registration as reg
+    from pedp_hip.compat import PointCloud, determine_pose
+
+    rng = np.random.default_rng(12)
+    mp, mn = _surface(26000, seed=21)                               # the model, ~1 point per mm^2
+    R = Rotation.from_euler("xyz", [0.4, 2.9, -0.7]).as_matrix()
+    t = np.array([12.0, -9.0, 350.0])
+    op, on = mp @ R.T + t, mn @ R.T                                 # the object in the camera frame
+    seen = np.einsum("ij,ij->i", on, -op / np.linalg.norm(op, axis=1, keepdims=True)) > 0.25
+    gx, gy = np.meshgrid(np.arange(-110.0, 110.0, 1.0), np.arange(-90.0, 90.0, 1.0))
+    plane = np.column_stack([gx.ravel(), gy.ravel(), np.full(gx.size, 420.0)])
+    scene = np.vstack([op[seen], plane]) + rng.normal(0, 0.05, (int(seen.sum()) + len(plane), 3))
+    scene = scene[rng.permutation(len(scene))]
+    src = PointCloud(scene, normals=-scene / np.linalg.norm(scene, axis=1, keepdims=True))
+    tgt = PointCloud(mp, normals=mn)
+    params = {"preprocess_target": {"max_pcd": 100000, "keep_normals": True, "fpfh_radius": 8.0, "fpfh_max_nn": 100},
+              "preprocess_source": {"down_sample": 1, "plane_removal": {"distance_threshold": 1.0, "num_iterations": 300},
+                                    "fpfh_radius": 8.0, "fpfh_max_nn": 100},
+              "box": False, "mesh": False,
+              "execute_global_registration": {"distance_threshold": 2.0, "correspondence_checkers": [{"value": 0.9}],
+                                              "angle_threshold": 0.6, "ransac_criteria": {"iterations": 100000, "confidence": 0.999}},
+              "refine_registration": {"distance_threshold": 3.0}, "run_icp": {"fitness_threshold": 0.95, "rmse_threshold": 1.0}}
+    np.random.seed(3)
+    reg.set_ransac_seed(77)
+    try:
+        moved, best, z, tgt_proc = determine_pose(src, tgt, None, None, params, icp=True)
+    finally:
+        reg.set_ransac_seed(None)
+    assert z == 0 and tgt_proc is tgt and len(moved.points) == len(mp)
+    assert best.fitness >= 0.95 and best.inlier_rmse <= 1.0
+    d, _ = cKDTree(np.asarray(moved.points)).query(op[seen])
+    assert np.percentile(d, 95) < 1.5
+    assert np.abs(np.linalg.inv(best.transformation)[:3, 3] - t).max() < 2.0
