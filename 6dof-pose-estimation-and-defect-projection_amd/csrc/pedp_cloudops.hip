@@ -587,6 +587,90 @@ __global__ __launch_bounds__(NRM_THREADS) void hybrid_list_kernel(Grid g, const 
     }
 }
 
+// The same lists, one WAVE per query: the 64 lanes fetch a cell's points together, the candidates
+// closer than the radius are packed into LDS (ballot + prefix count), and the max_nn nearest are
+// extracted one by one with a wave-wide lexicographic argmin over (d^2, original index) -- the order
+// of hybrid_collect -- every lane keeping the minimum of its strided share.  A query with more
+// candidates than the LDS share raises `overflow`; the host then tries the larger share and, past that,
+// the thread-per-query kernel.
+// WCAP candidates per query wave (12 B each), WPB query waves per workgroup: <1024, 4> = 48 KB (three
+// workgroups per CU) first, <4096, 2> = 96 KB for clouds with denser neighbourhoods
+template <int HYB_WCAP, int HYB_WPB>
+__global__ __launch_bounds__(HYB_WPB * 64) void hybrid_list_wave_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                       const int *__restrict__ cell_start,
+                                                                       const int *__restrict__ cell_end,
+                                                                       const int *__restrict__ idx_sorted, double r2, int max_nn,
+                                                                       int *__restrict__ nbr_j, double *__restrict__ nbr_d,
+                                                                       int *__restrict__ nbr_n, int *__restrict__ overflow) {
+    __shared__ double cd_all[HYB_WPB][HYB_WCAP];
+    __shared__ int cj_all[HYB_WPB][HYB_WCAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * HYB_WPB + wave;
+    if (j >= N) return;  // wave-uniform
+    double *cd = cd_all[wave];
+    int *cj = cj_all[wave];
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
+    int n_c = 0;
+    bool over = false;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dim[2] - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1); ++y)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1); ++x) {
+                const int c = x + g.dim[0] * (y + g.dim[1] * z);
+                const int e = cell_end[c];
+                for (int q0 = cell_start[c]; q0 < e; q0 += 64) {  // wave-uniform bounds
+                    const int q = q0 + lane;
+                    double d = 0.0;
+                    bool in = false;
+                    if (q < e) { d = dist2(p, sp + 3 * (size_t)q); in = d < r2; }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                    const int at = n_c + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (in && at < HYB_WCAP) { cd[at] = d; cj[at] = idx_sorted[q]; }
+                    n_c += __builtin_popcountll(m);
+                    over |= n_c > HYB_WCAP;
+                }
+            }
+    if (over) {  // wave-uniform
+        if (lane == 0) atomicOr(overflow, 1);
+        return;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double lmin = inf;
+    int lj = 0x7FFFFFFF, lidx = -1;
+    for (int q = lane; q < n_c; q += 64) {
+        const double d = cd[q];
+        const int jq = cj[q];
+        if (d < lmin || (d == lmin && jq < lj)) { lmin = d; lj = jq; lidx = q; }
+    }
+    const int have = n_c < max_nn ? n_c : max_nn;
+    const int64_t i = idx_sorted[j];
+    for (int r = 0; r < have; ++r) {
+        double v = lmin;
+        int vj = lj, owner = lane;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int oj = __shfl_xor(vj, off, 64), oo = __shfl_xor(owner, off, 64);
+            if (ov < v || (ov == v && oj < vj)) { v = ov; vj = oj; owner = oo; }
+        }
+        if (lane == owner) {  // hand the entry over and find the share's next minimum
+            nbr_j[(size_t)r * N + i] = vj;
+            nbr_d[(size_t)r * N + i] = v;
+            cd[lidx] = inf;
+            cj[lidx] = 0x7FFFFFFF;
+            lmin = inf; lj = 0x7FFFFFFF; lidx = -1;
+            for (int q = lane; q < n_c; q += 64) {
+                const double d = cd[q];
+                const int jq = cj[q];
+                if (d < lmin || (d == lmin && jq < lj)) { lmin = d; lj = jq; lidx = q; }
+            }
+        }
+    }
+    if (lane == 0) nbr_n[i] = have;
+}
+
 // Feature.cpp ComputePairFeatures, operation for operation (oracle/features.c pair_features)
 __device__ __forceinline__ void pair_features_dev(const double *p1, const double *n1, const double *p2, const double *n2,
                                                   double r[4]) {
@@ -679,21 +763,25 @@ __global__ __launch_bounds__(NRM_THREADS) void fpfh_kernel(int64_t N, const int 
 }
 
 // nearest target feature of every source feature: squared L2 over the 33 components summed in order
-// (float64, as KDTreeFlann::SearchKNN on the Feature matrix), ties to the lower index.  A workgroup
-// holds 64 source features in registers (one per thread) and streams the target features through LDS.
+// (float64, as KDTreeFlann::SearchKNN on the Feature matrix), ties to the lower index.  Grid = source
+// blocks x target chunks: a workgroup holds 64 source features in registers (one per thread), streams
+// its chunk of FM_CHUNK target features through LDS and leaves (d^2, index) per source and chunk; a
+// second kernel takes the minimum over the chunks in chunk order (strict <, so the lowest index wins a tie).
 constexpr int FM_TILE = 64;
+constexpr int FM_CHUNK = 1024;
 __global__ __launch_bounds__(64) void feature_match_kernel(const double *__restrict__ fs, int64_t Ns, const double *__restrict__ ft,
-                                                           int64_t Nt, int32_t *__restrict__ idx) {
+                                                           int64_t Nt, double *__restrict__ part_d, int32_t *__restrict__ part_j) {
     __shared__ double tile[FM_TILE][33];
     const int t = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 64 + t;
+    const int64_t c0 = (int64_t)blockIdx.y * FM_CHUNK, c1 = c0 + FM_CHUNK < Nt ? c0 + FM_CHUNK : Nt;
     double a[33];
 #pragma unroll
     for (int k = 0; k < 33; ++k) a[k] = i < Ns ? fs[33 * i + k] : 0.0;
     double best = __longlong_as_double(0x7FF0000000000000ll);
     int bj = -1;
-    for (int64_t j0 = 0; j0 < Nt; j0 += FM_TILE) {
-        const int m = (int)(Nt - j0 < FM_TILE ? Nt - j0 : FM_TILE);
+    for (int64_t j0 = c0; j0 < c1; j0 += FM_TILE) {
+        const int m = (int)(c1 - j0 < FM_TILE ? c1 - j0 : FM_TILE);
         __syncthreads();
         for (int e = t; e < m * 33; e += 64) tile[e / 33][e % 33] = ft[33 * j0 + e];
         __syncthreads();
@@ -707,7 +795,23 @@ __global__ __launch_bounds__(64) void feature_match_kernel(const double *__restr
             if (d < best) { best = d; bj = (int)(j0 + jj); }
         }
     }
-    if (i < Ns) idx[i] = bj;
+    if (i < Ns) {
+        part_d[(size_t)blockIdx.y * Ns + i] = best;
+        part_j[(size_t)blockIdx.y * Ns + i] = bj;
+    }
+}
+
+__global__ void feature_match_fold_kernel(int64_t Ns, int n_chunks, const double *__restrict__ part_d,
+                                          const int32_t *__restrict__ part_j, int32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ns) return;
+    double best = __longlong_as_double(0x7FF0000000000000ll);
+    int bj = -1;
+    for (int c = 0; c < n_chunks; ++c) {
+        const double d = part_d[(size_t)c * Ns + i];
+        if (d < best) { best = d; bj = part_j[(size_t)c * Ns + i]; }
+    }
+    idx[i] = bj;
 }
 
 // ------------------------------------------------------------------ plane RANSAC
@@ -1101,7 +1205,7 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
                                            (int *)nullptr, n, 0, 32, c->stream));
     const size_t need = a256(sizeof(double) * 3 * N) * 3 + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 3 +
                         a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + a256(sizeof(int) * (size_t)N * max_nn) +
-                        a256(sizeof(double) * (size_t)N * max_nn) + a256(sizeof(double) * 33 * N) * 2 + 4096;
+                        a256(sizeof(double) * (size_t)N * max_nn) + a256(sizeof(double) * 33 * N) * 2 + 8192;
     int st = c->ops.reserve(need);
     if (st) return st;
     Carver cv{(char *)c->ops.ptr};
@@ -1121,10 +1225,28 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
     hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
     hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
-    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)hybrid_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hybrid_list_kernel, dim3(grid64), dim3(NRM_THREADS), lds, c->stream, g, sp, N, cell_start, cell_end, val_s,
-                       radius * radius, max_nn, nbr_j, nbr_d, nbr_n);
+    // a wave per query, 1,024 candidates each; a denser neighbourhood somewhere sends the cloud to the 4,096-candidate
+    // instantiation and, past that, to the thread-per-query kernel
+    int *d_over = cv.take<int>(64), h_over = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+        if (attempt == 0)
+            hipLaunchKernelGGL((hybrid_list_wave_kernel<1024, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, g, sp, N,
+                               cell_start, cell_end, val_s, radius * radius, max_nn, nbr_j, nbr_d, nbr_n, d_over);
+        else if (attempt == 1)
+            hipLaunchKernelGGL((hybrid_list_wave_kernel<4096, 2>), dim3((unsigned)((N + 1) / 2)), dim3(128), 0, c->stream, g, sp, N,
+                               cell_start, cell_end, val_s, radius * radius, max_nn, nbr_j, nbr_d, nbr_n, d_over);
+        else {
+            const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
+            PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)hybrid_list_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(hybrid_list_kernel, dim3(grid64), dim3(NRM_THREADS), lds, c->stream, g, sp, N, cell_start, cell_end,
+                               val_s, radius * radius, max_nn, nbr_j, nbr_d, nbr_n);
+        }
+        PEDP_HIP_CHECK(hipGetLastError());
+        PEDP_HIP_CHECK(hipMemcpyAsync(&h_over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!h_over) break;
+    }
     hipLaunchKernelGGL(spfh_kernel, dim3(grid64), dim3(NRM_THREADS), 0, c->stream, d_pts, d_nrm, N, nbr_j, nbr_n, spfh);
     hipLaunchKernelGGL(fpfh_kernel, dim3(grid64), dim3(NRM_THREADS), 0, c->stream, N, nbr_j, nbr_d, nbr_n, spfh, d_out);
     PEDP_HIP_CHECK(hipGetLastError());
@@ -1139,14 +1261,22 @@ int pedp_feature_match(pedp_ctx_t c, const double *fs, int64_t Ns, const double 
     if (Ns == 0) return PEDP_OK;
     PEDP_REQUIRE(fs && idx && (ft || Nt == 0), "pedp_feature_match: null arrays");
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    int st = c->ops.reserve(a256(sizeof(double) * 33 * Ns) + a256(sizeof(double) * 33 * (Nt > 0 ? Nt : 1)) + a256(sizeof(int32_t) * Ns) + 1024);
+    const int n_chunks = (int)((Nt + FM_CHUNK - 1) / FM_CHUNK > 0 ? (Nt + FM_CHUNK - 1) / FM_CHUNK : 1);
+    PEDP_REQUIRE(n_chunks <= 65535, "pedp_feature_match: more than 67 M target features");
+    int st = c->ops.reserve(a256(sizeof(double) * 33 * Ns) + a256(sizeof(double) * 33 * (Nt > 0 ? Nt : 1)) + a256(sizeof(int32_t) * Ns) +
+                            a256(sizeof(double) * (size_t)n_chunks * Ns) + a256(sizeof(int32_t) * (size_t)n_chunks * Ns) + 1024);
     if (st) return st;
     Carver cv{(char *)c->ops.ptr};
     double *d_fs = cv.take<double>(33 * (size_t)Ns), *d_ft = cv.take<double>(33 * (size_t)(Nt > 0 ? Nt : 1));
     int32_t *d_idx = cv.take<int32_t>(Ns);
+    double *part_d = cv.take<double>((size_t)n_chunks * Ns);
+    int32_t *part_j = cv.take<int32_t>((size_t)n_chunks * Ns);
     { int up_ = pedp_upload(c, d_fs, fs, sizeof(double) * 33 * (size_t)Ns); if (up_) return up_; }
     if (Nt > 0) { int up_ = pedp_upload(c, d_ft, ft, sizeof(double) * 33 * (size_t)Nt); if (up_) return up_; }
-    hipLaunchKernelGGL(feature_match_kernel, dim3((unsigned)((Ns + 63) / 64)), dim3(64), 0, c->stream, d_fs, Ns, d_ft, Nt, d_idx);
+    hipLaunchKernelGGL(feature_match_kernel, dim3((unsigned)((Ns + 63) / 64), (unsigned)n_chunks), dim3(64), 0, c->stream, d_fs, Ns,
+                       d_ft, Nt, part_d, part_j);
+    hipLaunchKernelGGL(feature_match_fold_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, c->stream, Ns, n_chunks,
+                       (const double *)part_d, (const int32_t *)part_j, d_idx);
     PEDP_HIP_CHECK(hipGetLastError());
     { int dn_ = pedp_download(c, idx, d_idx, sizeof(int32_t) * (size_t)Ns); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -45,6 +45,15 @@ def test_fpfh_edge_cases(ctx, oracle):
     for normals in (nrm, flat_n):
         got, ref = cloud_ops.compute_fpfh(pts, normals, 10.0, 50, ctx=ctx), oracle.fpfh(pts, normals, 10.0, 50)
         assert (np.abs(got - ref) > 1e-9 * (1 + np.abs(ref))).any(axis=1).mean() <= 0.01
+    # more than 1,024 / 4,096 points inside one query's radius: the wave kernel's larger instantiation, then the
+    # thread-per-query kernel, take the cloud
+    rng = np.random.default_rng(9)
+    for extra in (2300, 4400):
+        clump = np.vstack([pts, pts[7] + rng.normal(0, 0.4, (extra, 3))])
+        cn = np.vstack([nrm, rng.normal(size=(extra, 3))])
+        cn /= np.linalg.norm(cn, axis=1, keepdims=True)
+        got, ref = cloud_ops.compute_fpfh(clump, cn, 6.0, 100, ctx=ctx), oracle.fpfh(clump, cn, 6.0, 100)
+        assert (np.abs(got - ref) > 1e-9 * (1 + np.abs(ref))).any(axis=1).mean() <= 0.01
     assert cloud_ops.compute_fpfh(np.zeros((0, 3)), np.zeros((0, 3)), 1.0, 10, ctx=ctx).shape == (0, 33)
     with pytest.raises(_lib.PedpError, match="max_nn"):
         cloud_ops.compute_fpfh(pts, nrm, 1.0, 500, ctx=ctx)
