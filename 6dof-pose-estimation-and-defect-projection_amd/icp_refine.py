@@ -199,36 +199,76 @@ def preprocess_source(pcd, background, param, i=0):
     return source_processed, source_processed, source_fpfh
 
 
+Z_LOOKAHEAD = 3   # probes tried ahead per batch: 2^3 - 1 = 7 start poses share the launches of one
+
+
+def _z_move(offset, step, heading, better, max_adjustment):
+    """Where the line search goes after a probe that was / was not an improvement (pose_estimation.py:661-675):
+    keep walking, or turn round and halve; clamp to +-max_adjustment (step / 1.25, turn)."""
+    if not better:
+        heading = -heading
+        step = step / 2
+    offset += step * heading
+    if abs(offset) > max_adjustment:
+        offset = max_adjustment * np.sign(offset)
+        step = step / 1.25
+        heading = -heading
+    return offset, step, heading
+
+
 def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, max_adjustment=50,
                               initial_step=10):
     """Adaptive 1-D search for the camera-z offset that maximises ICP fitness
     (pose_estimation.py:624-683).  Each probe is a single-iteration point-to-plane ICP started
     from inv(T) with T[2,3] lowered by the probe offset.  Walk in the current direction while
     the probe improves (fitness, then lower rmse); otherwise turn round and halve the step;
-    clamp to +-max_adjustment (step / 1.25, turn); stop below 0.1 mm or above 0.95 fitness."""
+    clamp to +-max_adjustment (step / 1.25, turn); stop below 0.1 mm or above 0.95 fitness.
+
+    Where the search goes next depends only on WHETHER a probe improved, so the offsets of the next
+    Z_LOOKAHEAD probes are known for both answers: the 2^k - 1 candidate poses run as one batch and
+    the results are then taken along the path the real answers pick -- the same probes in the same
+    order with the same numbers as one by one (the rest are discarded)."""
     radius = param["refine_registration"]["distance_threshold"]
     d_src, d_tgt = reg.upload(source), reg.upload(target)  # one upload for all probes
     one_iteration = reg.ICPConvergenceCriteria(max_iteration=1)
     plane = reg.TransformationEstimationPointToPlane()
     best_adjustment, best_fitness, best_rmse = 0, 0, float("inf")
     offset, step, heading = 0, initial_step, 1
-    while abs(step) >= 0.1:
-        probe = np.copy(initial_fp_transformation)
-        probe[2, 3] -= offset
-        res = reg.registration_icp(d_src, d_tgt, radius, np.linalg.inv(probe), plane, one_iteration)
-        better = res.fitness > best_fitness or (res.fitness == best_fitness and res.inlier_rmse < best_rmse)
-        if better:
-            best_adjustment, best_fitness, best_rmse = offset, res.fitness, res.inlier_rmse
-        else:
-            heading = -heading
-            step = step / 2
-        offset += step * heading
-        if abs(offset) > max_adjustment:
-            offset = max_adjustment * np.sign(offset)
-            step = step / 1.25
-            heading = -heading
-        if best_fitness > 0.95:
-            break
+    done = False
+    while abs(step) >= 0.1 and not done:
+        # the tree of probes the next Z_LOOKAHEAD answers can lead to; node = (offset, step, heading)
+        nodes = {(): (offset, step, heading)}
+        frontier = [()]
+        for _ in range(Z_LOOKAHEAD - 1):
+            grown = []
+            for path in frontier:
+                for better in (True, False):
+                    nxt = _z_move(*nodes[path], better, max_adjustment)
+                    if abs(nxt[1]) >= 0.1:               # a path that has run out of step probes nothing more
+                        nodes[path + (better,)] = nxt
+                        grown.append(path + (better,))
+            frontier = grown
+        paths = list(nodes)
+        starts = []
+        for path in paths:
+            probe = np.copy(initial_fp_transformation)
+            probe[2, 3] -= nodes[path][0]
+            starts.append(np.linalg.inv(probe))
+        results = dict(zip(paths, reg.registration_icp_batch(d_src, d_tgt, [radius] * len(paths), starts, plane, one_iteration)))
+        path = ()
+        while path in results:
+            res = results[path]
+            offset, step, heading = nodes[path]
+            better = res.fitness > best_fitness or (res.fitness == best_fitness and res.inlier_rmse < best_rmse)
+            if better:
+                best_adjustment, best_fitness, best_rmse = offset, res.fitness, res.inlier_rmse
+            offset, step, heading = _z_move(offset, step, heading, better, max_adjustment)
+            if best_fitness > 0.95:
+                done = True
+                break
+            if abs(step) < 0.1:
+                break
+            path = path + (better,)
     logging.info(f":: Best z-axis adjustment: {best_adjustment:.2f}mm, Fitness: {best_fitness:.4f}, "
                  f"RMSE: {best_rmse:.4f}")
     return best_adjustment, best_fitness, best_rmse
