@@ -2774,6 +2774,7 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
     // convergence (Open3D's default criteria stop problems of this kind after 6-9 iterations)
     key.seg = no_exit ? all : (all < 10 ? all : 10);
     key.poses = G;
+    slot = 3 * slot + (key.seg == 1 ? 0 : (key.seg == 2 ? 1 : 2));  // a graph per group size and kind of stretch
     if (!(c->icp_bgraph[slot] && graph_key_equal(c->icp_bgraph_key[slot], key))) {
         if (c->icp_bgraph[slot]) { (void)hipGraphExecDestroy(c->icp_bgraph[slot]); c->icp_bgraph[slot] = nullptr; }
         hipGraph_t graph = nullptr;
@@ -3040,8 +3041,8 @@ int pedp_icp_configure(pedp_ctx_t c, int exhaustive, int timed_pass) {
     c->icp_timed_pass = timed_pass;
     for (int k = 0; k < PEDP_MAX_SUB; ++k)  // captured graphs bake the mode in
         if (c->sub[k] && c->sub[k]->icp_graph) { (void)hipGraphExecDestroy(c->sub[k]->icp_graph); c->sub[k]->icp_graph = nullptr; }
-    for (int k = 0; k < 6; ++k)
-        if (c->icp_bgraph[k]) { (void)hipGraphExecDestroy(c->icp_bgraph[k]); c->icp_bgraph[k] = nullptr; }
+    for (hipGraphExec_t &g : c->icp_bgraph)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     return PEDP_OK;
 }
 

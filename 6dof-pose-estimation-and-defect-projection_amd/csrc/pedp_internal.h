@@ -104,8 +104,10 @@ struct pedp_ctx_s {
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
     pedp_icp_graph_key icp_graph_key;
-    hipGraphExec_t icp_bgraph[6] = {};   // fused path: one graph per group size 1, 2, 4, ... 32 (poses share launches)
-    pedp_icp_graph_key icp_bgraph_key[6];
+    // fused path: one graph per group size 1, 2, 4, ... 32 (poses share launches) and per stretch of passes
+    // [0] one pass (evaluation), [1] two (single-iteration probes), [2] the rest -- a frame alternates between them
+    hipGraphExec_t icp_bgraph[18] = {};
+    pedp_icp_graph_key icp_bgraph_key[18];
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
     void *stage[2] = {nullptr, nullptr};  // pinned staging buffers of pedp_upload [0] / pedp_download [1], grown on demand
