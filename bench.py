@@ -326,7 +326,7 @@ def run(args):
             except OSError:
                 pass
         trace_us = None     # the same kernel in the committed rocprofv3 kernel trace of this command
-        for name in ("r02_bench_kernel_stats_v4.csv",):
+        for name in ("r02_bench_kernel_stats_v4.csv", "r02_bench_kernel_stats_v5.csv"):   # the newest one present wins
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in csv.DictReader(fh):
