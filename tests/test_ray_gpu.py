@@ -344,3 +344,45 @@ def test_grid_sweep_hands_over_what_it_cannot_answer(ctx, oracle):
     assert _lib.raycast_last_variant(own)[0] == 3
     _same(mesh.cast_rays(base[:18000]), oracle.raycast(f.verts_posed, f.tris, base[:18000]))   # another count: the grid again
     assert _lib.raycast_last_variant(own) == (4, 0)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_grid_sweep_fuzz_against_exhaustive(ctx, seed):
+    """Random triangle soups (sizes over four decades, slivers, a few triangles through or behind the
+    camera plane, some far larger than the view), random pinhole cameras: the triangle-driven sweep
+    (variant 4) against the exhaustive sweep (variant 1) of the same library, every bit of t / ids / uv."""
+    from pedp_hip import _lib
+
+    rng = np.random.default_rng(1000 + seed)
+    n_tri = int(rng.integers(3000, 30000))
+    centre = rng.normal(0, 1, 3) * [200.0, 200.0, 0.0] + [0.0, 0.0, rng.uniform(300, 900)]
+    c = centre + rng.normal(0, 1, (n_tri, 3)) * rng.uniform(30, 400)
+    size = 10.0 ** rng.uniform(-1.5, 2.5, n_tri)                     # 0.03 .. 300 mm edges
+    a = c + rng.normal(0, 1, (n_tri, 3)) * size[:, None]
+    b = c + rng.normal(0, 1, (n_tri, 3)) * size[:, None]
+    sl = rng.random(n_tri) < 0.05                                    # slivers: third corner almost on the first edge
+    b[sl] = c[sl] + (a[sl] - c[sl]) * rng.uniform(0.2, 0.8, (int(sl.sum()), 1)) + rng.normal(0, 1e-4, (int(sl.sum()), 3))
+    verts = np.stack([c, a, b], axis=1).reshape(-1, 3)
+    k = max(1, n_tri // 200)                                         # some triangles through / behind the camera plane
+    verts[: 3 * k] = rng.normal(0, 1, (3 * k, 3)) * [300.0, 300.0, 150.0]
+    tris = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+    w, h = int(rng.integers(120, 320)), int(rng.integers(90, 240))
+    fx = rng.uniform(0.6, 2.0) * w
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    d = np.stack([(u.ravel() - w / 2 + rng.uniform(-20, 20)) / fx, (v.ravel() - h / 2 + rng.uniform(-20, 20)) / fx, np.ones(w * h)], axis=1)
+    tilt = np.linalg.qr(rng.normal(size=(3, 3)))[0] if seed % 3 == 2 else np.eye(3)   # a camera looking anywhere
+    origin = rng.normal(0, 30, 3) if seed % 2 else np.zeros(3)
+    if seed % 3 == 2:
+        verts = verts @ tilt.T
+    rays = np.hstack([np.tile(origin, (w * h, 1)), d @ tilt.T]).astype(np.float32)
+    if seed % 4 == 3:
+        rays = rays[rng.permutation(len(rays))[: len(rays) // 2]]    # an unordered sub-set
+    mesh = _lib.Mesh(ctx, verts, tris)
+    _lib.raycast_configure(ctx, 0, 1)
+    try:
+        ref = mesh.cast_rays(rays)
+    finally:
+        _lib.raycast_configure(ctx, 0, 0)
+    got = _grid_cast(ctx, mesh, rays, 0)
+    assert np.isfinite(ref["t_hit"]).mean() > 0.05
+    _same(got, ref)
