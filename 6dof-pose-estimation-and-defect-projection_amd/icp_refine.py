@@ -48,7 +48,7 @@ def estimate_normals(pcd, params):
 
 def compute_average_normal(pcd):
     """pose_estimation.py:314-321: mean normal of the cloud on a 10-unit voxel grid, normalised."""
-    normals = np.asarray(clone(pcd).voxel_down_sample(voxel_size=10).normals)
+    normals = np.asarray(pcd.voxel_down_sample(voxel_size=10).normals)     # (voxel_down_sample leaves its input alone)
     average_normal = np.mean(normals, axis=0)
     return average_normal / np.linalg.norm(average_normal)
 
@@ -175,15 +175,21 @@ def preprocess_source(pcd, background, param, i=0):
         background = background.voxel_down_sample(voxel_size=params["down_sample"] * 2)
     pcd_down = pcd.voxel_down_sample(voxel_size=params["down_sample"])
     plane_model, inliers = perform_plane_segmentation(pcd_down, params["plane_removal"])
+    # Without param['box'] the half-space cut below is thrown away (the reference overwrites it, :232-236), and
+    # with it the only reader of the flipped plane and of the average normal -- apart from two log lines.
+    # They are worked out when something can see them: the box branch, or INFO logging.
+    box = bool(param.get("box"))
+    seen = box or logging.getLogger().isEnabledFor(logging.INFO)
     average_normal = np.array([1, 1, 1], dtype=float)
     if i == 0:
-        estimate_normals(pcd_down, params)
-        average_normal = compute_average_normal(pcd_down)
-        logging.info(f":: Average Normal for Source = {average_normal}")
-    plane_model, _ = flip_plane_normal_if_needed(plane_model, average_normal)
-    source_processed = remove_points_below_plane(pcd_down, plane_model)
-    if param.get("box"):
-        source_processed = background_removal(source_processed, background)
+        estimate_normals(pcd_down, params)      # (kept either way: these normals orient the final ones)
+        if seen:
+            average_normal = compute_average_normal(pcd_down)
+            logging.info(f":: Average Normal for Source = {average_normal}")
+    if seen:
+        plane_model, _ = flip_plane_normal_if_needed(plane_model, average_normal)
+    if box:
+        source_processed = background_removal(remove_points_below_plane(pcd_down, plane_model), background)
     else:
         source_processed = remove_plane(pcd_down, inliers)
     if param.get("mesh"):
