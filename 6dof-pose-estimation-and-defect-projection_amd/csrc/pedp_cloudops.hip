@@ -127,38 +127,75 @@ __device__ __forceinline__ void for_neighbours(const Grid &g, const double *p, c
 }
 
 // ------------------------------------------------------------------ DBSCAN
-__global__ void dbscan_core_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
-                                   const int *__restrict__ cell_end, double e2, int min_points,
-                                   const int *__restrict__ idx_sorted, int *__restrict__ core /* by original index */,
-                                   int *__restrict__ parent) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
-    int cnt = 0;
-    for_neighbours(g, p, cell_start, cell_end, [&](int q) { cnt += dist2(p, sp + 3 * (size_t)q) < e2; });
-    const int i = idx_sorted[j];
-    core[i] = cnt >= min_points;
-    parent[i] = i;
+// The two passes over a point's neighbourhood run a WAVE per point: the 64 lanes take the points of the 27
+// cells 64 at a time (a thread walking them alone is one long chain of dependent loads: 6.9 k points took
+// 117 us for the counts and 950 us for the unions).
+template <class F>
+__device__ __forceinline__ void for_neighbours_wave(const Grid &g, const double *p, const int *__restrict__ cell_start,
+                                                    const int *__restrict__ cell_end, int lane, F f) {
+    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dim[2] - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1); ++y)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1); ++x) {
+                const int c = x + g.dim[0] * (y + g.dim[1] * z);
+                const int e = cell_end[c];
+                for (int q0 = cell_start[c]; q0 < e; q0 += 64) f(q0 + lane, q0 + lane < e);  // wave-uniform trip count
+            }
 }
 
+constexpr int DB_WPB = 4;  // point waves per workgroup
+__global__ __launch_bounds__(DB_WPB * 64) void dbscan_core_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                 const int *__restrict__ cell_start,
+                                                                 const int *__restrict__ cell_end, double e2, int min_points,
+                                                                 const int *__restrict__ idx_sorted,
+                                                                 int *__restrict__ core /* by original index */,
+                                                                 int *__restrict__ parent) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * DB_WPB + (threadIdx.x >> 6);
+    if (j >= N) return;  // wave-uniform
+    const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
+    int cnt = 0;
+    for_neighbours_wave(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
+        const bool in = valid && dist2(p, sp + 3 * (size_t)q) < e2;
+        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+    });
+    if (lane == 0) {
+        const int i = idx_sorted[j];
+        core[i] = cnt >= min_points;
+        parent[i] = i;
+    }
+}
+
+// Find with path halving.  parent[x] <= x always points at a member of x's component, and only roots are
+// ever hooked (atomicCAS on parent[root] == root in the union loop), so overwriting a NON-root's parent with
+// its grandparent -- a plain store, whoever wins a race stores an ancestor -- keeps every invariant and the
+// component's smallest index as its root; without it the index-ordered hooking grows chains hundreds of
+// links long (6.9 k points: union kernel 950 us).
 __device__ __forceinline__ int uf_find(int *parent, int a) {
     int r = a;
     while (true) {
         const int p = ((volatile int *)parent)[r];
         if (p == r) return r;
+        const int gp = ((volatile int *)parent)[p];
+        if (gp != p) ((volatile int *)parent)[r] = gp;
         r = p;
     }
 }
 
-__global__ void dbscan_union_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
-                                    const int *__restrict__ cell_end, double e2, const int *__restrict__ idx_sorted,
-                                    const int *__restrict__ core, int *__restrict__ parent) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
+__global__ __launch_bounds__(DB_WPB * 64) void dbscan_union_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                  const int *__restrict__ cell_start,
+                                                                  const int *__restrict__ cell_end, double e2,
+                                                                  const int *__restrict__ idx_sorted, const int *__restrict__ core,
+                                                                  int *__restrict__ parent) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * DB_WPB + (threadIdx.x >> 6);
+    if (j >= N) return;  // wave-uniform
     const int i = idx_sorted[j];
-    if (!core[i]) return;
+    if (!core[i]) return;  // wave-uniform
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
-    for_neighbours(g, p, cell_start, cell_end, [&](int q) {
+    for_neighbours_wave(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
+        if (!valid) return;
         const int iq = idx_sorted[q];
         if (iq >= i || !core[iq] || !(dist2(p, sp + 3 * (size_t)q) < e2)) return;
         int a = i, b = iq;  // union: the larger root is hooked under the smaller one
@@ -1045,10 +1082,11 @@ int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, 
     hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell, cell_s, val, val_s, n, 0, 32, c->stream));
     hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, min_points,
-                       val_s, core, parent);
-    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, core,
-                       parent);
+    const unsigned grid_w = (unsigned)((N + DB_WPB - 1) / DB_WPB);
+    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, sp, N, cell_start, cell_end, e2,
+                       min_points, val_s, core, parent);
+    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s,
+                       core, parent);
     hipLaunchKernelGGL(dbscan_root_kernel, dim3(grid), dim3(256), 0, c->stream, N, core, parent, root, is_rep);
     PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, is_rep, rank, 0u, n, rocprim::plus<unsigned>(), c->stream));
     hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, root,
