@@ -26,13 +26,28 @@ class PointCloud:
     def __init__(self, points=None, normals=None, colors=None):
         self.points = _arr([] if points is None else points)
         self.normals = _arr([] if normals is None else normals)
+        self._uniform = None          # paint_uniform_color: one colour for every point, written out when read
         self.colors = _arr([] if colors is None else colors)
+
+    @property
+    def colors(self):
+        if self._uniform is not None:
+            self._colors = np.tile(self._uniform, (len(self.points), 1))
+            self._uniform = None
+        return self._colors
+
+    @colors.setter
+    def colors(self, value):
+        self._colors = value
+        self._uniform = None
 
     def has_normals(self):
         return len(self.normals) == len(self.points) and len(self.points) > 0
 
     def has_colors(self):
-        return len(self.colors) == len(self.points) and len(self.points) > 0
+        if self._uniform is not None:
+            return len(self.points) > 0
+        return len(self._colors) == len(self.points) and len(self.points) > 0
 
     def has_points(self):
         return len(self.points) > 0
@@ -46,14 +61,20 @@ class PointCloud:
         return self
 
     def paint_uniform_color(self, rgb):
-        self.colors = np.tile(np.asarray(rgb, np.float64), (len(self.points), 1))
+        """One colour for every point (pose_estimation.py:769-770 paints both clouds every frame); the N x 3
+        array is written out when `colors` is read."""
+        self._colors = np.zeros((0, 3))
+        self._uniform = np.asarray(rgb, np.float64).reshape(3).copy()
         return self
 
     def __len__(self):
         return len(self.points)
 
     def __deepcopy__(self, memo):
-        return PointCloud(np.array(self.points), np.array(self.normals), np.array(self.colors))
+        out = PointCloud(np.array(self.points), np.array(self.normals), None if self._uniform is not None else np.array(self._colors))
+        if self._uniform is not None:
+            out.paint_uniform_color(self._uniform)
+        return out
 
     # ---- the Open3D methods preprocess_source calls (src/pose_estimation.py:186-268); GPU work in
     # pedp_hip.cloud_ops.  Colours are not carried through voxel_down_sample (nothing downstream
@@ -64,8 +85,11 @@ class PointCloud:
             mask = np.ones(len(self.points), bool)
             mask[idx] = False
             idx = np.nonzero(mask)[0]
-        return PointCloud(np.asarray(self.points)[idx], self.normals[idx] if self.has_normals() else None,
-                          self.colors[idx] if self.has_colors() else None)
+        out = PointCloud(np.asarray(self.points)[idx], self.normals[idx] if self.has_normals() else None,
+                         self._colors[idx] if self._uniform is None and self.has_colors() else None)
+        if self._uniform is not None:
+            out.paint_uniform_color(self._uniform)
+        return out
 
     def voxel_down_sample(self, voxel_size):
         from . import cloud_ops

@@ -26,8 +26,25 @@ for rep in range(3):
     r = registration_icp(src, tgt, 6.0, np.linalg.inv(T0), TransformationEstimationPointToPlane())
     t1 = time.perf_counter()
     print(f"single registration_icp (host clouds, {r.iterations} its): {1e3*(t1-t0):.2f} ms  fitness {r.fitness:.3f}")
-np.random.seed(0)
-t0 = time.perf_counter(); z = predict_z_axis_adjustment(src, tgt, T0.copy(), param); t1 = time.perf_counter()
-print(f"predict_z_axis_adjustment: {1e3*(t1-t0):.1f} ms -> {z}")
-t0 = time.perf_counter(); res = improve_result(src, tgt, T0, param); t1 = time.perf_counter()
-print(f"improve_result (50 restarts): {1e3*(t1-t0):.1f} ms  fitness {res.fitness:.4f} rmse {res.inlier_rmse:.4f}")
+for rep in range(3):      # the first call of each kind captures its graphs and sizes the workspace
+    np.random.seed(0)
+    t0 = time.perf_counter(); z = predict_z_axis_adjustment(src, tgt, T0.copy(), param); t1 = time.perf_counter()
+    print(f"predict_z_axis_adjustment: {1e3*(t1-t0):.1f} ms -> {z}")
+    t0 = time.perf_counter(); res = improve_result(src, tgt, T0, param); t1 = time.perf_counter()
+    print(f"improve_result (50 restarts): {1e3*(t1-t0):.1f} ms  fitness {res.fitness:.4f} rmse {res.inlier_rmse:.4f}")
+# the whole refine_pose_with_icp of a frame (run.py:99): raw scene with its back plane, preprocess_source included
+from pedp_hip.compat import refine_pose_with_icp
+raw = big.scene(d2)
+params = {"preprocess_target": {"max_pcd": 100000, "keep_normals": True},
+          "preprocess_source": {"down_sample": 2, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 500}},
+          "box": False, "mesh": False,
+          "refine_registration": {"distance_threshold": 6.0}, "run_icp": {"fitness_threshold": 0.97, "rmse_threshold": 0.8}}
+model = PointCloud(big.model_points, normals=big.normals)
+for rep in range(4):
+    init = synth.start_pose(); init[2, 3] += 5.0
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    moved, best, z, _ = refine_pose_with_icp(PointCloud(raw), model, None, init, params)
+    t1 = time.perf_counter()
+    print(f"refine_pose_with_icp ({len(raw)} scene points x {len(big.model_points)} model points): {1e3*(t1-t0):.1f} ms  "
+          f"fitness {best.fitness:.4f} rmse {best.inlier_rmse:.3f}")
