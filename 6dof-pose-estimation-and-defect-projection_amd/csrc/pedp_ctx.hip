@@ -35,11 +35,25 @@ static int stage_reserve(pedp_ctx_s *c, int which, size_t bytes) {
     return PEDP_OK;
 }
 
+// page-locked host memory (hipHostMalloc / hipHostRegister, whoever made it)?
+static bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary pageable pointer: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PEDP_OK;
     if (bytes < STAGE_MIN) {
         PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         return PEDP_OK;
+    }
+    if (host_is_pinned(src)) {  // the caller's buffer is page-locked already (e.g. a pinned torch tensor): no staging copy
+        PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return PEDP_OK;          // (every entry point synchronises the stream before it hands the buffer back)
     }
     int rc = stage_reserve(c, 0, bytes < STAGE_MAX ? bytes : STAGE_MAX);
     if (rc) return rc;
@@ -57,6 +71,12 @@ int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
 int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PEDP_OK;
     if (bytes < STAGE_MIN) {
+        PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->stage_busy = false;
+        return PEDP_OK;
+    }
+    if (host_is_pinned(dst)) {
         PEDP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
         c->stage_busy = false;
