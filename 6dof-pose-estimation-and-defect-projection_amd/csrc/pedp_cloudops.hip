@@ -938,6 +938,57 @@ int check_cloud(pedp_ctx_t c, const double *pts, int64_t N, const char *who) {
     return PEDP_OK;
 }
 
+// Bounding box of device-resident points: per-workgroup partial minima / maxima (the host loop's
+// comparisons, so NaN coordinates are passed over the same way), folded on the host from the pinned block.
+// One small read-back instead of a host pass over the caller's array (0.5 ms for 365 k points).
+constexpr int BND_BLOCKS = 256;
+__global__ __launch_bounds__(256) void bounds_kernel(const double *__restrict__ pts, int64_t N, double *__restrict__ part) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = pts[3 * i + k];
+            if (v < lo[k]) lo[k] = v;
+            if (v > hi[k]) hi[k] = v;
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a = __shfl_xor(lo[k], off, 64), b = __shfl_xor(hi[k], off, 64);
+            if (a < lo[k]) lo[k] = a;
+            if (b > hi[k]) hi[k] = b;
+        }
+    __shared__ double red[4][6];
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) {
+            const double o = red[w][threadIdx.x];
+            if (threadIdx.x < 3 ? o < v : o > v) v = o;
+        }
+        part[6 * blockIdx.x + threadIdx.x] = v;
+    }
+}
+
+int bounds_device(pedp_ctx_t c, const double *d_pts, int64_t N, double *d_part /* 6 * BND_BLOCKS */, double lo[3], double hi[3]) {
+    hipLaunchKernelGGL(bounds_kernel, dim3(BND_BLOCKS), dim3(256), 0, c->stream, d_pts, N, d_part);
+    PEDP_HIP_CHECK(hipGetLastError());
+    double *h = (double *)((char *)c->pinned + 16384);
+    PEDP_HIP_CHECK(hipMemcpyAsync(h, d_part, sizeof(double) * 6 * BND_BLOCKS, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) { lo[k] = h[k]; hi[k] = h[3 + k]; }
+    for (int b = 1; b < BND_BLOCKS; ++b)
+        for (int k = 0; k < 3; ++k) {
+            if (h[6 * b + k] < lo[k]) lo[k] = h[6 * b + k];
+            if (h[6 * b + 3 + k] > hi[k]) hi[k] = h[6 * b + 3 + k];
+        }
+    return PEDP_OK;
+}
+
 void bounds(const double *pts, int64_t N, double lo[3], double hi[3]) {
     for (int k = 0; k < 3; ++k) lo[k] = hi[k] = pts[k];
     for (int64_t i = 1; i < N; ++i)
@@ -946,6 +997,23 @@ void bounds(const double *pts, int64_t N, double lo[3], double hi[3]) {
             if (v < lo[k]) lo[k] = v;
             if (v > hi[k]) hi[k] = v;
         }
+}
+
+// Large clouds: the points go up first (into their own scratch, so the workspace can still be sized by the grid)
+// and their box comes from the device copy; small ones keep the host pass.  Returns the device copy or nullptr.
+constexpr int64_t BND_DEVICE_MIN = 32768;
+int bounds_of(pedp_ctx_t c, const double *pts, int64_t N, double lo[3], double hi[3], double **d_in) {
+    *d_in = nullptr;
+    if (N < BND_DEVICE_MIN) { bounds(pts, N, lo, hi); return PEDP_OK; }
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    int st = c->ops_in.reserve(a256(sizeof(double) * 3 * (size_t)N) + a256(sizeof(double) * 6 * BND_BLOCKS));
+    if (st) return st;
+    double *d = (double *)c->ops_in.ptr, *d_part = (double *)((char *)c->ops_in.ptr + a256(sizeof(double) * 3 * (size_t)N));
+    { int up_ = pedp_upload(c, d, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    st = bounds_device(c, d, N, d_part, lo, hi);
+    if (st) return st;
+    *d_in = d;
+    return PEDP_OK;
 }
 
 // grid over the bounding box with the given cell size, coarsened until it has at most 2^24 cells
@@ -989,12 +1057,6 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     PEDP_REQUIRE(voxel_size > 0.0, "pedp_voxel_down_sample: voxel_size <= 0");  // Open3D raises too
     if (N == 0) return PEDP_OK;
     double lo[3], hi[3];
-    bounds(pts, N, lo, hi);
-    for (int k = 0; k < 3; ++k) {
-        PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
-        lo[k] = lo[k] - voxel_size * 0.5;
-        PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
-    }
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     const unsigned n = (unsigned)N;
     size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
@@ -1007,7 +1069,7 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     size_t tmp = tmp_sort > tmp_rle ? tmp_sort : tmp_rle;
     if (tmp_scan > tmp) tmp = tmp_scan;
     const size_t need = a256(sizeof(double) * 3 * N) * 4 + a256(sizeof(unsigned long long) * N) * 3 + a256(sizeof(int) * N) * 2 +
-                        a256(sizeof(unsigned) * N) * 2 + 256 + a256(tmp) + 4096;
+                        a256(sizeof(unsigned) * N) * 2 + 256 + a256(tmp) + a256(sizeof(double) * 6 * BND_BLOCKS) + 4096;
     int st = c->ops.reserve(need);
     if (st) return st;
     Carver cv{(char *)c->ops.ptr};
@@ -1018,8 +1080,16 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
     unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
     void *d_tmp = cv.take<char>(tmp);
+    double *d_part = cv.take<double>(6 * BND_BLOCKS);
     { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     if (normals) { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    rc = bounds_device(c, d_pts, N, d_part, lo, hi);   // (the box of the points just uploaded: no host pass over them)
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k) {
+        PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
+        lo[k] = lo[k] - voxel_size * 0.5;
+        PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
+    }
     const unsigned grid = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
@@ -1182,8 +1252,9 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
     PEDP_REQUIRE(max_nn >= 1 && max_nn <= 128, "pedp_estimate_normals: max_nn must be in 1..128");
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(normals, "pedp_estimate_normals: null output");
-    double lo[3], hi[3];
-    bounds(pts, N, lo, hi);
+    double lo[3], hi[3], *d_in = nullptr;
+    rc = bounds_of(c, pts, N, lo, hi, &d_in);
+    if (rc) return rc;
     Grid g;
     int64_t n_cells = 0;
     rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_estimate_normals");
@@ -1204,7 +1275,8 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
     int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
     void *d_tmp = cv.take<char>(tmp_sort);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (d_in) d_pts = d_in;  // already up (bounds_of)
+    else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     if (prior) { int up_ = pedp_upload(c, d_prior, prior, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
     PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
@@ -1230,8 +1302,9 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(normals && out, "pedp_fpfh: null normals / output (FPFH needs the cloud's normals)");
     PEDP_REQUIRE(N * (int64_t)max_nn < (int64_t)1 << 31, "pedp_fpfh: neighbour table too large");
-    double lo[3], hi[3];
-    bounds(pts, N, lo, hi);
+    double lo[3], hi[3], *d_in = nullptr;
+    rc = bounds_of(c, pts, N, lo, hi, &d_in);
+    if (rc) return rc;
     Grid g;
     int64_t n_cells = 0;
     rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_fpfh");
@@ -1255,7 +1328,8 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
     int *nbr_j = cv.take<int>((size_t)N * max_nn);
     double *nbr_d = cv.take<double>((size_t)N * max_nn);
     double *spfh = cv.take<double>(33 * (size_t)N), *d_out = cv.take<double>(33 * (size_t)N);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (d_in) d_pts = d_in;  // already up (bounds_of)
+    else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
     PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));

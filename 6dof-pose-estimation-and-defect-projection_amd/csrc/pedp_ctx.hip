@@ -175,6 +175,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_aux.release();
     c->ray_order.release();
     c->ray_rast.release();
+    c->ops_in.release();
     if (c->rast_status) (void)hipHostFree(c->rast_status);
     c->icp_ws.release();
     c->proj.release();

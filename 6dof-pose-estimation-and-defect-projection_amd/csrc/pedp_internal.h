@@ -97,6 +97,7 @@ struct pedp_ctx_s {
     // ICP
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
+    pedp_scratch ops_in;     // a large cloud's points, uploaded ahead of the workspace sizing (its box comes from the device copy)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
     int icp_timed_pass = -1;      // pedp_icp_configure: HIP events around the sweep kernel of this pass
