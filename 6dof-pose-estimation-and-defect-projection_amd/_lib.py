@@ -60,6 +60,8 @@ PROTOTYPES = {
                                           C.c_int, C.c_void_p]),
     "pedp_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_int64, _P(C.c_int64)]),
+    "pedp_voxel_down_sample_device_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
+                                                   _P(C.c_int64)]),
     "pedp_cluster_dbscan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
     "pedp_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pedp_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),

@@ -22,15 +22,37 @@ def _pts(points):
     return np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
 def voxel_down_sample(points, voxel_size, normals=None, ctx=None):
+    """Voxel-grid averages (PointCloud.voxel_down_sample).  `points` may be a float64 N x 3 torch tensor on the
+    GPU (a scene that was back-projected there): the grid is then built from the device array and only the
+    averages come to the host."""
     ctx = ctx or _lib.default_context()
+    if _is_device_tensor(points):
+        import torch
+
+        if normals is not None and len(normals):
+            raise NotImplementedError("voxel_down_sample: device points with normals")
+        t = points.reshape(-1, 3)
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            t = t.to(torch.float64).contiguous()
+        torch.cuda.current_stream(t.device).synchronize()     # the library reads the array on its own stream
+        out = np.empty((len(t), 3), np.float64)
+        m = C.c_int64()
+        _lib.check(_lib.load().pedp_voxel_down_sample_device_in(ctx._h, C.c_void_p(t.data_ptr()), len(t), float(voxel_size),
+                                                                _lib._ptr(out), len(t), C.byref(m)),
+                   "pedp_voxel_down_sample_device_in")
+        return out[:m.value], None
     p = _pts(points)
     n = None if normals is None or len(normals) == 0 else _pts(normals)
     out, outn = np.empty_like(p), (np.empty_like(p) if n is not None else None)
     m = C.c_int64()
     _lib.check(_lib.load().pedp_voxel_down_sample(ctx._h, _lib._ptr(p), _lib._ptr(n), len(p), float(voxel_size), _lib._ptr(out),
                                                   _lib._ptr(outn), len(p), C.byref(m)), "pedp_voxel_down_sample")
-    return out[:m.value].copy(), (None if outn is None else outn[:m.value].copy())
+    return out[:m.value], (None if outn is None else outn[:m.value])     # (views of the call's output buffers)
 
 
 def cluster_dbscan(points, eps, min_points, ctx=None):

@@ -1048,8 +1048,21 @@ int make_grid(const double lo[3], const double hi[3], double cell, Grid &g, int6
 
 extern "C" {
 
+static int voxel_down_sample_impl(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
+                                  double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, bool pts_on_device);
+
 int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
                            double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out) {
+    return voxel_down_sample_impl(c, pts, normals, N, voxel_size, out_pts, out_normals, capacity, n_out, false);
+}
+
+int pedp_voxel_down_sample_device_in(pedp_ctx_t c, const double *d_pts, int64_t N, double voxel_size, double *out_pts,
+                                     int64_t capacity, int64_t *n_out) {
+    return voxel_down_sample_impl(c, d_pts, nullptr, N, voxel_size, out_pts, nullptr, capacity, n_out, true);
+}
+
+static int voxel_down_sample_impl(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
+                                  double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, bool pts_on_device) {
     int rc = check_cloud(c, pts, N, "pedp_voxel_down_sample");
     if (rc) return rc;
     PEDP_REQUIRE(n_out, "pedp_voxel_down_sample: null count");
@@ -1081,7 +1094,8 @@ int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normal
     unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
     void *d_tmp = cv.take<char>(tmp);
     double *d_part = cv.take<double>(6 * BND_BLOCKS);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (pts_on_device) d_pts = const_cast<double *>(pts);  // the caller's device array, read only
+    else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     if (normals) { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     rc = bounds_device(c, d_pts, N, d_part, lo, hi);   // (the box of the points just uploaded: no host pass over them)
     if (rc) return rc;

@@ -22,17 +22,44 @@ def _arr(x, cols=3, dtype=np.float64):
     return a.reshape(-1, cols) if a.size else np.zeros((0, cols), dtype)
 
 
+def _on_device(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
 class PointCloud:
+    """Open3D-shaped holder: `points` / `normals` / `colors` are N x 3 float64 numpy arrays.
+
+    `points` may also be given as a float64 N x 3 torch tensor on the GPU (a scene back-projected there,
+    estimater.py hands CUDA tensors around): the holder keeps the tensor, `voxel_down_sample` works from it,
+    and the numpy array is only made if somebody reads `points`."""
+
     def __init__(self, points=None, normals=None, colors=None):
-        self.points = _arr([] if points is None else points)
+        self._dev_points = None
+        if _on_device(points):
+            self._dev_points, self._points = points.reshape(-1, 3), None
+        else:
+            self._points = _arr([] if points is None else points)
         self.normals = _arr([] if normals is None else normals)
         self._uniform = None          # paint_uniform_color: one colour for every point, written out when read
         self.colors = _arr([] if colors is None else colors)
 
     @property
+    def points(self):
+        if self._points is None:
+            self._points = _arr(self._dev_points.detach().cpu().numpy())
+        return self._points
+
+    @points.setter
+    def points(self, value):
+        self._points, self._dev_points = value, None
+
+    def _count(self):
+        return len(self._dev_points) if self._points is None else len(self._points)
+
+    @property
     def colors(self):
         if self._uniform is not None:
-            self._colors = np.tile(self._uniform, (len(self.points), 1))
+            self._colors = np.tile(self._uniform, (self._count(), 1))
             self._uniform = None
         return self._colors
 
@@ -42,15 +69,15 @@ class PointCloud:
         self._uniform = None
 
     def has_normals(self):
-        return len(self.normals) == len(self.points) and len(self.points) > 0
+        return len(self.normals) == self._count() and self._count() > 0
 
     def has_colors(self):
         if self._uniform is not None:
-            return len(self.points) > 0
-        return len(self._colors) == len(self.points) and len(self.points) > 0
+            return self._count() > 0
+        return len(self._colors) == self._count() and self._count() > 0
 
     def has_points(self):
-        return len(self.points) > 0
+        return self._count() > 0
 
     def transform(self, T):
         """In place, float64, like Open3D: points by the full 4x4, normals by the rotation."""
@@ -68,7 +95,7 @@ class PointCloud:
         return self
 
     def __len__(self):
-        return len(self.points)
+        return self._count()
 
     def __deepcopy__(self, memo):
         out = PointCloud(np.array(self.points), np.array(self.normals), None if self._uniform is not None else np.array(self._colors))
@@ -94,7 +121,10 @@ class PointCloud:
     def voxel_down_sample(self, voxel_size):
         from . import cloud_ops
 
-        pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)
+        if self._points is None and not self.has_normals():      # device-resident scene: the grid is built from it
+            pts, nrm = cloud_ops.voxel_down_sample(self._dev_points, voxel_size)
+        else:
+            pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)
         return PointCloud(pts, nrm)
 
     def segment_plane(self, distance_threshold, ransac_n, num_iterations, probability=0.99999999):

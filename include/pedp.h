@@ -171,6 +171,13 @@ int pedp_depth2xyzmap_batch(pedp_ctx_t ctx, const float *depths, int B, int H, i
  * Output order: ascending (ix, iy, iz) (Open3D: unordered_map order).  capacity = N always fits. */
 int pedp_voxel_down_sample(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N, double voxel_size,
                            double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out);
+
+/* The same grid over points that are already on the device (N x 3 float64 device memory, e.g. the output of
+ * pedp_depth2xyzmap_batch turned into millimetres by the caller): the scene of a frame then never visits the
+ * host at full resolution.  Voxel averages come back to host memory like above; no normals.  The caller
+ * orders its own work on the array before the call (the library reads it on the context's stream). */
+int pedp_voxel_down_sample_device_in(pedp_ctx_t ctx, const double *d_pts, int64_t N, double voxel_size, double *out_pts,
+                                     int64_t capacity, int64_t *n_out);
 /* cluster_dbscan (:284): neighbours are points with d^2 < eps^2 (itself included), core points
  * have >= min_points neighbours; labels as Open3D's breadth-first sweep assigns them: clusters
  * numbered by their smallest core index, a border point takes the smallest id among its core

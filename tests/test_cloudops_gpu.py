@@ -269,3 +269,34 @@ def test_foreign_cloud_objects_take_the_gpu_methods(ctx, oracle):
     a, _, _ = preprocess_source(Foreign(scene), None, param, i=0)
     b, _, _ = preprocess_source(PointCloud(scene), None, param, i=0)
     assert isinstance(a, PointCloud) and np.array_equal(a.points, b.points)
+
+
+def test_device_resident_scene_through_the_voxel_grid(ctx, oracle):
+    """A scene cloud that lives on the GPU (float64 N x 3 torch tensor, what the depth back-projection
+    leaves there): `voxel_down_sample` works from the device array -- same averages bit for bit -- and
+    a PointCloud holding the tensor goes through preprocess_source like the host copy, without the full
+    cloud visiting the host unless `points` is read."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import cloud_ops
+    from pedp_hip.compat import PointCloud, preprocess_source
+
+    pts = _scene(n_plane=60000, n_obj=9000, seed=5)
+    dev = torch.from_numpy(pts).cuda()
+    got, none = cloud_ops.voxel_down_sample(dev, 2.0, ctx=ctx)
+    ref, _ = cloud_ops.voxel_down_sample(pts, 2.0, ctx=ctx)
+    assert none is None and np.array_equal(got, ref) and np.array_equal(got, oracle.voxel_down_sample(pts, 2.0)[0])
+    assert np.array_equal(cloud_ops.voxel_down_sample(dev.float(), 2.0, ctx=ctx)[0],                 # other dtypes are converted
+                          cloud_ops.voxel_down_sample(pts.astype(np.float32).astype(np.float64), 2.0, ctx=ctx)[0])
+    holder = PointCloud(dev)
+    assert len(holder) == len(pts) and holder.has_points() and not holder.has_normals() and holder._points is None
+    holder.paint_uniform_color([1, 0, 0])
+    assert holder.has_colors() and holder._points is None                                           # still only on the device
+    params = {"preprocess_source": {"down_sample": 2, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 200}},
+              "box": False, "mesh": False}
+    cloud_ops.set_ransac_seed(4)
+    a, _, _ = preprocess_source(holder, None, params, i=0)
+    assert holder._points is None
+    cloud_ops.set_ransac_seed(4)
+    b, _, _ = preprocess_source(PointCloud(pts), None, params, i=0)
+    assert np.array_equal(a.points, b.points) and np.array_equal(a.normals, b.normals)
+    assert np.array_equal(holder.points, pts) and holder.colors.shape == pts.shape                   # read: now it is made

@@ -38,7 +38,10 @@ for rep in range(4):
     xyz = compat.depth2xyzmap_batch(d[None], Kt, zfar=np.inf, ctx=one)[0]
     if one is not None: one.synchronize()
     lap()
-    if "--pinned" in sys.argv:
+    if "--device-scene" in sys.argv:     # the scene stays on the GPU: the voxel grid is built from the device array
+        pts = xyz[xyz[..., 2] >= 0.001].double() * 1000.0
+        torch.cuda.synchronize()
+    elif "--pinned" in sys.argv:
         dev_pts = xyz[xyz[..., 2] >= 0.001].double() * 1000.0
         if rep == 0: host_pts = torch.empty((f.width * f.height, 3), dtype=torch.float64, pin_memory=True)
         host_pts[: len(dev_pts)].copy_(dev_pts)
