@@ -92,8 +92,8 @@ int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
  * outside the half space, 2 a crowded cell, 3 item table full).  Synchronises the stream. */
 int pedp_raycast_last_variant(pedp_ctx_t ctx, int *variant, int *grid_status);
 
-/* Milliseconds the last pedp_raycast spent in its sweep stage -- for variant 3 the direction
- * binning, cull masks, segment table and the sweep itself (HIP events on the context's stream,
+/* Milliseconds the last pedp_raycast spent in its sweep stage -- for variant 4 the bounds, chain, triangle
+ * and tile kernels, for variant 3 the direction binning, cull masks, segment table and the sweep itself (HIP events on the context's stream,
  * around everything between the operand set-up and the final t / id / uv write-out);
  * synchronises on the second event. */
 int pedp_raycast_last_sweep_ms(pedp_ctx_t ctx, float *ms);
