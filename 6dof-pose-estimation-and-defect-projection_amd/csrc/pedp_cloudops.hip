@@ -1454,28 +1454,54 @@ int pedp_segment_plane(pedp_ctx_t c, const double *pts, int64_t N, double distan
 // Stable sort of point indices by a small integer key (pedp_icp.hip: spatial order of a cloud by
 // the Hilbert index of its grid cell).  Stable = equal keys keep ascending point index, so the
 // order is a function of the data alone -- the ICP sums that follow it are run-to-run bit-stable.
-// d_keys: N unsigned keys below 2^bits on the device (overwritten); d_perm: N int32 out.
+// keys: N 64-bit keys below 2^bits on the device (overwritten); d_perm: N int32 out.
 namespace {
 __global__ void iota_kernel(int *__restrict__ v, int64_t N) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) v[i] = (int)i;
 }
 }  // namespace
-int pedp_stable_sort_by_key(pedp_ctx_t c, unsigned *d_keys, int64_t N, int bits, int32_t *d_perm) {
-    if (N <= 0) return PEDP_OK;
-    const unsigned n = (unsigned)N;
+// Two calls: _begin reserves the context's scratch for N 64-bit keys plus the sort's buffers and returns the key
+// array for the caller's key kernel; _run sorts.  Everything is stream-ordered in the context's pooled scratch:
+// no allocation once sizes have settled, no synchronisation.
+namespace {
+struct Sort64Layout {
+    unsigned long long *keys, *keys_s;
+    int *val;
+    void *tmp;
+    size_t tmp_bytes;
+};
+int sort64_layout(pedp_ctx_t c, int64_t N, int bits, Sort64Layout &L) {
     size_t tmp_sort = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
-                                           (int *)nullptr, n, 0, bits, c->stream));
-    const size_t need = a256(sizeof(unsigned) * N) + a256(sizeof(int) * N) + a256(tmp_sort) + 1024;
-    int st = c->ops.reserve(need);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                           (int *)nullptr, (int *)nullptr, (unsigned)N, 0, bits, c->stream));
+    const size_t need = 2 * a256(sizeof(unsigned long long) * N) + a256(sizeof(int) * N) + a256(tmp_sort) + 1024;
+    int st = c->sort_ws.reserve(need);
     if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    unsigned *keys_s = cv.take<unsigned>(N);
-    int *val = cv.take<int>(N);
-    void *d_tmp = cv.take<char>(tmp_sort);
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, val, N);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, d_keys, keys_s, val, (int *)d_perm, n, 0, bits, c->stream));
+    Carver cv{(char *)c->sort_ws.ptr};
+    L.keys = cv.take<unsigned long long>(N);
+    L.keys_s = cv.take<unsigned long long>(N);
+    L.val = cv.take<int>(N);
+    L.tmp = cv.take<char>(tmp_sort);
+    L.tmp_bytes = tmp_sort;
+    return PEDP_OK;
+}
+}  // namespace
+int pedp_sort_keys64_begin(pedp_ctx_t c, int64_t N, int bits, unsigned long long **d_keys) {
+    Sort64Layout L;
+    int st = sort64_layout(c, N, bits, L);
+    if (st) return st;
+    *d_keys = L.keys;
+    return PEDP_OK;
+}
+int pedp_sort_keys64_run(pedp_ctx_t c, int64_t N, int bits, int32_t *d_perm) {
+    if (N <= 0) return PEDP_OK;
+    Sort64Layout L;
+    int st = sort64_layout(c, N, bits, L);  // same sizes as _begin: the scratch does not move
+    if (st) return st;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, L.val, N);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(L.tmp, L.tmp_bytes, L.keys, L.keys_s, L.val, (int *)d_perm, (unsigned)N, 0, bits,
+                                           c->stream));
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }

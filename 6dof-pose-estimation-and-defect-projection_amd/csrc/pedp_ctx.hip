@@ -176,6 +176,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_order.release();
     c->ray_rast.release();
     c->ops_in.release();
+    c->sort_ws.release();
     if (c->rast_status) (void)hipHostFree(c->rast_status);
     c->icp_ws.release();
     c->proj.release();

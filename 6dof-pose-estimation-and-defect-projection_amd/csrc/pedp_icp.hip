@@ -59,8 +59,32 @@ __device__ long long g_icp_stamps[3][4096][8];
 extern "C" int pedp_debug_icp_stamps(long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_stamps), sizeof(long long) * 3 * 4096 * 8) == hipSuccess ? 0 : -3;
 }
+// s_memrealtime (100 MHz, one clock for the whole device) per pass and workgroup of the pass kernel:
+// [0] entry, [1] state read, [2] chunks done, [3] ticket returned, [4] pass closed (last workgroup only)
+__device__ long long g_icp_rt[32][512][8];
+// per wave of the pass kernel (last pass that ran): [0] start [1] slots ready [2] culled+swept [3] selected [4] sums done (s_memtime),
+// [5] words << 32 | batches << 16 | wide << 8 | slots, [6] tiles
+__device__ long long g_icp_wave[512][8][8];
+#define PEDP_WV(slot, val)                                                                         \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512 && blockIdx.y == 0)                        \
+            g_icp_wave[blockIdx.x][threadIdx.x >> 6][slot] = (long long)(val);                     \
+    } while (0)
+extern "C" int pedp_debug_icp_wave(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_wave), sizeof(long long) * 512 * 8 * 8) == hipSuccess ? 0 : -3;
+}
+#define PEDP_RT(pass, slot)                                                                     \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && (pass) < 32 && blockIdx.x < 512 && blockIdx.y == 0)             \
+            g_icp_rt[pass][blockIdx.x][slot] = (long long)__builtin_amdgcn_s_memrealtime();     \
+    } while (0)
+extern "C" int pedp_debug_icp_rt(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_rt), sizeof(long long) * 32 * 512 * 8) == hipSuccess ? 0 : -3;
+}
 #else
 #define PEDP_STAMP(kern, unit, slot) do {} while (0)
+#define PEDP_RT(pass, slot) do {} while (0)
+#define PEDP_WV(slot, val) do {} while (0)
 #endif
 
 namespace {
@@ -78,8 +102,8 @@ constexpr int NN_TU = 4;    // rows are padded to multiples of 16 * NN_TU (= the
 constexpr int NN_LIST_TILES = 2048; // most MFMA tiles one sweep wave walks (its unit list lives in LDS)
 constexpr int SEG_MIN_TILES = 64;   // MFMA tiles per sweep segment at least
 constexpr int CULL_WORDS = 8;       // 64-unit mask words one cull wave fills
-constexpr int SORT_BITS = 8;          // spatial sort: 256^3 Hilbert-ordered cells over the cloud's bounding box
-constexpr int SORT_CELLS = 1 << (3 * SORT_BITS);
+constexpr int SORT_BITS = 16;         // spatial sort: 65536^3 Hilbert-ordered cells over the cloud's own bounding box
+constexpr int SORT_KEY_BITS = 3 * SORT_BITS + 1;  // + the bucket of points without a cell (non-finite coordinates)
 constexpr int NN_TILE_PAD = 2 * NN_TU;  // readable pad tiles behind the last real tile
 constexpr int ACC_BLOCKS = 256;
 constexpr int ACC_THREADS = 256;
@@ -111,6 +135,7 @@ struct IcpState {
     float r1, r_search, wide_radius, r2f;
     int pass, max_iter;        // the pass the fused kernels are in (advanced by icp_finish_kernel), and the limit
     double mu_theta, mu_tau;   // sum of |R - I|_F and of |t + (R - I) c| since the last rebuild
+    unsigned ticket;           // workgroups of the running pass that have stored their partial sums (the last one closes the pass)
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -124,16 +149,20 @@ __device__ __forceinline__ double dist2(double ax, double ay, double az, double 
 }
 
 // ------------------------------------------------------------------ spatial order of a cloud
-// Stable sort by the Hilbert-curve index of the point's cell in a 256^3 grid over the bounding box:
-// consecutive entries of `perm` are neighbours in space, so 128-point scene blocks and 16-point
-// target tiles are compact and their bounding spheres are small.  Inside a cell the points keep
-// ascending index (stable radix sort), so the order -- and with it the order of every float64 sum
-// of a registration -- is a function of the data alone.
+// Stable sort by the Hilbert-curve index of the point's cell in a 65536^3 grid over the cloud's OWN
+// bounding box: consecutive entries of `perm` are neighbours in space, so 128-point scene chunks and
+// 16-point target tiles are compact and their bounding spheres are small.  Inside a cell the points
+// keep ascending index (stable radix sort).  The order -- and with it the order of every float64 sum
+// of a registration -- is a function of the cloud's data alone: not of the registration that first
+// touched the handle, not of its start pose (round 2 laid 256^3 cells over the region the target
+// could reach from the first start pose, so two handles of the same data could sum in different
+// orders).  48 bits keep the cells far below the point spacing even when one stray point stretches
+// the box a hundredfold.
 // 3-D Hilbert index of cell (x, y, z), SORT_BITS bits per axis (Skilling, "Programming the
 // Hilbert curve", 2004: axes -> transpose, then bit interleave).  Unlike Morton order, points
 // that are consecutive along the curve are always neighbours in space, so no 128-point scene
 // block or 16-point target tile straddles a long jump (such blocks would defeat the culling).
-__device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z) {
+__device__ __forceinline__ unsigned long long hilbert3(unsigned x, unsigned y, unsigned z) {
     unsigned X[3] = {x, y, z};
     const unsigned M = 1u << (SORT_BITS - 1);
     for (unsigned Q = M; Q > 1; Q >>= 1) {
@@ -150,23 +179,23 @@ __device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z)
     for (unsigned Q = M; Q > 1; Q >>= 1)
         if (X[2] & Q) t ^= Q - 1;
     X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    unsigned h = 0;
+    unsigned long long h = 0;
 #pragma unroll
     for (int b = SORT_BITS - 1; b >= 0; --b)
-        h = (h << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+        h = (h << 3) | (unsigned long long)((((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u));
     return h;
 }
-// Cell of point i; points outside the region [lo, lo + extent) all share the extra bucket
-// SORT_CELLS (they are no ICP candidates; one bucket keeps them off the border cells).
-__device__ __forceinline__ unsigned point_cell(const double *__restrict__ pts, int64_t i, double lox, double loy,
-                                               double loz, double sx, double sy, double sz) {
+// Cell of point i; a point without a cell (a non-finite coordinate) goes to the extra bucket behind
+// the curve.
+__device__ __forceinline__ unsigned long long point_cell(const double *__restrict__ pts, int64_t i, double lox, double loy,
+                                                         double loz, double sx, double sy, double sz) {
     const double fx = (pts[3 * i] - lox) * sx, fy = (pts[3 * i + 1] - loy) * sy, fz = (pts[3 * i + 2] - loz) * sz;
     const double top = (double)(1 << SORT_BITS);
-    if (!(fx >= 0.0 && fx < top && fy >= 0.0 && fy < top && fz >= 0.0 && fz < top)) return (unsigned)SORT_CELLS;
+    if (!(fx >= 0.0 && fx < top && fy >= 0.0 && fy < top && fz >= 0.0 && fz < top)) return 1ull << (3 * SORT_BITS);
     return hilbert3((unsigned)(int)fx, (unsigned)(int)fy, (unsigned)(int)fz);
 }
 __global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
-                                double sx, double sy, double sz, unsigned *__restrict__ key) {
+                                double sx, double sy, double sz, unsigned long long *__restrict__ key) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) key[i] = point_cell(pts, i, lox, loy, loz, sx, sy, sz);
 }
@@ -185,17 +214,20 @@ __global__ void pack_target_kernel(const double *__restrict__ pts, const int32_t
     double w = (double)x * x + (double)y * y + (double)z * z;
     out[k] = make_float4(x, y, z, (float)w);
 }
-// sorted float64 rows of the target (row k = point perm[k]): the exact re-scoring reads them with
-// one load per row instead of perm -> point
-__global__ void sort_rows_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm, int64_t N, int64_t N_pad,
-                                 double *__restrict__ out) {
+// sorted float64 rows of the target (row k = point perm[k]): x y z nx ny nz, so that the exact
+// re-scoring reads a candidate row -- and with it what the winner contributes to the sums -- with
+// one contiguous 48-byte load instead of perm -> point -> normal
+__global__ void sort_rows_kernel(const double *__restrict__ pts, const double *__restrict__ nrm, const int32_t *__restrict__ perm,
+                                 int64_t N, int64_t N_pad, double *__restrict__ out) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N_pad) return;
     const bool real = k < N;
     const int64_t i = real ? perm[k] : 0;
-    out[3 * k] = real ? pts[3 * i] : 0.0;
-    out[3 * k + 1] = real ? pts[3 * i + 1] : 0.0;
-    out[3 * k + 2] = real ? pts[3 * i + 2] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[6 * k + c] = real ? pts[3 * i + c] : 0.0;
+        out[6 * k + 3 + c] = real && nrm ? nrm[3 * i + c] : 0.0;
+    }
 }
 __global__ void tile_sphere_kernel(const float4 *__restrict__ t4, int64_t N, int64_t n_units_all, int UNIT_ROWS,
                                    float4 *__restrict__ sph) {
@@ -778,650 +810,6 @@ __global__ __launch_bounds__(FB_WAVES * 64) void nn_fallback_kernel(const IcpSta
     }
 }
 
-// ================================================================== fused pass
-// Radius-limited registrations (unit size 1) run TWO launches per correspondence pass:
-//   icp_pass_kernel    one workgroup (8 waves) per live scene chunk, everything of the pass that
-//                      belongs to the chunk: transform its 128 points, box test, compaction into
-//                      slots, sub-block spheres, two-level culling of the target tiles, MFMA sweep
-//                      of the survivors (triples in LDS), exact selection, exact search for
-//                      ambiguous slots, the chunk's partial sums of J^T J / J^T r in a fixed order;
-//   icp_finish_kernel  partial sums of the live chunks in ascending chunk order, 6x6 solve in
-//                      registers, pose update, convergence, motion bound, live list.
-// A chunk is 128 consecutive entries of the scene's spatial order.  Only LIVE chunks are visited:
-// those that had a point within r + margin of the target's bounding box when the live set was
-// last rebuilt.  A rebuild pass walks the whole scene and recomputes every point from the source
-// through the history of updates -- the same float64 operations, in the same order, as applying
-// them pass by pass, so a point's coordinates do not depend on when its chunk became live.
-// Between rebuilds a point outside the live chunks is farther than r + margin from the box; an
-// update (R, t) moves a point x by at most |R - I| |x - c| + |t + (R - I) c| (c = box centre), and
-// with e = (distance to the box) + rho (rho = half diagonal), E = r + margin + rho:
-//   e_new >= e (1 - theta) - tau   =>   e_n >= E - (Theta E + Tau) = E - mu,
-// so no such point can come within r while mu < margin; icp_finish_kernel requests a rebuild at
-// mu >= 0.95 margin.  Chunk ids, slot order, tile order and the order of the partial sums depend
-// only on the data, never on execution order: results are run-to-run bit-stable.
-//
-// The pass is bound by chains of dependent memory accesses (about a microsecond per level on this
-// part), not by arithmetic.  The kernel is laid out to keep the chain short: what does not depend
-// on the points (word spheres) is requested first, every culling level is one round of
-// independent loads spread over all eight waves, and nothing the later phases need goes through
-// global memory.
-constexpr int CH = NN_SB * 16;   // 128 scene points per chunk = slots per scene block
-constexpr int BK_W = 8;          // waves of a pass workgroup
-constexpr int BK_TL = 2048;      // surviving tiles of a chunk held in LDS per round
-constexpr int BK_QS = 144;       // floats between the lane groups of one wave's triples (bank spread)
-constexpr int BK_WCAP = BK_W * 64;  // mask words (64 tiles each) the fused pass handles: 524,288 target points
-constexpr int PSTRIDE = 32;      // doubles per chunk in the partials: packet, [29] tiles, [30] fallback slots
-constexpr int LIVE_CAP = 8192;   // live chunks the finish kernel lists in LDS (1M scene points)
-
-// chunk of the rank-th set bit of the live mask (ascending), -1 beyond the last; wave-uniform
-__device__ __forceinline__ int live_rank_to_chunk(const unsigned long long *__restrict__ live, int n_lw, int rank, int lane) {
-    int running = 0;
-    for (int w0 = 0; w0 < n_lw; w0 += 64) {
-        const unsigned long long word = (w0 + lane < n_lw) ? live[w0 + lane] : 0ull;
-        const int pc = __builtin_popcountll(word);
-        int incl = pc;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        const int excl = running + incl - pc;
-        const unsigned long long hm = __builtin_amdgcn_ballot_w64(rank >= excl && rank < excl + pc);
-        if (hm != 0ull) {
-            const int srcl = __builtin_ctzll(hm);
-            unsigned long long ww = __shfl(word, srcl, 64);
-            const int k = rank - __shfl(excl, srcl, 64);
-            for (int t = 0; t < k; ++t) ww &= ww - 1ull;
-            return (w0 + srcl) * 64 + __builtin_ctzll(ww);
-        }
-        running += __shfl(incl, 63, 64);
-    }
-    return -1;
-}
-
-__device__ __forceinline__ void xform(const double *__restrict__ M, double &x, double &y, double &z) {
-    const double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
-    const double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
-    const double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
-    x = nx; y = ny; z = nz;
-}
-
-// float <-> int keys with the same order (finite values and +-inf), for an LDS atomicMin
-__device__ __forceinline__ int fkey(float v) {
-    const int b = __float_as_int(v);
-    return b ^ ((b >> 31) & 0x7FFFFFFF);
-}
-__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7FFFFFFF)); }
-
-// Can a target sphere ts (a tile's, or a whole mask word's) hold the nearest neighbour of a
-// candidate of the chunk?  Every slot has a search radius rho <= r (see "temporal coherence" in
-// icp_pass_kernel), a sub-block the largest of its slots'.  Per 16-slot sub-block: bounding-sphere test; a WIDE sub-block (16 consecutive
-// points of the spatial order that straddle a jump of the curve: radius above r) is resolved
-// point by point, so its tiles are those near an actual point, not the (possibly huge) ball
-// around all sixteen.  Spheres, flags and points are read from LDS (broadcast reads).
-__device__ __forceinline__ bool near_chunk(const float4 &ts, const float4 *__restrict__ bs, const float *__restrict__ rsb,
-                                           unsigned wide, int cnt_lo, int cnt_hi, const float (*__restrict__ cs)[CH],
-                                           const float *__restrict__ rho) {
-    unsigned hit = 0;  // bit sb: the sub-block's sphere is near
-#pragma unroll
-    for (int sb = 0; sb < NN_SB; ++sb) {
-        const float4 b = bs[sb];
-        const float dx = ts.x - b.x, dy = ts.y - b.y, dz = ts.z - b.z;
-        const float lim = rsb[sb] + b.w + ts.w;
-        const bool k = (b.w >= 0.f) & !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
-        hit |= (k ? 1u : 0u) << sb;
-    }
-    if (wide & hit) {  // rare: resolve the wide sub-blocks that passed point by point
-        unsigned todo = wide & hit;
-        hit &= ~wide;
-#pragma nounroll
-        while (todo != 0u && hit == 0u) {
-            const int sb = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            bool any = false;
-            const int j_end = sb < 4 ? cnt_lo : 64 + cnt_hi;  // real slots: [0, cnt_lo) and [64, 64 + cnt_hi)
-#pragma nounroll
-            for (int j = sb * 16; j < sb * 16 + 16 && j < j_end; ++j) {
-                const float px = cs[0][j], py = cs[1][j], pz = cs[2][j];
-                const float ex = ts.x - px, ey = ts.y - py, ez = ts.z - pz;
-                const float lp = rho[j] + ts.w + 1e-5f * (fabsf(px) + fabsf(py) + fabsf(pz)) + 1e-6f;
-                any |= !((ex * ex + ey * ey + ez * ez) > lp * lp * 1.00001f + 1e-6f);
-            }
-            hit |= any ? 1u : 0u;
-        }
-    }
-    return hit != 0u && ts.w >= 0.f;
-}
-
-struct PassArgs {
-    // scene
-    const double *src;          // N x 3 source points
-    const int32_t *perm;        // spatial order
-    int64_t N;
-    int n_chunks;
-    const double *hist;         // [pass + 1][16]: init, then the update of every pass so far
-    double *Pk;                 // N_pad x 3: transformed points in spatial order (live chunks)
-    double *Tprev;              // N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none)
-    unsigned long long *live;
-    const int32_t *live_list;   // live chunks ascending (valid outside rebuild passes)
-    // target
-    const float *tgtf;          // sorted target operand, 64 floats per 16-row tile
-    int n_tiles, n_words;
-    const float4 *tile_sph, *word_sph;
-    const double *tgt_s;        // sorted target rows, float64 x 3
-    const int32_t *tperm;       // sorted row -> target index
-    int64_t Nt;
-    const double *tgt, *nrm;
-    // parameters (the radius-dependent ones live in IcpState)
-    float Tn, T2;
-    double lo[3], hi[3];
-    int estimator;
-    int32_t *idx_out;
-    double *partials;           // n_chunks x PSTRIDE: by chunk id in a rebuild pass, by live rank otherwise
-    // Several start poses of one (scene, target) pair share a launch: pose b = blockIdx.y owns the
-    // state and the per-pose buffers (Pk, Tprev, live, live_list, hist, idx_out, partials) b * pose_stride
-    // bytes behind pose 0's.
-    size_t pose_stride;
-};
-
-template <typename T>
-__device__ __host__ __forceinline__ T *pose_ptr(T *p, size_t bytes) {
-    return (T *)((char *)p + bytes);
-}
-template <typename T>
-__device__ __host__ __forceinline__ const T *pose_ptr(const T *p, size_t bytes) {
-    return (const T *)((const char *)p + bytes);
-}
-
-// exact float64 scan of the rows of the tiles in `near` (one bit per lane's tile), 64 rows per trip
-__device__ __forceinline__ void scan_near_tiles(unsigned long long near, int unit_of_lane, const PassArgs &a, double qx,
-                                                double qy, double qz, int lane, double &bd, int &bj) {
-    while (near != 0ull) {  // wave-uniform: 64 lanes = 64 rows = 4 tiles per trip
-        int unit = -1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (near != 0ull) {
-                const int bit = __builtin_ctzll(near);
-                near &= near - 1ull;
-                const int u = __shfl(unit_of_lane, bit, 64);
-                if (g == (lane >> 4)) unit = u;
-            }
-        }
-        const int64_t row = (int64_t)unit * 16 + (lane & 15);
-        if (unit >= 0 && row < a.Nt)
-            lexmin(bd, bj, dist2(qx, qy, qz, a.tgt_s[3 * row], a.tgt_s[3 * row + 1], a.tgt_s[3 * row + 2]), a.tperm[row]);
-    }
-}
-
-// BATCH: the launch carries several poses (grid.y); a separate instantiation, so that a kernel
-// trace tells the single registration's launches from a batch's
-template <int W, bool BATCH>
-__global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(const IcpState *__restrict__ st0, const PassArgs a0) {
-    static_assert(W * 64 == 4 * CH, "four threads per slot");
-    const size_t pose_off = BATCH ? (size_t)blockIdx.y * a0.pose_stride : 0;
-    const IcpState *__restrict__ st = pose_ptr(st0, pose_off);
-    // The argument block (with this pose's pointers) is parked in LDS and read from there where it is
-    // used: held in scalar registers for the whole kernel its 40-odd fields overflow the SGPR file,
-    // and the spills -- executed at entry by EVERY launched workgroup -- left tens of MB of dirty
-    // scratch for the kernel boundary to write back.
-    __shared__ PassArgs sa;
-    if (threadIdx.x == 0) {
-        PassArgs t = a0;
-        t.Pk = pose_ptr(a0.Pk, pose_off); t.Tprev = pose_ptr(a0.Tprev, pose_off); t.live = pose_ptr(a0.live, pose_off);
-        t.live_list = pose_ptr(a0.live_list, pose_off); t.hist = pose_ptr(a0.hist, pose_off);
-        t.idx_out = pose_ptr(a0.idx_out, pose_off); t.partials = pose_ptr(a0.partials, pose_off);
-        sa = t;
-    }
-    const PassArgs &a = sa;
-    __shared__ float tri_b1[W][4 * BK_QS];
-    __shared__ int tri_t1[W][4 * BK_QS], m2key[4 * BK_QS];
-    __shared__ unsigned tl[BK_TL + 8];
-    __shared__ float4 Bs[CH], bsph[NN_SB];
-    __shared__ double sel_p[3][CH], res_d[CH], accsh[W][PSTRIDE];
-    __shared__ float sel_e[CH], sel_S[CH], cs[3][CH], rho_s[CH], rsb[NN_SB];
-    __shared__ unsigned char sel_k[CH];
-    __shared__ unsigned long long mwords[BK_WCAP];
-    __shared__ int sel_i[CH], res_j[CH], fb_slots[CH], wlist[BK_WCAP], wcnt[W], ccnt[2], misc[8];
-    __shared__ float4 wsph[BK_WCAP];
-    // the first unit's live-list entry is requested together with the state (the list has one entry
-    // per chunk, so the index is always inside it; the value is used only when it is valid)
-    int chunk_next = pose_ptr(a0.live_list, pose_off)[blockIdx.x < (unsigned)a0.n_chunks ? blockIdx.x : 0];
-    if (st->done) return;
-    __syncthreads();  // the argument block is in LDS
-    const bool rebuild = st->rebuild != 0;
-    const int n_live = st->n_live, pass = st->pass;
-    const float inf = __uint_as_float(0x7F800000u);
-    const double dinf = __longlong_as_double(0x7FF0000000000000ll);
-    const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
-    const float r_search = st->r_search;
-    // word spheres do not depend on the chunk: requested before anything else, parked in LDS
-    wsph[threadIdx.x] = a.word_sph[(int)threadIdx.x < a.n_words ? threadIdx.x : 0];
-    for (int unit = blockIdx.x;; unit += gridDim.x) {
-        // The thread index is made opaque per chunk: everything derived from it (LDS addresses, lane
-        // masks, role predicates) is then computed where it is used instead of being hoisted out of
-        // this loop and kept alive -- spilled -- through every phase.
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int frag_slot = lane & 15, frag_comp = lane >> 4;  // MFMA B fragment: slot in the sub-block, component
-        const int frag = frag_slot * 4 + frag_comp;              // float offset inside a 16-point target tile
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        // a rebuild pass visits every chunk (unit = chunk id), other passes the live list (unit = rank);
-        // `unit` also indexes the chunk's partial sums (see icp_finish_kernel)
-        int chunk;
-        if (rebuild) {
-            chunk = unit;
-            if (chunk >= a.n_chunks) break;
-        } else {
-            if (unit >= n_live) break;
-            chunk = unit == (int)blockIdx.x ? chunk_next : a.live_list[unit];
-        }
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 0);
-        // ---- 1. waves 0 and 1: transform the chunk's points (one per thread), box test, compaction of
-        // the candidates into slots -- wave 0's into slots 0.., wave 1's into slots 64.. (ascending
-        // position; no hand-over between the two waves) --, MFMA operand, filter bound, and the bounding
-        // spheres of the eight 16-slot sub-blocks (centred fp32 coordinates)
-        if (tid < CH) {
-            bool valid = false, cand = false, near = false;
-            int pi = -1;
-            double x = 0.0, y = 0.0, z = 0.0, dprev = __longlong_as_double(0x7FF8000000000000ll);
-            const int64_t k = (int64_t)chunk * CH + tid;
-            valid = k < a.N;
-            if (valid) {
-                pi = a.perm[k];
-                if (rebuild) {
-                    x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
-                    for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
-                } else {
-                    x = a.Pk[3 * k]; y = a.Pk[3 * k + 1]; z = a.Pk[3 * k + 2];
-                    const double ux = a.Tprev[3 * k], uy = a.Tprev[3 * k + 1], uz = a.Tprev[3 * k + 2];
-                    xform(st->upd, x, y, z);
-                    // Temporal coherence: last pass's neighbour is still a target point, so the new nearest
-                    // neighbour is no farther than it is now.  NaN (no neighbour last pass) fails the
-                    // comparison below and leaves the full radius.
-                    dprev = sqrt(dist2(x, y, z, ux, uy, uz));
-                }
-                const double ex = fmax(fmax(a.lo[0] - x, x - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - y, y - a.hi[1]), 0.0),
-                             ez = fmax(fmax(a.lo[2] - z, z - a.hi[2]), 0.0);
-                const double d2box = ex * ex + ey * ey + ez * ez;
-                cand = d2box <= st->r2cut;   // r2cut = r^2 (1 + 1e-12): rounding-safe
-                near = d2box <= st->r2live;
-            }
-            const unsigned long long mc = __builtin_amdgcn_ballot_w64(cand), mn = __builtin_amdgcn_ballot_w64(near);
-            const int wc = __builtin_popcountll(mc);
-            if (lane == 0) { ccnt[wv] = wc; misc[wv] = mn != 0ull; }
-            if (valid) {  // (a rebuild pass stores every chunk's coordinates; only the live ones are read again)
-                if (!cand) { a.idx_out[pi] = -1; a.Tprev[3 * k] = __longlong_as_double(0x7FF8000000000000ll); }
-                a.Pk[3 * k] = x; a.Pk[3 * k + 1] = y; a.Pk[3 * k + 2] = z;
-            }
-            const int base = wv * 64;
-            const float sx = (float)(x - ccx), sy = (float)(y - ccy), sz = (float)(z - ccz);
-            if (cand) {
-                const int sl = base + __builtin_popcountll(mc & lt);
-                Bs[sl] = make_float4(-2.0f * sx, -2.0f * sy, -2.0f * sz, 1.0f);
-                // error bound of the fp32 surrogate against the float64 distance, see pack_store()
-                const float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
-                const float Mi = 2.0f * s1 * a.Tn + a.T2;
-                sel_e[sl] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(st->r1, s1 + a.Tn) * (a.Tn + s1)) * 1.0001f;
-                sel_S[sl] = sx * sx + sy * sy + sz * sz;
-                sel_i[sl] = pi;
-                sel_k[sl] = (unsigned char)tid;
-                sel_p[0][sl] = x; sel_p[1][sl] = y; sel_p[2][sl] = z;
-                cs[0][sl] = sx; cs[1][sl] = sy; cs[2][sl] = sz;
-                // search radius of the slot: the distance to last pass's neighbour, rounded up, at most r
-                const float rp = (float)dprev * 1.00001f + 1e-5f * s1 + 1e-6f;
-                rho_s[sl] = rp < r_search ? rp : r_search;
-            }
-            if (lane >= wc) {  // dummies behind the wave's candidates: never inliers, never selected
-                const int sl = base + lane;
-                Bs[sl] = make_float4(0.f, 0.f, 0.f, 1.f);
-                sel_e[sl] = 0.f; sel_S[sl] = 3e38f; sel_i[sl] = -1;
-                sel_p[0][sl] = 0.0; sel_p[1][sl] = 0.0; sel_p[2][sl] = 0.0;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
-            const bool real = lane < wc;
-            const float px = real ? cs[0][base + lane] : 0.f, py = real ? cs[1][base + lane] : 0.f,
-                        pz = real ? cs[2][base + lane] : 0.f;
-            float rmax = real ? rho_s[base + lane] : 0.f;
-            const float big = 3e38f;
-            float lx = real ? px : big, hx = real ? px : -big, ly = real ? py : big, hy = real ? py : -big,
-                  lz = real ? pz : big, hz = real ? pz : -big;
-#pragma unroll
-            for (int off = 1; off <= 8; off <<= 1) {
-                lx = fminf(lx, __shfl_xor(lx, off, 64)); hx = fmaxf(hx, __shfl_xor(hx, off, 64));
-                ly = fminf(ly, __shfl_xor(ly, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64));
-                lz = fminf(lz, __shfl_xor(lz, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
-                rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
-            }
-            if ((lane & 15) == 0) {
-                float4 sp = make_float4(0.f, 0.f, 0.f, -1.f);  // empty sub-block: matches nothing
-                if (hx >= lx) {
-                    const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
-                    const float ex = hx - mx, ey = hy - my, ez = hz - mz;
-                    sp = make_float4(mx, my, mz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f +
-                                                     1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz)) + 1e-30f);
-                }
-                bsph[tid >> 4] = sp;
-                rsb[tid >> 4] = rmax;
-            }
-        } else {
-            for (int o = tid - CH; o < 4 * BK_QS; o += W * 64 - CH) m2key[o] = 0x7F800000;  // +inf
-            if (tid == CH) misc[2] = 0;  // ambiguous-slot counter
-        }
-        __syncthreads();
-        // candidates of the two waves: slots [0, cnt_lo) and [64, 64 + cnt_hi); a slot index below
-        // `cnt` (as the wide-sub-block test and the sphere code read it) means "real" per half
-        const int cnt_lo = ccnt[0], cnt_hi = ccnt[1];
-        const bool is_live = !rebuild || (misc[0] | misc[1]) != 0;
-        if (!is_live) {  // workgroup-uniform: the chunk stays outside the live set
-            __syncthreads();
-            continue;
-        }
-        if (rebuild && tid == 0) atomicOr(&a.live[chunk >> 6], 1ull << (chunk & 63));
-        if (cnt_lo + cnt_hi == 0) {  // workgroup-uniform
-            if (tid < PSTRIDE) a.partials[(size_t)unit * PSTRIDE + tid] = 0.0;
-            __syncthreads();
-            continue;
-        }
-        unsigned wide = 0;
-#pragma unroll
-        for (int sb = 0; sb < NN_SB; ++sb) wide |= (bsph[sb].w > st->wide_radius ? 1u : 0u) << sb;
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 1);
-        // ---- 4. culling, level 1: thread t tests the sphere of mask word t (64 tiles = 1024 sorted rows);
-        // surviving words listed in ascending order
-        {
-            const bool keepw = tid < a.n_words && near_chunk(wsph[tid], bsph, rsb, wide, cnt_lo, cnt_hi, cs, rho_s);
-            const unsigned long long km = __builtin_amdgcn_ballot_w64(keepw);
-            if (lane == 0) wcnt[wv] = __builtin_popcountll(km);
-            __syncthreads();
-            int off = 0, nsurv = 0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) { off += w < wv ? wcnt[w] : 0; nsurv += wcnt[w]; }
-            if (keepw) wlist[off + __builtin_popcountll(km & lt)] = tid;
-            if (tid == 0) misc[3] = nsurv;
-        }
-        __syncthreads();
-        const int nsurv = misc[3];
-        // ---- level 2: wave w takes the surviving words w, w + W, ...; lane l tests tile 64 word + l;
-        // the ballot is the word's tile mask.  Four sphere loads in flight per lane.
-        for (int q0 = wv; q0 < nsurv; q0 += 4 * W) {
-            int word[4];
-            float4 ts[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = q0 + u * W;
-                word[u] = q < nsurv ? wlist[q] : -1;
-                const int tile = word[u] * 64 + lane;
-                ts[u] = a.tile_sph[(word[u] >= 0 && tile < a.n_tiles) ? tile : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (word[u] < 0) continue;
-                const int tile = word[u] * 64 + lane;
-                const unsigned long long m =
-                    __builtin_amdgcn_ballot_w64(tile < a.n_tiles && near_chunk(ts[u], bsph, rsb, wide, cnt_lo, cnt_hi, cs, rho_s));
-                if (lane == 0) mwords[q0 + u * W] = m;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 2);
-        // ---- 5. sweep: the surviving tiles, ascending, in W equal pieces (rounds of BK_TL tiles)
-        int c = 0;
-        {
-            // every wave counts the survivors itself (a scan over <= BK_WCAP words)
-            for (int q0 = 0; q0 < nsurv; q0 += 64) {
-                int pc = q0 + lane < nsurv ? __builtin_popcountll(mwords[q0 + lane]) : 0;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) pc += __shfl_xor(pc, off, 64);
-                c += pc;
-            }
-            float b[NN_SB], b1[NN_SB], b2[NN_SB];
-            int t1[NN_SB];
-#pragma unroll
-            for (int sb = 0; sb < NN_SB; ++sb) {
-                const float4 v = Bs[sb * 16 + frag_slot];
-                b[sb] = frag_comp == 0 ? v.x : (frag_comp == 1 ? v.y : (frag_comp == 2 ? v.z : v.w));
-                b1[sb] = inf; b2[sb] = inf; t1[sb] = a.n_tiles;
-            }
-            for (int R0 = 0; R0 < c || R0 == 0; R0 += BK_TL) {
-                const int nr = c - R0 < BK_TL ? c - R0 : BK_TL;
-                const int piece = (((nr + W - 1) / W) + 3) & ~3;
-                const int lo = wv * piece < nr ? wv * piece : nr, hi = lo + piece < nr ? lo + piece : nr;
-                if (R0 > 0) __syncthreads();  // the previous round's list has been read
-                {   // this wave's ranks go straight to their place in the shared list
-                    int running = 0;
-                    const int r0 = R0 + lo, n_s = hi - lo;
-                    for (int q0 = 0; q0 < nsurv && running < r0 + n_s; q0 += 64) {
-                        unsigned long long word = q0 + lane < nsurv ? mwords[q0 + lane] : 0ull;
-                        const int pc = __builtin_popcountll(word);
-                        int incl = pc;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int o = __shfl_up(incl, off, 64);
-                            if (lane >= off) incl += o;
-                        }
-                        int rk = running + incl - pc;
-                        if (pc > 0 && rk < r0 + n_s && rk + pc > r0) {
-                            const unsigned tile0 = (unsigned)wlist[q0 + lane] * 64u;
-                            while (word != 0ull) {
-                                const int bit = __builtin_ctzll(word);
-                                word &= word - 1ull;
-                                if (rk >= r0 && rk < r0 + n_s) tl[rk - R0] = tile0 + (unsigned)bit;
-                                ++rk;
-                            }
-                        }
-                        running += __shfl(incl, 63, 64);
-                    }
-                    if (wv == W - 1 && lane < 8) tl[nr + lane] = (unsigned)a.n_tiles;  // pad units: rows that never win
-                }
-                __syncthreads();
-                sweep_list<1, 4>(tl + lo, hi - lo, a.tgtf, frag, b, b1, t1, b2);
-            }
-#pragma unroll
-            for (int sb = 0; sb < NN_SB; ++sb) {
-                const int o = frag_comp * BK_QS + sb * 16 + frag_slot;
-                tri_b1[wv][o] = b1[sb];
-                tri_t1[wv][o] = t1[sb];
-                atomicMin(&m2key[o], fkey(b2[sb]));
-            }
-        }
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 3);
-        __syncthreads();
-        // ---- 6. exact selection, four threads per slot (thread gl reads lane group gl of every wave's
-        // best tile): window = min b1 + 2 eps; every (wave, lane group) whose best tile is inside the
-        // window has its 4 rows re-scored in float64 (the oracle's formula, lexicographic
-        // (d^2, index) min); a second tile of one lane group inside the window sends the slot to the
-        // exact search below.
-        {
-            const int sslot = tid >> 2, gl = tid & 3;
-            const float e = sel_e[sslot], Si = sel_S[sslot];
-            const double px = sel_p[0][sslot], py = sel_p[1][sslot], pz = sel_p[2][sslot];
-            const bool live_slot = sel_i[sslot] >= 0;
-            float m = inf, sm = inf;
-            int mt = 0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const int o = gl * BK_QS + sslot;
-                const float v1 = tri_b1[w][o];
-                const int vt = tri_t1[w][o];
-                sm = v1 < m ? m : fminf(sm, v1);
-                mt = v1 < m ? vt : mt;
-                m = fminf(m, v1);
-            }
-            float m2 = fkey_inv(m2key[gl * BK_QS + sslot]);
-            float mg = fminf(m, __shfl_xor(m, 1, 64)); mg = fminf(mg, __shfl_xor(mg, 2, 64));
-            m2 = fminf(m2, __shfl_xor(m2, 1, 64)); m2 = fminf(m2, __shfl_xor(m2, 2, 64));
-            const bool maybe = mg + Si <= st->r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
-            const float win = mg + 2.0f * e;
-            double bd = dinf;
-            int bj = 0x7FFFFFFF;
-            auto rescore = [&](int tile) {
-                const int64_t row0 = (int64_t)tile * 16 + 4 * gl;  // lane group gl: rows 4 gl .. 4 gl + 3 of the tile
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + r;
-                    if (row < a.Nt)
-                        lexmin(bd, bj, dist2(px, py, pz, a.tgt_s[3 * row], a.tgt_s[3 * row + 1], a.tgt_s[3 * row + 2]),
-                               a.tperm[row]);
-                }
-            };
-            if (live_slot && maybe) {
-                if (sm <= win) {  // rare: several waves hold a tile of this lane group inside the window
-                    for (int w = 0; w < W; ++w)
-                        if (tri_b1[w][gl * BK_QS + sslot] <= win) rescore(tri_t1[w][gl * BK_QS + sslot]);
-                } else if (m <= win) {
-                    rescore(mt);
-                }
-            }
-#pragma unroll
-            for (int off = 1; off <= 2; off <<= 1) {
-                const double od = __shfl_xor(bd, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                lexmin(bd, bj, od, oj);
-            }
-            if (gl == 0) {
-                const bool found = live_slot && maybe && bj != 0x7FFFFFFF;
-                res_d[sslot] = found ? bd : dinf;
-                res_j[sslot] = found ? bj : -1;
-                if (live_slot && maybe && m2 <= win) fb_slots[atomicAdd(&misc[2], 1)] = sslot;  // ambiguous
-            }
-        }
-        __syncthreads();
-        // ---- 7. ambiguous slots: exact float64 search over the chunk's surviving tiles that also come
-        // within r of the point itself.  One wave per slot (slots w, w + W, ...), 256 tiles of the LDS
-        // list per step (four sphere loads in flight per lane); the word masks when the list did not
-        // fit one round.
-        const int nfb = misc[2];
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 4);
-        for (int f = wv; f < nfb; f += W) {
-            const int fs = fb_slots[f];
-            const double qx = sel_p[0][fs], qy = sel_p[1][fs], qz = sel_p[2][fs];
-            const float sx = cs[0][fs], sy = cs[1][fs], sz = cs[2][fs];
-            const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
-            double bd = dinf;
-            int bj = 0x7FFFFFFF;
-            auto near_tile = [&](int tile) {
-                const float4 ts = a.tile_sph[tile < 0 ? 0 : tile];
-                const float dx = ts.x - sx, dy = ts.y - sy, dz = ts.z - sz;
-                const float lim = rho_s[fs] + ts.w + slack;
-                return !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
-            };
-            if (c <= BK_TL) {
-                for (int k0 = 0; k0 < c; k0 += 256) {
-                    int tu[4];
-                    bool keep[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = k0 + 64 * u + lane;
-                        tu[u] = k < c ? (int)tl[k] : -1;
-                        keep[u] = near_tile(tu[u]) && tu[u] >= 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        scan_near_tiles(__builtin_amdgcn_ballot_w64(keep[u]), tu[u], a, qx, qy, qz, lane, bd, bj);
-                }
-            } else {
-                for (int q = 0; q < nsurv; ++q) {
-                    const unsigned long long word = mwords[q];  // wave-uniform
-                    if (word == 0ull) continue;
-                    const int tu = wlist[q] * 64 + lane;
-                    const bool keep = ((word >> lane) & 1ull) && near_tile(tu);
-                    scan_near_tiles(__builtin_amdgcn_ballot_w64(keep), tu, a, qx, qy, qz, lane, bd, bj);
-                }
-            }
-#pragma unroll
-            for (int off = 1; off <= 32; off <<= 1) {
-                const double od = __shfl_xor(bd, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                lexmin(bd, bj, od, oj);
-            }
-            if (lane == 0) {
-                res_d[fs] = bd;
-                res_j[fs] = bj == 0x7FFFFFFF ? -1 : bj;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 5);
-        // ---- 8. the chunk's partial sums (layout: see icp_accumulate_kernel).  Four threads per slot,
-        // thread g owns the packet entries k = g (mod 4); entries are summed over the wave's 16 slots
-        // by a shuffle tree, then over the waves in order: a fixed tree.
-        {
-            const int slot = tid >> 2, g = tid & 3;
-            double acc[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-            const int i = sel_i[slot];
-            int j = res_j[slot];
-            const double dd = res_d[slot];
-            if (i >= 0) {
-                if (j >= 0 && !(dd < st->r2)) j = -1;  // strict, as SearchHybrid's lower_bound
-                const int64_t kp = (int64_t)chunk * CH + sel_k[slot];
-                if (g == 0) {
-                    a.idx_out[i] = j;
-                    if (j < 0) a.Tprev[3 * kp] = __longlong_as_double(0x7FF8000000000000ll);
-                }
-                if (j >= 0) {
-                    const double sx = sel_p[0][slot], sy = sel_p[1][slot], sz = sel_p[2][slot];
-                    const double tx = a.tgt[3 * (int64_t)j], ty = a.tgt[3 * (int64_t)j + 1], tz = a.tgt[3 * (int64_t)j + 2];
-                    if (g == 0) { a.Tprev[3 * kp] = tx; a.Tprev[3 * kp + 1] = ty; a.Tprev[3 * kp + 2] = tz; }
-                    // entry k of the packet goes to thread g = k % 4, accumulator k / 4; every product is
-                    // handed over as soon as it is formed
-#define PEDP_PUT(K, V)                                   \
-    do {                                                 \
-        const double v_ = (V);                           \
-        if (g == ((K) & 3)) acc[(K) >> 2] = v_;          \
-    } while (0)
-                    if (a.estimator == PEDP_POINT_TO_PLANE) {
-                        const double nx = a.nrm[3 * (int64_t)j], ny = a.nrm[3 * (int64_t)j + 1], nz = a.nrm[3 * (int64_t)j + 2];
-                        const double r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
-                        const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
-                        int k = 0;
-#pragma unroll
-                        for (int u = 0; u < 6; ++u)
-#pragma unroll
-                            for (int v = u; v < 6; ++v) { PEDP_PUT(k, J[u] * J[v]); ++k; }
-#pragma unroll
-                        for (int u = 0; u < 6; ++u) PEDP_PUT(21 + u, J[u] * r);
-                    } else {
-                        const double s3[3] = {sx - ccx, sy - ccy, sz - ccz}, t3[3] = {tx - ccx, ty - ccy, tz - ccz};
-#pragma unroll
-                        for (int u = 0; u < 3; ++u) { PEDP_PUT(u, s3[u]); PEDP_PUT(3 + u, t3[u]); }
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-#pragma unroll
-                            for (int v = 0; v < 3; ++v) PEDP_PUT(6 + 3 * u + v, t3[u] * s3[v]);
-                    }
-                    PEDP_PUT(27, dd);
-                    PEDP_PUT(28, 1.0);
-#undef PEDP_PUT
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                double v = acc[k];
-#pragma unroll
-                for (int off = 4; off <= 32; off <<= 1) v += __shfl_xor(v, off, 64);
-                if (lane < 4) accsh[wv][4 * k + lane] = v;
-            }
-        }
-        __syncthreads();
-        if (tid < PACKET) {
-            double v = 0.0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) v += accsh[w][tid];
-            a.partials[(size_t)unit * PSTRIDE + tid] = v;
-        }
-        if (tid == PACKET) a.partials[(size_t)unit * PSTRIDE + PACKET] = (double)c;
-        if (tid == PACKET + 1) a.partials[(size_t)unit * PSTRIDE + PACKET + 1] = (double)nfb;
-        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 6);
-#if PEDP_ICP_STAMPS
-        if (tid == 1 && blockIdx.x < 4096)
-            g_icp_stamps[1][blockIdx.x][7] = ((long long)c << 32) | ((long long)nsurv << 24) | (long long)(nfb << 16) | (cnt_lo + cnt_hi);
-#endif
-        __syncthreads();  // LDS is reused by the next chunk
-    }
-}
-
 // ------------------------------------------------------------------ accumulate
 
 // Packet layout.  point-to-plane: [0..20] upper triangle of J J^T (row-major), [21..26] J r,
@@ -1914,123 +1302,263 @@ __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__
     return ok;
 }
 
+// ================================================================== fused pass
+// Radius-limited registrations (unit size 1) run ONE launch per correspondence pass:
+//   icp_pass_kernel    one workgroup (8 waves) per live scene chunk.  Every WAVE owns one 16-slot
+//                      sub-block of the chunk from the transform to the partial sums and never
+//                      waits for another wave on the way: transform, box test, compaction into the
+//                      wave's slots, the sub-block's bounding sphere, two-level culling of the target
+//                      tiles against THAT sphere, MFMA sweep of the survivors (one MFMA per tile,
+//                      the two best tiles per lane in registers), exact float64 selection, the
+//                      sub-block's partial sums of J^T J / J^T r by a fixed shuffle tree.  The eight
+//                      waves meet once, to add their sums in order.  The workgroup that finishes
+//                      last (a ticket) adds the live chunks' partial sums in ascending chunk order,
+//                      solves the 6x6 system, updates the pose, the convergence test, the motion
+//                      bound and the live list (icp_finish_body).
+//   icp_finish_kernel  the same body as a launch of its own: only where an exchange step (scene
+//                      sharded over ranks) sits between the sum and the solve.
+// Round 2 ran the chunk as eight cooperating waves with ten workgroup barriers, its triples and tile
+// lists in LDS, and the finish as a second launch: 36 + 10 us per pass of which a few hundred
+// nanoseconds were arithmetic.
+//
+// A chunk is 128 consecutive entries of the scene's spatial order.  Only LIVE chunks are visited:
+// those that had a point within r + margin of the target's bounding box when the live set was
+// last rebuilt.  A rebuild pass walks the whole scene and recomputes every point from the source
+// through the history of updates -- the same float64 operations, in the same order, as applying
+// them pass by pass, so a point's coordinates do not depend on when its chunk became live.
+// Between rebuilds a point outside the live chunks is farther than r + margin from the box; an
+// update (R, t) moves a point x by at most |R - I| |x - c| + |t + (R - I) c| (c = box centre), and
+// with e = (distance to the box) + rho (rho = half diagonal), E = r + margin + rho:
+//   e_new >= e (1 - theta) - tau   =>   e_n >= E - (Theta E + Tau) = E - mu,
+// so no such point can come within r while mu < margin; the finish requests a rebuild at
+// mu >= 0.95 margin.  Chunk ids, slot order, tile order and the order of the partial sums depend
+// only on the data, never on execution order: results are run-to-run bit-stable.
+//
+// Hand-over of the partial sums inside the launch (MI355X: per-XCD L2s are not coherent, a CU's L1
+// is never refreshed): every partial is stored write-through (sc1), every storing wave drains its
+// stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane takes an agent-scope
+// ticket; the workgroup whose ticket is the last reads every partial with sc1 loads (they bypass
+// its L1).  No fence: a release fence per workgroup writes the XCD's L2 back and took the pass from
+// 36 to 92 us in round 2.  The live mask words are only ever touched by agent-scope atomics.
+constexpr int CH = NN_SB * 16;   // 128 scene points per chunk = slots per scene block
+constexpr int BK_W = 8;          // waves of a pass workgroup = sub-blocks of a chunk
+constexpr int BK_WCAP = BK_W * 64;  // mask words (64 tiles each) the fused pass handles: 524,288 target points
+constexpr int PSTRIDE = 32;      // doubles per chunk in the partials: packet, [29] wave-tiles swept, [30] exact searches
+constexpr int LIVE_CAP = 8192;   // live chunks the finish kernel lists in LDS (1M scene points)
+constexpr int WTL = 1024;        // tiles a wave lists before it sweeps them
+constexpr int L2_WORDS = 8;      // mask words whose tile spheres a wave requests at once
+constexpr int SW_G = 8;          // tiles per group of the sweep (A fragments fetched one group ahead)
+
+__device__ __forceinline__ void xform(const double *__restrict__ M, double &x, double &y, double &z) {
+    const double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+    const double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+    const double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+    x = nx; y = ny; z = nz;
+}
+
+struct PassArgs {
+    // scene
+    const double *src;          // N x 3 source points
+    const int32_t *perm;        // spatial order
+    int64_t N;
+    int n_chunks;
+    double *hist;               // [pass + 1][16]: init, then the update of every pass so far
+    double *Pk;                 // N_pad x 3: transformed points in spatial order (live chunks)
+    double *Tprev;              // N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none)
+    unsigned long long *live;
+    int32_t *live_list;         // live chunks ascending (valid outside rebuild passes)
+    // target
+    const float *tgtf;          // sorted target operand, 64 floats per 16-row tile
+    int n_tiles, n_words;
+    const float4 *tile_sph, *word_sph;
+    const double *tgt_s;        // sorted target rows, float64 x 6: x y z nx ny nz
+    const int32_t *tperm;       // sorted row -> target index
+    int64_t Nt;
+    const double *tgt, *nrm;
+    // parameters (the radius-dependent ones live in IcpState)
+    float Tn, T2;
+    double lo[3], hi[3];
+    int estimator;
+    int32_t *idx_out;
+    double *partials;           // n_chunks x PSTRIDE: by chunk id in a rebuild pass, by live rank otherwise
+    // Several start poses of one (scene, target) pair share a launch: pose b = blockIdx.y owns the
+    // state and the per-pose buffers (Pk, Tprev, live, live_list, hist, idx_out, partials, packet)
+    // b * pose_stride bytes behind pose 0's.
+    size_t pose_stride;
+    // the finish inside the launch (fuse != 0)
+    int fuse, n_lw, hand;
+    double *packet, *trace;
+    double bc[3];               // centre of the target's box (motion bound)
+};
+
+template <typename T>
+__device__ __host__ __forceinline__ T *pose_ptr(T *p, size_t bytes) {
+    return (T *)((char *)p + bytes);
+}
+template <typename T>
+__device__ __host__ __forceinline__ const T *pose_ptr(const T *p, size_t bytes) {
+    return (const T *)((const char *)p + bytes);
+}
+
+// ------------------------------------------------------------------ finish
 // phase 0: sum the live chunks' partials, solve, update (one GPU); phase 1: sum only (the packet
 // then goes through the all-reduce); phase 2: solve from the summed packet.
-// Order of the sum: 8 contiguous ranges of live-mask words, chunks ascending inside a range, then
-// the ranges in order -- a function of the live set alone.
-constexpr int FIN_THREADS = 1024;
-__global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, unsigned long long *live, int32_t *live_list,
-                                                         int n_lw, const double *partials, double *packet, int phase, int estimator,
-                                                         double *__restrict__ trace, double *__restrict__ hist,
-                                                         double bcx, double bcy, double bcz, size_t pose_stride) {
-    {   // pose b = blockIdx.x of a batch: its state and buffers are b * pose_stride bytes behind pose 0's
-        const size_t off = (size_t)blockIdx.x * pose_stride;
-        st = pose_ptr(st, off); live = pose_ptr(live, off); live_list = pose_ptr(live_list, off);
-        partials = pose_ptr(partials, off); packet = pose_ptr(packet, off); hist = pose_ptr(hist, off);
-    }
-    if (st->done) return;
+// Order of the sum: 32 contiguous ranges of the live chunks, ascending inside a range, then the
+// ranges in order -- a function of the live set alone, whatever the number of threads.
+struct FinishArgs {
+    unsigned long long *live;
+    int32_t *live_list;
+    int n_lw;
+    const double *partials;
+    double *packet;
+    int phase, estimator;
+    double *trace, *hist;
+    double bcx, bcy, bcz;
+};
+template <int NT, int LCAP>
+struct FinishLds {
+    double slice[32][32], pk[32];
+    int scan[NT], lst[LCAP];
+    int do_rebuild, n_live_s;
+};
+// COHERENT: the partial sums and the live mask were written earlier in THIS launch by other
+// workgroups (sc1 stores / atomics): read them past this CU's L1 -- global_load ... sc1, never a
+// flat_ load (the pointers come out of the LDS-parked argument block, so the address space is
+// stated here).
+typedef __attribute__((address_space(1))) unsigned long long g_u64;
+typedef __attribute__((address_space(1))) int g_i32;
+typedef __attribute__((address_space(1))) unsigned g_u32;
+__device__ __forceinline__ double load_sc1(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((g_u64 *)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int load_sc1(const int32_t *p) {
+    return __hip_atomic_load((g_i32 *)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_sc1(double *p, double v) {
+    __hip_atomic_store((g_u64 *)(uintptr_t)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COHERENT>
+__device__ __forceinline__ double load_partial(const double *p) {
+    return COHERENT ? load_sc1(p) : *p;
+}
+template <bool COHERENT>
+__device__ __forceinline__ unsigned long long load_live(unsigned long long *p) {
+    if (COHERENT) return __hip_atomic_fetch_or((g_u64 *)(uintptr_t)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <int NT, int LCAP, bool COHERENT>
+__device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &f, FinishLds<NT, LCAP> &L, const int tid) {
     const int pass = st->pass, max_iter = st->max_iter;
     const double n_source = st->n_source, rel_fitness = st->rel_fitness, rel_rmse = st->rel_rmse, reachE = st->reachE,
                  margin = st->margin;
-    constexpr int PARTS = FIN_THREADS / 32;
-    __shared__ double slice[PARTS][32], pk[32];
-    __shared__ int lst[LIVE_CAP], scan[FIN_THREADS];
-    __shared__ int do_rebuild, n_live_s;
-    const int tid = threadIdx.x;
+    constexpr int PARTS = 32, TPARTS = NT / 32, PPT = PARTS / TPARTS;  // ranges; ranges in flight; ranges per thread
+    static_assert(NT % 32 == 0 && PARTS % TPARTS == 0, "thread count");
     if (tid == 0) PEDP_STAMP(2, 0, 0);
+    if (tid == 0 && pass == 5) PEDP_STAMP(2, 3, 0);
 #if PEDP_ICP_STAMPS
     if (tid == 0) { g_icp_stamps[2][1][0] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][1] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
-    if (phase != 2) {
-        // Partial sums are indexed by chunk id in a rebuild pass and by live rank otherwise (see
-        // icp_patch_kernel); either way they are summed in ascending chunk order.
+    if (f.phase != 2) {
+        // Partial sums are indexed by chunk id in a rebuild pass and by live rank otherwise; either
+        // way they are summed in ascending chunk order.
         const bool listing = st->rebuild != 0;
         int n_live = st->n_live;
         bool listed = true;
         if (listing) {
             // the new live list, ascending: thread t owns a contiguous range of mask words
-            const int per = (n_lw + FIN_THREADS - 1) / FIN_THREADS;
-            const int w_lo = tid * per < n_lw ? tid * per : n_lw, w_hi = w_lo + per < n_lw ? w_lo + per : n_lw;
+            const int per = (f.n_lw + NT - 1) / NT;
+            const int w_lo = tid * per < f.n_lw ? tid * per : f.n_lw, w_hi = w_lo + per < f.n_lw ? w_lo + per : f.n_lw;
             int mine = 0;
-            for (int wi = w_lo; wi < w_hi; ++wi) mine += __builtin_popcountll(live[wi]);
-            scan[tid] = mine;
+            unsigned long long first = 0ull;  // (per == 1 for scenes up to 64 NT chunks: the word is read once)
+            for (int wi = w_lo; wi < w_hi; ++wi) {
+                const unsigned long long word = load_live<COHERENT>(&f.live[wi]);
+                if (wi == w_lo) first = word;
+                mine += __builtin_popcountll(word);
+            }
+            L.scan[tid] = mine;
             __syncthreads();
-            for (int off = 1; off < FIN_THREADS; off <<= 1) {
-                const int t = tid >= off ? scan[tid - off] : 0;
+            for (int off = 1; off < NT; off <<= 1) {
+                const int t = tid >= off ? L.scan[tid - off] : 0;
                 __syncthreads();
-                scan[tid] += t;
+                L.scan[tid] += t;
                 __syncthreads();
             }
-            n_live = scan[FIN_THREADS - 1];
-            listed = n_live <= LIVE_CAP;
-            int at = scan[tid] - mine;
+            n_live = L.scan[NT - 1];
+            listed = n_live <= LCAP;
+            int at = L.scan[tid] - mine;
             for (int wi = w_lo; wi < w_hi; ++wi) {
-                unsigned long long word = live[wi];
+                unsigned long long word = wi == w_lo ? first : load_live<COHERENT>(&f.live[wi]);
                 while (word != 0ull) {
                     const int chunk = wi * 64 + __builtin_ctzll(word);
                     word &= word - 1ull;
-                    if (listed) lst[at] = chunk;
-                    live_list[at] = chunk;
+                    if (listed) L.lst[at] = chunk;
+                    f.live_list[at] = chunk;
                     ++at;
                 }
             }
             __syncthreads();
         }
         // PARTS contiguous ranges of the live chunks, ascending inside a range, then the ranges in
-        // order: a function of the live set alone.  Up to sixteen loads in flight per thread.
-        const int k = tid & 31, part = tid >> 5;
+        // order.  Sixteen loads in flight per thread and range; branch-free (an entry beyond the range
+        // reads the range's last chunk again and is not added), the three ways to a chunk's position in
+        // the partials -- live rank; list in LDS; list in memory, written a moment ago by this workgroup:
+        // read past L1 -- are told apart outside the loops.
+        const int k = tid & 31;
         const int lper = (n_live + PARTS - 1) / PARTS;
-        const int l_lo = part * lper < n_live ? part * lper : n_live, l_hi = l_lo + lper < n_live ? l_lo + lper : n_live;
-        double v = 0.0;
-        if (k < PACKET + 2) {
-            int q = l_lo;
-            for (; q + 16 <= l_hi; q += 16) {
-                double x[16];
+        auto sum_ranges = [&](auto position) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int at = listing ? (listed ? lst[q + u] : live_list[q + u]) : q + u;
-                    x[u] = partials[(size_t)at * PSTRIDE + k];
+            for (int pp = 0; pp < PPT; ++pp) {
+                const int part = (tid >> 5) + pp * TPARTS;
+                const int l_lo = part * lper < n_live ? part * lper : n_live, l_hi = l_lo + lper < n_live ? l_lo + lper : n_live;
+                double v = 0.0;
+                if (k < PACKET + 2) {
+                    for (int q = l_lo; q < l_hi; q += 16) {
+                        int at[16];
+                        double x[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) at[u] = position(q + u < l_hi ? q + u : l_hi - 1);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) x[u] = load_partial<COHERENT>(&f.partials[(size_t)at[u] * PSTRIDE + k]);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v = q + u < l_hi ? v + x[u] : v;
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v += x[u];
+                L.slice[part][k] = v;
             }
-            double x[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const bool in = q + u < l_hi;
-                const int at = !in ? 0 : (listing ? (listed ? lst[q + u] : live_list[q + u]) : q + u);
-                x[u] = in ? partials[(size_t)at * PSTRIDE + k] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (q + u < l_hi) v += x[u];
-        }
-        slice[part][k] = v;
-        if (tid == 0) n_live_s = n_live;
+        };
+        if (!listing) sum_ranges([&](int q) { return q; });
+        else if (listed) sum_ranges([&](int q) { return L.lst[q]; });
+        else sum_ranges([&](int q) { return load_sc1(&f.live_list[q]); });
+        if (tid == 0 && pass == 5) PEDP_STAMP(2, 3, 1);
+        if (tid == 0) L.n_live_s = n_live;
         __syncthreads();
+        if (tid == 0 && pass == 5) PEDP_STAMP(2, 3, 2);
         if (tid < 32) {
             double t = 0.0;
-            for (int q = 0; q < PARTS; ++q) t += slice[q][tid];
-            pk[tid] = t;
-            if (tid < PACKET) packet[tid] = t;
+            for (int q = 0; q < PARTS; ++q) t += L.slice[q][tid];
+            L.pk[tid] = t;
+            if (tid < PACKET) f.packet[tid] = t;
         }
         __syncthreads();
         if (tid == 0) {
-            st->sum_tiles += (long long)pk[PACKET];
-            st->sum_fb += (long long)pk[PACKET + 1];
-            st->n_live = n_live_s;
+            st->sum_tiles += (long long)L.pk[PACKET];
+            st->sum_fb += (long long)L.pk[PACKET + 1];
+            st->n_live = L.n_live_s;
 #if PEDP_ICP_STAMPS
             g_icp_stamps[2][1][2] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
         }
-        if (phase == 1) return;
+        if (f.phase == 1) return;
     } else {
-        if (tid < PACKET) pk[tid] = packet[tid];
+        if (tid < PACKET) L.pk[tid] = f.packet[tid];
         __syncthreads();
     }
     if (tid == 0) {
         PEDP_STAMP(2, 0, 1);
-        do_rebuild = 0;
+        if (pass == 5) PEDP_STAMP(2, 3, 3);
+        L.do_rebuild = 0;
+        const double *pk = L.pk;
         const double K = pk[28];
         double fit = 0.0, rmse = 0.0;
         if (K > 0.0) { fit = K / n_source; rmse = sqrt(pk[27] / K); }
@@ -2038,8 +1566,8 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
         st->prev_rmse = st->rmse;
         st->fitness = fit;
         st->rmse = rmse;
-        if (trace) {
-            double *tr = trace + 18 * pass;
+        if (f.trace) {
+            double *tr = f.trace + 18 * pass;
             tr[0] = fit; tr[1] = rmse;
             for (int k = 0; k < 16; ++k) tr[2 + k] = st->T[k];
         }
@@ -2052,8 +1580,9 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
             double upd[16];
             ident4(upd);
             PEDP_STAMP(2, 2, 0);
+            if (pass == 5) PEDP_STAMP(2, 3, 4);
             if (K > 0.0) {
-                if (estimator == PEDP_POINT_TO_PLANE) {
+                if (f.estimator == PEDP_POINT_TO_PLANE) {
                     double A[36], nb[6], x[6];
                     int k = 0;
 #pragma unroll
@@ -2087,14 +1616,15 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
                 }
             }
             PEDP_STAMP(2, 0, 2);
-            for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; hist[16 * (pass + 1) + k] = upd[k]; }
+            if (pass == 5) PEDP_STAMP(2, 3, 5);
+            for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; f.hist[16 * (pass + 1) + k] = upd[k]; }
             mat4_mul_dev(upd, st->T, st->T);
             // how far this update can move a point near the target: |R - I|_F (>= the spectral norm) and
             // |t + (R - I) c| about the box centre c
             double th2 = 0.0, tv[3];
             for (int u = 0; u < 3; ++u) {
                 tv[u] = upd[4 * u + 3];
-                const double cc[3] = {bcx, bcy, bcz};
+                const double cc[3] = {f.bcx, f.bcy, f.bcz};
                 for (int v = 0; v < 3; ++v) {
                     const double dlt = upd[4 * u + v] - (u == v ? 1.0 : 0.0);
                     th2 += dlt * dlt;
@@ -2105,20 +1635,620 @@ __global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, u
             st->mu_tau += sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
             const double mu = st->mu_theta * reachE + st->mu_tau;
             if (!(mu < 0.95 * margin)) {  // also when mu is NaN
-                do_rebuild = 1;
+                L.do_rebuild = 1;
                 st->mu_theta = 0.0;
                 st->mu_tau = 0.0;
                 st->n_rebuilds += 1;
             }
-            st->rebuild = do_rebuild;
+            st->rebuild = L.do_rebuild;
             st->pass = pass + 1;
             PEDP_STAMP(2, 2, 3);
+            if (pass == 5) PEDP_STAMP(2, 3, 6);
         }
         PEDP_STAMP(2, 0, 3);
     }
     __syncthreads();
-    if (do_rebuild)
-        for (int wi = tid; wi < n_lw; wi += FIN_THREADS) live[wi] = 0ull;
+    if (L.do_rebuild)
+        for (int wi = tid; wi < f.n_lw; wi += NT) f.live[wi] = 0ull;
+}
+
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void icp_finish_kernel(IcpState *st, unsigned long long *live, int32_t *live_list,
+                                                         int n_lw, const double *partials, double *packet, int phase, int estimator,
+                                                         double *__restrict__ trace, double *__restrict__ hist,
+                                                         double bcx, double bcy, double bcz, size_t pose_stride) {
+    {   // pose b = blockIdx.x of a batch: its state and buffers are b * pose_stride bytes behind pose 0's
+        const size_t off = (size_t)blockIdx.x * pose_stride;
+        st = pose_ptr(st, off); live = pose_ptr(live, off); live_list = pose_ptr(live_list, off);
+        partials = pose_ptr(partials, off); packet = pose_ptr(packet, off); hist = pose_ptr(hist, off);
+    }
+    if (st->done) return;
+    __shared__ FinishLds<FIN_THREADS, LIVE_CAP> L;
+    FinishArgs f;
+    f.live = live; f.live_list = live_list; f.n_lw = n_lw; f.partials = partials; f.packet = packet; f.phase = phase;
+    f.estimator = estimator; f.trace = trace; f.hist = hist; f.bcx = bcx; f.bcy = bcy; f.bcz = bcz;
+    icp_finish_body<FIN_THREADS, LIVE_CAP, false>(st, f, L, threadIdx.x);
+}
+
+// ------------------------------------------------------------------ pass
+// exact float64 scan of the rows of the tiles in `near` (one bit per lane's tile), 64 rows per trip
+__device__ __forceinline__ void scan_near_tiles(unsigned long long near, int unit_of_lane, const PassArgs &a, double qx,
+                                                double qy, double qz, int lane, double &bd, int &bj) {
+    while (near != 0ull) {  // wave-uniform: 64 lanes = 64 rows = 4 tiles per trip
+        int unit = -1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (near != 0ull) {
+                const int bit = __builtin_ctzll(near);
+                near &= near - 1ull;
+                const int u = __shfl(unit_of_lane, bit, 64);
+                if (g == (lane >> 4)) unit = u;
+            }
+        }
+        const int64_t row = (int64_t)unit * 16 + (lane & 15);
+        if (unit >= 0 && row < a.Nt)
+            lexmin(bd, bj, dist2(qx, qy, qz, a.tgt_s[6 * row], a.tgt_s[6 * row + 1], a.tgt_s[6 * row + 2]), a.tperm[row]);
+    }
+}
+
+// The MFMA loop of one wave over the n tiles of its LDS list against ITS sub-block (B operand b):
+// per lane -- slot lane & 15, target rows 4 (lane >> 4) .. + 3 of every tile -- the two best tiles
+// (value, tile) and the third-best value.  One MFMA per tile; the A fragments of the next SW_G tiles
+// are requested before this group's MFMAs are issued.  Pad tiles (rows that never win) follow the
+// list's last entry.
+__device__ __forceinline__ void sweep_sub_block(const unsigned *__restrict__ list, int n, const float *__restrict__ tgtf,
+                                                int frag, float b, float &b1, int &t1, float &b2, int &t2, float &b3) {
+    if (n <= 0) return;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float a[SW_G];
+    unsigned un[SW_G];
+#pragma unroll
+    for (int g = 0; g < SW_G; ++g) {
+        un[g] = list[g];
+        a[g] = tgtf[(size_t)un[g] * 64 + frag];
+    }
+    for (int k = 0; k < n; k += SW_G) {
+        float an[SW_G];
+        unsigned unn[SW_G];
+#pragma unroll
+        for (int g = 0; g < SW_G; ++g) {
+            unn[g] = list[k + SW_G + g];  // pad tiles follow the last real one
+            an[g] = tgtf[(size_t)unn[g] * 64 + frag];
+        }
+        f32x4 acc[SW_G];
+#pragma unroll
+        for (int g = 0; g < SW_G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], b, zero, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < SW_G; ++g) {
+            const float v = fminf(fminf(fminf(acc[g][0], acc[g][1]), acc[g][2]), acc[g][3]);
+            const int tile = (int)un[g];
+            const bool lt1 = v < b1, lt2 = v < b2;
+            t2 = lt1 ? t1 : (lt2 ? tile : t2);
+            t1 = lt1 ? tile : t1;
+            b3 = __builtin_amdgcn_fmed3f(b2, b3, v);  // b2 <= b3: the third smallest of the four
+            b2 = __builtin_amdgcn_fmed3f(b1, b2, v);  // b1 <= b2
+            b1 = fminf(b1, v);
+        }
+#pragma unroll
+        for (int g = 0; g < SW_G; ++g) { a[g] = an[g]; un[g] = unn[g]; }
+    }
+}
+
+// BATCH: the launch carries several poses (grid.y); a separate instantiation, so that a kernel
+// trace tells the single registration's launches from a batch's
+template <int W, bool BATCH>
+__global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, const PassArgs a0) {
+    static_assert(W == 8 && CH == 128, "a chunk is two halves of four 16-slot sub-blocks");
+    const size_t pose_off = BATCH ? (size_t)blockIdx.y * a0.pose_stride : 0;
+    IcpState *st = pose_ptr(st0, pose_off);
+    // The argument block (with this pose's pointers) is parked in LDS and read from there where it is
+    // used: held in scalar registers for the whole kernel its 40-odd fields overflow the SGPR file,
+    // and the spills -- executed at entry by EVERY launched workgroup -- left tens of MB of dirty
+    // scratch for the kernel boundary to write back.
+    __shared__ PassArgs sa;
+    __shared__ FinishLds<W * 64, 2048> fin;
+    // a wave's slots (its sub-block): written and read by that wave only
+    __shared__ double wp[W][3][16], accsh[W][PSTRIDE];
+    __shared__ float wcs[W][3][16], weps[W][16], wS[W][16], wrho[W][16];
+    __shared__ int wpi[W][16], wkk[W][16], misc[8];
+    __shared__ unsigned wtl[W][WTL + 2 * SW_G];
+    __shared__ float4 wnode[W][16];
+    __shared__ float wnode_r[W][16];
+    if (threadIdx.x == 0) {
+        PassArgs t = a0;
+        t.Pk = pose_ptr(a0.Pk, pose_off); t.Tprev = pose_ptr(a0.Tprev, pose_off); t.live = pose_ptr(a0.live, pose_off);
+        t.live_list = pose_ptr(a0.live_list, pose_off); t.hist = pose_ptr(a0.hist, pose_off);
+        t.idx_out = pose_ptr(a0.idx_out, pose_off); t.partials = pose_ptr(a0.partials, pose_off);
+        t.packet = pose_ptr(a0.packet, pose_off);
+        sa = t;
+    }
+    const PassArgs &a = sa;
+#if PEDP_ICP_STAMPS
+    const long long rt_entry = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // the first unit's live-list entry is requested together with the state (the list has one entry
+    // per chunk, so the index is always inside it; the value is used only when it is valid)
+    int chunk_next = pose_ptr(a0.live_list, pose_off)[blockIdx.x < (unsigned)a0.n_chunks ? blockIdx.x : 0];
+    // word spheres do not depend on the chunk: the first 64 are requested before anything else (lane l: word l)
+    const float4 ws0 = a0.word_sph[(int)(threadIdx.x & 63) < a0.n_words ? (threadIdx.x & 63) : 0];
+    if (st->done) return;
+    const bool rebuild = st->rebuild != 0;
+    const int n_live = st->n_live, pass = st->pass;
+    // EVERY workgroup of the launch takes a ticket, also those without a chunk: the pass is closed --
+    // and the state rewritten -- only after all of them have read the state (a batch's grid is not
+    // resident at once; a workgroup that starts late must not find the next pass's state)
+    const int n_wg = (int)gridDim.x;
+#if PEDP_ICP_STAMPS
+    if (threadIdx.x == 0 && pass < 32 && blockIdx.x < 512 && blockIdx.y == 0) g_icp_rt[pass][blockIdx.x][0] = rt_entry;
+#endif
+    PEDP_RT(pass, 1);
+    __syncthreads();  // the argument block is in LDS
+    const float inf = __uint_as_float(0x7F800000u);
+    const double dinf = __longlong_as_double(0x7FF0000000000000ll);
+    const double dnan = __longlong_as_double(0x7FF8000000000000ll);
+    const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
+    const float r_search = st->r_search;
+    for (int unit = blockIdx.x;; unit += gridDim.x) {
+        // The thread index is made opaque per chunk: everything derived from it (LDS addresses, lane
+        // masks, role predicates) is then computed where it is used instead of being hoisted out of
+        // this loop and kept alive -- spilled -- through every phase.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int half = wv >> 2, q4 = wv & 3;   // the wave's half of the chunk (64 points), its quarter of the half's slots
+        const int j = lane & 15, g = lane >> 4;  // MFMA layout: slot of the sub-block, row group / component
+        const int frag = j * 4 + g;              // float offset inside a 16-point target tile
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // a rebuild pass visits every chunk (unit = chunk id), other passes the live list (unit = rank);
+        // `unit` also indexes the chunk's partial sums (see icp_finish_body)
+        int chunk;
+        if (rebuild) {
+            chunk = unit;
+            if (chunk >= a.n_chunks) break;
+        } else {
+            if (unit >= n_live) break;
+            chunk = unit == (int)blockIdx.x ? chunk_next : a.live_list[unit];
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 0);
+        PEDP_WV(0, __builtin_amdgcn_s_memtime());
+        // ---- 1. every wave transforms the 64 points of its half (the four waves of a half do the same
+        // arithmetic and get the same ballots; quarter 0 stores), box test, compaction of the candidates:
+        // the half's candidates in ascending position take the half's slots 0.., the wave keeps those
+        // whose rank falls into its quarter
+        int nsl;  // real slots of this wave's sub-block
+        bool st_valid, st_cand;  // what quarter 0 stores once every wave of the chunk has read its inputs
+        int st_pi;
+        int64_t st_k;
+        double st_x, st_y, st_z;
+        {
+            bool cand = false, near = false;
+            int pi = -1;
+            double x = 0.0, y = 0.0, z = 0.0, dprev = dnan;
+            const int64_t k = (int64_t)chunk * CH + half * 64 + lane;
+            const bool valid = k < a.N;
+            if (valid) {
+                pi = a.perm[k];
+                if (rebuild) {
+                    x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
+                    for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                } else {
+                    x = a.Pk[3 * k]; y = a.Pk[3 * k + 1]; z = a.Pk[3 * k + 2];
+                    const double ux = a.Tprev[3 * k], uy = a.Tprev[3 * k + 1], uz = a.Tprev[3 * k + 2];
+                    xform(st->upd, x, y, z);
+                    // Temporal coherence: last pass's neighbour is still a target point, so the new nearest
+                    // neighbour is no farther than it is now.  NaN (no neighbour last pass) fails the
+                    // comparison below and leaves the full radius.
+                    dprev = sqrt(dist2(x, y, z, ux, uy, uz));
+                }
+                const double ex = fmax(fmax(a.lo[0] - x, x - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - y, y - a.hi[1]), 0.0),
+                             ez = fmax(fmax(a.lo[2] - z, z - a.hi[2]), 0.0);
+                const double d2box = ex * ex + ey * ey + ez * ez;
+                cand = d2box <= st->r2cut;   // r2cut = r^2 (1 + 1e-12): rounding-safe
+                near = d2box <= st->r2live;
+            }
+            const unsigned long long mc = __builtin_amdgcn_ballot_w64(cand), mn = __builtin_amdgcn_ballot_w64(near);
+            const int wc = __builtin_popcountll(mc);
+            if (q4 == 0 && lane == 0) misc[half] = mn != 0ull;
+            st_valid = valid; st_cand = cand; st_pi = pi; st_k = k; st_x = x; st_y = y; st_z = z;
+            const int sl = __builtin_popcountll(mc & lt) - 16 * q4;
+            if (cand && sl >= 0 && sl < 16) {
+                const float sx = (float)(x - ccx), sy = (float)(y - ccy), sz = (float)(z - ccz);
+                // error bound of the fp32 surrogate against the float64 distance
+                const float s1 = fabsf(sx) + fabsf(sy) + fabsf(sz);
+                const float Mi = 2.0f * s1 * a.Tn + a.T2;
+                weps[wv][sl] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(st->r1, s1 + a.Tn) * (a.Tn + s1)) * 1.0001f;
+                wS[wv][sl] = sx * sx + sy * sy + sz * sz;
+                wpi[wv][sl] = pi;
+                wkk[wv][sl] = half * 64 + lane;
+                wp[wv][0][sl] = x; wp[wv][1][sl] = y; wp[wv][2][sl] = z;
+                wcs[wv][0][sl] = sx; wcs[wv][1][sl] = sy; wcs[wv][2][sl] = sz;
+                // search radius of the slot: the distance to last pass's neighbour, rounded up, at most r
+                const float rp = (float)dprev * 1.00001f + 1e-5f * s1 + 1e-6f;
+                wrho[wv][sl] = rp < r_search ? rp : r_search;
+            }
+            nsl = wc - 16 * q4;
+            nsl = nsl < 0 ? 0 : (nsl > 16 ? 16 : nsl);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+        }
+        // The four waves of a half read the same points and previous neighbours; the one that stores the
+        // transformed points does so only after all of them have (a wave that came late would otherwise
+        // transform a point twice).
+        __syncthreads();
+        if (q4 == 0 && st_valid) {  // (a rebuild pass stores every chunk's coordinates; only the live ones are read again)
+            if (!st_cand) { a.idx_out[st_pi] = -1; a.Tprev[3 * st_k] = dnan; }
+            a.Pk[3 * st_k] = st_x; a.Pk[3 * st_k + 1] = st_y; a.Pk[3 * st_k + 2] = st_z;
+        }
+        if (rebuild) {  // is the chunk live?  (both halves' flags)
+            const bool is_live = (misc[0] | misc[1]) != 0;
+            if (!is_live) {  // workgroup-uniform: the chunk stays outside the live set
+                __syncthreads();  // (the flags are rewritten by the next chunk)
+                continue;
+            }
+            if (tid == 0) __hip_atomic_fetch_or((g_u64 *)(uintptr_t)&a.live[chunk >> 6], 1ull << (chunk & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 1);
+        PEDP_WV(1, __builtin_amdgcn_s_memtime());
+        const bool real = j < nsl;
+        double fd = dinf;      // the slot's result: squared distance, target index (-1: none), neighbour and normal
+        int fj = -1;
+        double wt[3] = {0.0, 0.0, 0.0}, wn[3] = {0.0, 0.0, 0.0};
+        bool have_tn = false;
+        int ntl_w = 0, nfb_w = 0;
+        if (nsl > 0) {  // wave-uniform
+            // ---- 2. what the target's spheres are tested against: a COVER of the sub-block's slots by bounding
+            // spheres (centred fp32 coordinates), each with the largest search radius of its slots.  The slots'
+            // binary tree -- pairs, quads, octets, all sixteen: the levels of a butterfly reduction -- is cut
+            // where a node's sphere is no wider than r.  A compact sub-block is one node; 16 consecutive points
+            // of the spatial order that straddle a jump of the curve (a WIDE sub-block) come out as the few
+            // compact groups they really are, down to single points, instead of one huge ball whose tiles
+            // would all have to be swept.  Nodes live in the wave's LDS; the first also in registers.
+            const float px = real ? wcs[wv][0][j] : 0.f, py = real ? wcs[wv][1][j] : 0.f, pz = real ? wcs[wv][2][j] : 0.f;
+            const float rho_j = real ? wrho[wv][j] : 0.f;
+            int nn;  // nodes of the cover
+            {
+                const float big = 3e38f, wr = st->wide_radius;
+                float lx = real ? px : big, hx = real ? px : -big, ly = real ? py : big, hy = real ? py : -big,
+                      lz = real ? pz : big, hz = real ? pz : -big, rmx = rho_j;
+                // level 0: the point itself, widened by the rounding of its centred coordinates
+                float4 node = make_float4(px, py, pz, 1e-5f * (fabsf(px) + fabsf(py) + fabsf(pz)) + 1e-6f);
+                float node_r = rho_j;
+                bool open = real;   // no level of this lane's chain is in the cover yet
+                bool mine = false;  // this lane holds a node of the cover
+                int cut = 0;        // a chain inside this lane's current node has been closed
+#pragma unroll
+                for (int lev = 1; lev <= 4; ++lev) {
+                    const int off = 1 << (lev - 1);
+                    lx = fminf(lx, __shfl_xor(lx, off, 64)); hx = fmaxf(hx, __shfl_xor(hx, off, 64));
+                    ly = fminf(ly, __shfl_xor(ly, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64));
+                    lz = fminf(lz, __shfl_xor(lz, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
+                    rmx = fmaxf(rmx, __shfl_xor(rmx, off, 64));
+                    const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
+                    const float ex = hx - mx, ey = hy - my, ez = hz - mz;
+                    const float rad = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz)) + 1e-30f;
+                    // a node is cut where its sphere is wider than r -- or where a part of it has been cut already
+                    // (so that rounding can never leave a slot outside the cover); lanes of one node agree
+                    cut |= __shfl_xor(cut, off, 64);
+                    const bool wide_here = rad > wr || cut != 0;
+                    // the level below is in the cover where this level is cut: its nodes close their chains
+                    if (open && wide_here) { mine = (j & (off - 1)) == 0; open = false; cut = 1; }
+                    if (open) { node = make_float4(mx, my, mz, rad); node_r = rmx; }
+                }
+                if (open) mine = j == 0;  // the whole sub-block is one node
+                const unsigned long long nm = __builtin_amdgcn_ballot_w64(mine && g == 0);
+                nn = __builtin_popcountll(nm);
+                if (mine && g == 0) {
+                    const int at = __builtin_popcountll(nm & lt);
+                    wnode[wv][at] = node;
+                    wnode_r[wv][at] = node_r;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+            }
+            const float4 node0 = wnode[wv][0];
+            const float node0_r = wnode_r[wv][0];
+            // Can a target sphere ts (a tile's, or a whole mask word's) hold the nearest neighbour of a slot
+            // of this sub-block?  Every slot has a search radius rho <= r, a node the largest of its slots'.
+            auto near_sb = [&](const float4 &ts) -> bool {
+                const float dx = ts.x - node0.x, dy = ts.y - node0.y, dz = ts.z - node0.z;
+                const float lim = node0_r + node0.w + ts.w;
+                bool any = !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f);
+#pragma nounroll
+                for (int i = 1; i < nn; ++i) {  // wave-uniform; broadcast reads
+                    const float4 nd = wnode[wv][i];
+                    const float ex = ts.x - nd.x, ey = ts.y - nd.y, ez = ts.z - nd.z;
+                    const float li = wnode_r[wv][i] + nd.w + ts.w;
+                    any |= !((ex * ex + ey * ey + ez * ez) > li * li * 1.00001f + 1e-6f);
+                }
+                return any && ts.w >= 0.f;
+            };
+            // MFMA B operand of the sub-block: (-2x', -2y', -2z', 1) per slot, dummies (0, 0, 0, 1)
+            const float bfrag = g == 3 ? 1.0f : (real ? -2.0f * wcs[wv][g < 3 ? g : 0][j] : 0.f);
+            float b1 = inf, b2 = inf, b3 = inf;
+            int t1 = a.n_tiles, t2 = a.n_tiles;
+#if PEDP_ICP_STAMPS
+            int dbg_words = 0, dbg_batches = 0;
+#endif
+            // ---- 3. culling and sweep.  Level 1: lane l tests the sphere of mask word l (64 tiles = 1,024
+            // sorted rows).  Level 2, eight surviving words per round of loads: lane l tests tile 64 word + l,
+            // the ballot is the word's tile mask; the survivors of ALL words go to the wave's LDS list, which is
+            // then swept in one go (the list is swept early only if the next round might not fit).
+            int n = 0;
+            for (int R = 0; R * 64 < a.n_words; ++R) {
+                const int wi = R * 64 + lane;
+                const float4 wsR = R == 0 ? ws0 : a.word_sph[wi < a.n_words ? wi : 0];
+                unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_sb(wsR));
+#if PEDP_ICP_STAMPS
+                dbg_words += __builtin_popcountll(km);
+#endif
+                while (km != 0ull) {  // wave-uniform
+#if PEDP_ICP_STAMPS
+                    ++dbg_batches;
+#endif
+                    if (n + L2_WORDS * 64 > WTL) {  // rare: a dense neighbourhood
+                        if (lane < 2 * SW_G) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                        sweep_sub_block(wtl[wv], n, a.tgtf, frag, bfrag, b1, t1, b2, t2, b3);
+                        ntl_w += n;
+                        n = 0;
+                    }
+                    int word[L2_WORDS];
+                    float4 ts[L2_WORDS];
+#pragma unroll
+                    for (int u = 0; u < L2_WORDS; ++u) {
+                        word[u] = -1;
+                        if (km != 0ull) {
+                            word[u] = R * 64 + __builtin_ctzll(km);
+                            km &= km - 1ull;
+                        }
+                        const int tile = word[u] * 64 + lane;
+                        ts[u] = a.tile_sph[(word[u] >= 0 && tile < a.n_tiles) ? tile : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < L2_WORDS; ++u) {
+                        if (word[u] < 0) continue;
+                        const int tile = word[u] * 64 + lane;
+                        const bool keep = tile < a.n_tiles && near_sb(ts[u]);
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+                        if (keep) wtl[wv][n + __builtin_popcountll(m & lt)] = (unsigned)tile;
+                        n += __builtin_popcountll(m);
+                    }
+                }
+            }
+            if (lane < 2 * SW_G) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            sweep_sub_block(wtl[wv], n, a.tgtf, frag, bfrag, b1, t1, b2, t2, b3);
+            ntl_w += n;
+            if (tid == 0) PEDP_STAMP(1, blockIdx.x, 2);
+            PEDP_WV(2, __builtin_amdgcn_s_memtime());
+            PEDP_WV(5, ((long long)dbg_words << 32) | ((long long)dbg_batches << 16) | ((long long)nn << 8) | nsl);
+            PEDP_WV(6, ntl_w);
+            // ---- 4. exact selection.  fp32 g is a filter: with the slot's error bound e the true nearest
+            // neighbour lies in a tile whose value is within 2 e of the slot's minimum.  A lane re-scores the
+            // four rows it saw of its best tile (and of its second best, if that is inside the window too) in
+            // float64 with the oracle's formula, lexicographic (d^2, index); a third tile of one lane inside
+            // the window sends the slot to the exact search.
+            const float e = real ? weps[wv][j] : 0.f, Si = real ? wS[wv][j] : 3e38f;
+            const double qx = wp[wv][0][j], qy = wp[wv][1][j], qz = wp[wv][2][j];
+            float mg = fminf(b1, __shfl_xor(b1, 16, 64));
+            mg = fminf(mg, __shfl_xor(mg, 32, 64));
+            const bool maybe = real && mg + Si <= st->r2f + 4.0f * e + 4.8e-7f * Si;  // else certainly farther than r
+            const float win = mg + 2.0f * e;
+            double bd = dinf;
+            int bj = 0x7FFFFFFF;
+            auto rescore = [&](int tile) {
+                const int64_t row0 = (int64_t)tile * 16 + 4 * g;  // this lane's rows of the tile
+                double rw[4][6];
+                int ri[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r < a.Nt ? row0 + r : 0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) rw[r][c] = a.tgt_s[6 * row + c];
+                    ri[r] = a.tperm[row];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row0 + r < a.Nt) {
+                        const double d = dist2(qx, qy, qz, rw[r][0], rw[r][1], rw[r][2]);
+                        if (d < bd || (d == bd && ri[r] < bj)) {
+                            bd = d; bj = ri[r];
+                            wt[0] = rw[r][0]; wt[1] = rw[r][1]; wt[2] = rw[r][2];
+                            wn[0] = rw[r][3]; wn[1] = rw[r][4]; wn[2] = rw[r][5];
+                        }
+                    }
+                }
+            };
+            if (maybe && b1 <= win) rescore(t1);
+            if (__builtin_amdgcn_ballot_w64(maybe && b2 <= win) != 0ull) {  // (about one lane in a hundred)
+                if (maybe && b2 <= win) rescore(t2);
+            }
+            // the slot's winner over its four lanes; the lane that holds it hands neighbour and normal over
+            fd = bd;
+            int fjj = bj;
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const double od = __shfl_xor(fd, off, 64);
+                const int oj = __shfl_xor(fjj, off, 64);
+                lexmin(fd, fjj, od, oj);
+            }
+            const bool found = maybe && fjj != 0x7FFFFFFF;
+            {
+                int gw = (found && bj == fjj) ? g : 0;  // target indices are unique: one lane of the four at most
+                gw |= __shfl_xor(gw, 16, 64);
+                gw |= __shfl_xor(gw, 32, 64);
+                const int srcl = j + 16 * gw;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    wt[c] = __shfl(wt[c], srcl, 64);
+                    wn[c] = __shfl(wn[c], srcl, 64);
+                }
+            }
+            fj = found ? fjj : -1;
+            fd = found ? fd : dinf;
+            have_tn = found;
+            // ---- 5. ambiguous slots (three tiles of one lane inside the window): exact float64 search over
+            // the tiles within the slot's own search radius, the whole wave per slot
+            unsigned amb = (unsigned)__builtin_amdgcn_ballot_w64(maybe && b3 <= win);
+            {
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(maybe && b3 <= win);
+                amb = (unsigned)((am | (am >> 16) | (am >> 32) | (am >> 48)) & 0xFFFFull);
+            }
+            if (tid == 0) PEDP_STAMP(1, blockIdx.x, 3);
+            while (amb != 0u) {  // wave-uniform, rare
+                const int s = __builtin_ctz(amb);
+                amb &= amb - 1u;
+                ++nfb_w;
+                const double sx64 = wp[wv][0][s], sy64 = wp[wv][1][s], sz64 = wp[wv][2][s];
+                const float sx = wcs[wv][0][s], sy = wcs[wv][1][s], sz = wcs[wv][2][s], rho_s = wrho[wv][s];
+                const float slack = 1e-5f * (fabsf(sx) + fabsf(sy) + fabsf(sz)) + 1e-6f;  // fp32 rounding of the centred point
+                auto near_pt = [&](const float4 &ts) -> bool {
+                    const float dx = ts.x - sx, dy = ts.y - sy, dz = ts.z - sz;
+                    const float lim = rho_s + ts.w + slack;
+                    return !((dx * dx + dy * dy + dz * dz) > lim * lim * 1.00001f + 1e-6f) && ts.w >= 0.f;
+                };
+                double xd = dinf;
+                int xj = 0x7FFFFFFF;
+                for (int R = 0; R * 64 < a.n_words; ++R) {
+                    const int wi = R * 64 + lane;
+                    const float4 wsR = R == 0 ? ws0 : a.word_sph[wi < a.n_words ? wi : 0];
+                    unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_pt(wsR));
+                    while (km != 0ull) {
+                        const int word = R * 64 + __builtin_ctzll(km);
+                        km &= km - 1ull;
+                        const int tile = word * 64 + lane;
+                        const float4 ts = a.tile_sph[tile < a.n_tiles ? tile : 0];
+                        const bool keep = tile < a.n_tiles && near_pt(ts);
+                        scan_near_tiles(__builtin_amdgcn_ballot_w64(keep), tile, a, sx64, sy64, sz64, lane, xd, xj);
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off <= 32; off <<= 1) {
+                    const double od = __shfl_xor(xd, off, 64);
+                    const int oj = __shfl_xor(xj, off, 64);
+                    lexmin(xd, xj, od, oj);
+                }
+                if (j == s) {
+                    fd = xj == 0x7FFFFFFF ? dinf : xd;
+                    fj = xj == 0x7FFFFFFF ? -1 : xj;
+                    have_tn = false;  // neighbour and normal are fetched by index below
+                }
+            }
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 4);
+        PEDP_WV(3, __builtin_amdgcn_s_memtime());
+        // ---- 6. the sub-block's partial sums (layout: see icp_accumulate_kernel).  Four lanes per slot,
+        // lane group g owns the packet entries k = g (mod 4); entries are summed over the wave's 16
+        // slots by a shuffle tree, then over the waves in order: a fixed tree.
+        {
+            double acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+            const int i = real ? wpi[wv][j] : -1;
+            int jn = fj;
+            const double dd = fd;
+            if (i >= 0) {
+                if (jn >= 0 && !(dd < st->r2)) jn = -1;  // strict, as SearchHybrid's lower_bound
+                const int64_t kp = (int64_t)chunk * CH + wkk[wv][j];
+                if (g == 0) {
+                    a.idx_out[i] = jn;
+                    if (jn < 0) a.Tprev[3 * kp] = dnan;
+                }
+                if (jn >= 0) {
+                    const double sx = wp[wv][0][j], sy = wp[wv][1][j], sz = wp[wv][2][j];
+                    double tx = wt[0], ty = wt[1], tz = wt[2], nx = wn[0], ny = wn[1], nz = wn[2];
+                    if (!have_tn) {  // rare: the exact search returns an index
+                        tx = a.tgt[3 * (int64_t)jn]; ty = a.tgt[3 * (int64_t)jn + 1]; tz = a.tgt[3 * (int64_t)jn + 2];
+                        if (a.estimator == PEDP_POINT_TO_PLANE) {
+                            nx = a.nrm[3 * (int64_t)jn]; ny = a.nrm[3 * (int64_t)jn + 1]; nz = a.nrm[3 * (int64_t)jn + 2];
+                        }
+                    }
+                    if (g == 0) { a.Tprev[3 * kp] = tx; a.Tprev[3 * kp + 1] = ty; a.Tprev[3 * kp + 2] = tz; }
+                    // entry k of the packet goes to lane group g = k % 4, accumulator k / 4
+#define PEDP_PUT(K, V)                                   \
+    do {                                                 \
+        const double v_ = (V);                           \
+        if (g == ((K) & 3)) acc[(K) >> 2] = v_;          \
+    } while (0)
+                    if (a.estimator == PEDP_POINT_TO_PLANE) {
+                        const double r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+                        const double J[6] = {sy * nz - sz * ny, sz * nx - sx * nz, sx * ny - sy * nx, nx, ny, nz};
+                        int k = 0;
+#pragma unroll
+                        for (int u = 0; u < 6; ++u)
+#pragma unroll
+                            for (int v = u; v < 6; ++v) { PEDP_PUT(k, J[u] * J[v]); ++k; }
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) PEDP_PUT(21 + u, J[u] * r);
+                    } else {
+                        const double s3[3] = {sx - ccx, sy - ccy, sz - ccz}, t3[3] = {tx - ccx, ty - ccy, tz - ccz};
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) { PEDP_PUT(u, s3[u]); PEDP_PUT(3 + u, t3[u]); }
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) PEDP_PUT(6 + 3 * u + v, t3[u] * s3[v]);
+                    }
+                    PEDP_PUT(27, dd);
+                    PEDP_PUT(28, 1.0);
+#undef PEDP_PUT
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double v = acc[k];
+#pragma unroll
+                for (int off = 1; off <= 8; off <<= 1) v += __shfl_xor(v, off, 64);
+                if (j == 0) accsh[wv][4 * k + g] = v;
+            }
+            // (entries 29, 30 of the tree are zero: the statistics replace them)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (lane == 0) { accsh[wv][PACKET] = (double)ntl_w; accsh[wv][PACKET + 1] = (double)nfb_w; }
+        }
+        PEDP_WV(4, __builtin_amdgcn_s_memtime());
+        __syncthreads();
+        if (tid < PSTRIDE) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) v += accsh[w][tid];
+            double *dst = &a.partials[(size_t)unit * PSTRIDE + tid];
+            if (a.fuse) store_sc1(dst, v);
+            else *dst = v;
+        }
+        if (tid == 0) PEDP_STAMP(1, blockIdx.x, 5);
+#if PEDP_ICP_STAMPS
+        if (tid == 1 && blockIdx.x < 4096) g_icp_stamps[1][blockIdx.x][7] = ((long long)ntl_w << 32) | (long long)(nfb_w << 16) | nsl;
+#endif
+        __syncthreads();  // the waves' sums are reused by the next chunk
+    }
+    PEDP_RT(pass, 2);
+    if (!a.fuse) return;
+    // ---- the pass is closed by the workgroup that finishes last
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0 && (a.hand & 2)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add((g_u32 *)(uintptr_t)&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[4] = prev == (unsigned)(n_wg - 1);
+    }
+    __syncthreads();
+    PEDP_RT(pass, 3);
+    if (!misc[4]) return;
+    if (a.hand & 1) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) PEDP_STAMP(1, blockIdx.x, 6);
+    FinishArgs f;
+    f.live = a.live; f.live_list = a.live_list; f.n_lw = a.n_lw; f.partials = a.partials; f.packet = a.packet; f.phase = 0;
+    f.estimator = a.estimator; f.trace = a.trace; f.hist = a.hist; f.bcx = a.bc[0]; f.bcy = a.bc[1]; f.bcz = a.bc[2];
+    icp_finish_body<W * 64, 2048, true>(st, f, fin, threadIdx.x);
+    PEDP_RT(pass, 4);
+    if (threadIdx.x == 0) __hip_atomic_store((g_u32 *)(uintptr_t)&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ host side
@@ -2158,6 +2288,10 @@ struct IcpWorkspace {
     size_t pose_stride;  // bytes between the per-pose blocks of a batch (all pointers above are pose 0's)
 };
 
+// trace and update history are sized for a capacity class of max_iter, not for max_iter itself: the
+// per-pose block layout a captured batch graph bakes in then changes only with the class
+inline int iter_capacity(int max_iter) { return (max_iter + 2 + 63) / 64 * 64; }
+
 int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, IcpWorkspace &w, bool fused = false,
                     int poses = 1) {
     w.qt = qt;
@@ -2194,7 +2328,7 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     size_t o_d2 = take(sizeof(double) * (size_t)w.Ns_pad * seg_only);
     size_t o_part = take(sizeof(double) * ACC_BLOCKS * PACKET);
     size_t o_pack = take(sizeof(double) * 32);
-    size_t o_trace = take(sizeof(double) * 18 * (size_t)(max_iter + 1));
+    size_t o_trace = take(sizeof(double) * 18 * (size_t)iter_capacity(max_iter));
     size_t o_B = take(sizeof(float4) * (size_t)w.Ns_pad);
     size_t o_eps = take(sizeof(float) * (size_t)w.Ns_pad);
     size_t o_S = take(sizeof(float) * (size_t)w.Ns_pad);
@@ -2216,7 +2350,7 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     if (fused) {
         o_Pk = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
         o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
-        o_hist = take(sizeof(double) * 16 * (size_t)(max_iter + 2));
+        o_hist = take(sizeof(double) * 16 * (size_t)iter_capacity(max_iter));
         o_cpart = take(sizeof(double) * PSTRIDE * (size_t)w.blocks_cap);
         o_live = take(sizeof(unsigned long long) * (size_t)w.n_lw);
         o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
@@ -2318,9 +2452,14 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
 // Margin of the live set beyond the correspondence radius (see the fused-pass comment).
 inline double fused_margin(double r) { return 2.0 * r; }
 
-// Enqueue the chunk kernel of a fused pass.
+inline int handoff_mode() {
+    static const int m = getenv("PEDP_ICP_HANDOFF") ? atoi(getenv("PEDP_ICP_HANDOFF")) : 0;
+    return m;
+}
+// Enqueue the kernel of a fused pass.  fuse: the workgroup that finishes last closes the pass
+// (sum, solve, update); otherwise icp_finish_kernel launches follow (exchange step in between).
 int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int estimator,
-                       const TargetPrep &tp, hipEvent_t ev0, hipEvent_t ev1, int poses = 1) {
+                       const TargetPrep &tp, hipEvent_t ev0, hipEvent_t ev1, bool fuse, double *trace, int poses = 1) {
     PassArgs pa;
     pa.src = src->pts; pa.perm = w.src_perm; pa.N = src->N; pa.n_chunks = w.n_chunks;
     pa.hist = w.hist; pa.Pk = w.Pk; pa.Tprev = w.Tprev; pa.live = w.live; pa.live_list = w.live_list;
@@ -2328,9 +2467,12 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     pa.tile_sph = w.tile_sph; pa.word_sph = w.word_sph; pa.tgt_s = w.tgt_s; pa.tperm = w.tgt_perm; pa.Nt = tgt->N;
     pa.tgt = tgt->pts; pa.nrm = tgt->normals;
     pa.Tn = tp.Tn; pa.T2 = tp.T2;
-    for (int k = 0; k < 3; ++k) { pa.lo[k] = tp.lo[k]; pa.hi[k] = tp.hi[k]; }
+    for (int k = 0; k < 3; ++k) { pa.lo[k] = tp.lo[k]; pa.hi[k] = tp.hi[k]; pa.bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]); }
     pa.estimator = estimator; pa.idx_out = w.idx; pa.partials = w.cpart;
     pa.pose_stride = poses > 1 ? w.pose_stride : 0;
+    const int hand_env = handoff_mode();  // experiment
+    pa.hand = hand_env;
+    pa.fuse = fuse && hand_env != 9 ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace;
     // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
     int64_t g = w.n_chunks;
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
@@ -2345,63 +2487,33 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     return PEDP_OK;
 }
 
-// Spatial order of a cloud (device counting sort), cached in the handle.  The 32^3 cells are
-// laid over `roi` (lo xyz, hi xyz), not over the whole cloud: for a scene cloud that is the
-// region the target can occupy (its bounding box + radius, moved into the scene frame with
-// the inverse of the first registration's init), so the resolution goes where candidate
-// points are; points outside are clamped to the border cells (they are no candidates).  The
-// order is rebuilt if a later call's region has moved by more than half its size.
-int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl, const double *roi) {
-    if (cl->N == 0) return PEDP_OK;
-    double lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) { lo[k] = roi ? roi[k] : cl->lo[k]; hi[k] = roi ? roi[3 + k] : cl->hi[k]; }
-    if (cl->perm) {
-        bool moved = false;
-        for (int k = 0; k < 3; ++k) {
-            const double ext = cl->perm_hi[k] - cl->perm_lo[k];
-            if (std::fabs(0.5 * (lo[k] + hi[k]) - 0.5 * (cl->perm_lo[k] + cl->perm_hi[k])) > 0.5 * ext + 1e-12) moved = true;
-        }
-        if (!moved) return PEDP_OK;
-    } else {
-        PEDP_HIP_CHECK(hipMalloc(&cl->perm, sizeof(int32_t) * (size_t)cl->N));
-        for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = 0.0; cl->perm_hi[k] = -1.0; }  // no region yet: every request rebuilds
-    }
-    struct KeyGuard {  // freed on every exit path
-        unsigned *p = nullptr;
-        ~KeyGuard() { if (p) (void)hipFree(p); }
-    } guard;
-    PEDP_HIP_CHECK(hipMalloc((void **)&guard.p, sizeof(unsigned) * (size_t)cl->N));
+// Spatial order of a cloud, cached in the handle: a function of the cloud alone (cells over its own
+// bounding box), built once, stream-ordered in pooled scratch (no allocation besides the order
+// itself, no synchronisation).
+int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
+    if (cl->N == 0 || cl->perm) return PEDP_OK;
+    void *perm = nullptr;
+    PEDP_HIP_CHECK(hipMalloc(&perm, sizeof(int32_t) * (size_t)cl->N));
+    unsigned long long *keys = nullptr;
+    int rcs = pedp_sort_keys64_begin(c, cl->N, SORT_KEY_BITS, &keys);
+    if (rcs) { (void)hipFree(perm); return rcs; }
     double sc[3];
     for (int k = 0; k < 3; ++k) {
-        double ext = hi[k] - lo[k];
-        sc[k] = ext > 0.0 ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
+        const double ext = cl->hi[k] - cl->lo[k];
+        sc[k] = ext > 0.0 && std::isfinite(ext) ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
     }
     const unsigned grid = (unsigned)((cl->N + 255) / 256);
-    hipLaunchKernelGGL(cell_key_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, lo[0], lo[1], lo[2], sc[0],
-                       sc[1], sc[2], guard.p);
-    PEDP_HIP_CHECK(hipGetLastError());
-    // keys 0 .. SORT_CELLS (the outside bucket): 3 SORT_BITS + 1 bits
-    int rcs = pedp_stable_sort_by_key(c, guard.p, cl->N, 3 * SORT_BITS + 1, (int32_t *)cl->perm);
-    if (rcs) return rcs;
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 3; ++k) { cl->perm_lo[k] = lo[k]; cl->perm_hi[k] = hi[k]; }  // valid only now
-    return PEDP_OK;
-}
-
-// Region of the scene frame the target can reach: corners of (target box + r) through inv(init).
-void scene_roi(pedp_cloud_t tgt, double r, const double init[16], double roi[6]) {
-    // init maps scene -> target: x_t = R x_s + t  =>  x_s = R^T (x_t - t)
-    const double rr = std::isfinite(r) && r < 1e15 ? r : 0.0;
-    for (int k = 0; k < 3; ++k) { roi[k] = 1e300; roi[3 + k] = -1e300; }
-    for (int corner = 0; corner < 8; ++corner) {
-        double p[3];
-        for (int k = 0; k < 3; ++k) p[k] = ((corner >> k) & 1 ? tgt->hi[k] + rr : tgt->lo[k] - rr) - init[4 * k + 3];
-        for (int k = 0; k < 3; ++k) {
-            const double v = init[0 * 4 + k] * p[0] + init[1 * 4 + k] * p[1] + init[2 * 4 + k] * p[2];
-            if (v < roi[k]) roi[k] = v;
-            if (v > roi[3 + k]) roi[3 + k] = v;
-        }
+    hipLaunchKernelGGL(cell_key_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1], cl->lo[2],
+                       sc[0], sc[1], sc[2], keys);
+    rcs = pedp_sort_keys64_run(c, cl->N, SORT_KEY_BITS, (int32_t *)perm);
+    if (rcs || hipGetLastError() != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(perm);
+        if (!rcs) { pedp_set_error("pedp_icp: spatial order: launch failed"); rcs = PEDP_ERR_HIP; }
+        return rcs;
     }
+    cl->perm = perm;
+    return PEDP_OK;
 }
 
 // Target-side operand of the sweep, built once per cloud and kept in the handle (the
@@ -2412,7 +2524,7 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     tp.T2 = tgt->T2;
     for (int k = 0; k < 3; ++k) { tp.lo[k] = tgt->lo[k]; tp.hi[k] = tgt->hi[k]; }
     if (tgt->tgt4) return PEDP_OK;
-    int rc = ensure_spatial_perm(c, tgt, nullptr);
+    int rc = ensure_spatial_perm(c, tgt);
     if (rc) return rc;
     // real tiles rounded to NN_TU, plus readable pad tiles the pipelined sweep may prefetch
     int64_t pad = (int64_t)align_up((size_t)(tgt->N > 0 ? tgt->N : 1), 16 * NN_TU) + 16 * NN_TILE_PAD;
@@ -2423,7 +2535,7 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     if (e == hipSuccess) e = hipMalloc(&s1, sizeof(float4) * (size_t)(pad / 16));
     if (e == hipSuccess) e = hipMalloc(&s4, sizeof(float4) * (size_t)(pad / 64));
     if (e == hipSuccess) e = hipMalloc(&sw, sizeof(float4) * (size_t)n_wsph);
-    if (e == hipSuccess) e = hipMalloc(&ts, sizeof(double) * 3 * (size_t)pad);
+    if (e == hipSuccess) e = hipMalloc(&ts, sizeof(double) * 6 * (size_t)pad);
     if (e != hipSuccess) {
         if (t4) (void)hipFree(t4);
         if (s1) (void)hipFree(s1);
@@ -2448,7 +2560,7 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
                        (const float4 *)tgt->tgt4, tgt->N, pad / 64, 64, (float4 *)tgt->tile_sph4);
     hipLaunchKernelGGL(tile_sphere_kernel, dim3((unsigned)((n_wsph + 63) / 64)), dim3(64), 0, c->stream,
                        (const float4 *)tgt->tgt4, tgt->N, n_wsph, 1024, (float4 *)tgt->tile_sphw);
-    hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts,
+    hipLaunchKernelGGL(sort_rows_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, tgt->pts, tgt->normals,
                        (const int32_t *)tgt->perm, tgt->N, pad, (double *)tgt->tgt_s);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
@@ -2496,22 +2608,12 @@ int icp_unit_size(pedp_cloud_t target, double r) {
     return (r * r < diag2 / 16.0) ? 1 : 4;
 }
 
-// Cached per-cloud preparation on the owner's stream: sorted target operand + unit spheres,
-// spatial order of the scene over the region the target can reach from `init`.
-int icp_prepare(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, double r, const double *inits, int B, TargetPrep &tp) {
+// Cached per-cloud preparation on the owner's stream: sorted target operand + unit spheres, spatial
+// order of the scene.
+int icp_prepare(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, TargetPrep &tp) {
     int rc = ensure_target_pack(c, target, tp);
     if (rc) return rc;
-    double roi[6];
-    scene_roi(target, r, inits, roi);
-    for (int b = 1; b < B; ++b) {  // a batch orders the scene over the union of its start poses
-        double rb[6];
-        scene_roi(target, r, inits + 16 * b, rb);
-        for (int k = 0; k < 3; ++k) {
-            roi[k] = rb[k] < roi[k] ? rb[k] : roi[k];
-            roi[3 + k] = rb[3 + k] > roi[3 + k] ? rb[3 + k] : roi[3 + k];
-        }
-    }
-    return ensure_spatial_perm(c, source, roi);
+    return ensure_spatial_perm(c, source);
 }
 
 // workspace of one registration on executor x (may grow the executor's scratch buffer)
@@ -2605,10 +2707,12 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
             ++x->nn_pairs;
         }
         if (fused) {
-            rc = enqueue_fused_pass(x, w, source, target, prm->estimator, tp, ev0, ev1);
+            rc = enqueue_fused_pass(x, w, source, target, prm->estimator, tp, ev0, ev1, !exchange, want_trace ? w.trace : nullptr);
             if (rc) return rc;
-            int phase = 0;
-            if (exchange) {
+            if (!exchange && handoff_mode() == 9)
+                hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 0,
+                                   prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
+            if (exchange) {  // sum -> all-reduce over the ranks -> solve
                 hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 1,
                                    prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
                 if (prm->use_comm) {
@@ -2619,10 +2723,9 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
                     (void)hipStreamSynchronize(x->stream);
                     return PEDP_ERR_COLLECTIVE;
                 }
-                phase = 2;
+                hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 2,
+                                   prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
             }
-            hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, phase,
-                               prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
             PEDP_HIP_CHECK(hipGetLastError());
         } else {
         if (!degenerate) {
@@ -2677,7 +2780,8 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
     PEDP_HIP_CHECK(hipStreamSynchronize(x->stream));
     const IcpState *hp = (const IcpState *)x->pinned;
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
-    x->icp_last_cand = hp->sum_tiles * (16 * job.qt) * (NN_SB * 16);  // (scene slot, target point) pairs the MFMAs evaluated
+    // (scene slot, target point) pairs the MFMAs evaluated: fused pass counts 16 x 16 wave-tiles, the segmented path units x 128 slots
+    x->icp_last_cand = job.w.fused ? hp->sum_tiles * 256 : hp->sum_tiles * (16 * job.qt) * (NN_SB * 16);
     x->icp_last_fb = hp->sum_fb;
     x->icp_last_passes = hp->iters + 1;
     x->icp_last_nt = job.Nt;
@@ -2768,7 +2872,7 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
     pedp_icp_graph_key key;
     key.src_gen = source->gen; key.tgt_gen = target->gen; key.ws = c->icp_ws.ptr;
     key.Ns = job.Ns; key.Nt = job.Nt; key.qt = 1; key.estimator = prms[0].estimator;
-    key.max_iter = 0;  // the limit, the radius and the criteria are in the device state
+    key.max_iter = iter_capacity(job.max_iter);  // the limit itself is in the device state; the workspace layout (trace, history) depends on its capacity class
     key.r = -1.0;
     // passes per replay: everything when no pose can stop early, else a stretch that covers the usual
     // convergence (Open3D's default criteria stop problems of this kind after 6-9 iterations)
@@ -2779,13 +2883,13 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
         if (c->icp_bgraph[slot]) { (void)hipGraphExecDestroy(c->icp_bgraph[slot]); c->icp_bgraph[slot] = nullptr; }
         hipGraph_t graph = nullptr;
         PEDP_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        double bc[3];
-        for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
         for (int p = 0; p < key.seg && !rc; ++p) {
-            rc = enqueue_fused_pass(c, w, source, target, prms[0].estimator, tp, nullptr, nullptr, G);
-            hipLaunchKernelGGL(icp_finish_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, c->stream, w.st, w.live, w.live_list,
-                               w.n_lw, w.cpart, w.packet, 0, prms[0].estimator, (double *)nullptr, w.hist, bc[0], bc[1], bc[2],
-                               G > 1 ? w.pose_stride : (size_t)0);
+            rc = enqueue_fused_pass(c, w, source, target, prms[0].estimator, tp, nullptr, nullptr, true, nullptr, G);
+            if (handoff_mode() == 9)
+                hipLaunchKernelGGL(icp_finish_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, c->stream, w.st, w.live, w.live_list,
+                                   w.n_lw, w.cpart, w.packet, 0, prms[0].estimator, (double *)nullptr, w.hist,
+                                   0.5 * (tp.lo[0] + tp.hi[0]), 0.5 * (tp.lo[1] + tp.hi[1]), 0.5 * (tp.lo[2] + tp.hi[2]),
+                                   G > 1 ? w.pose_stride : (size_t)0);
         }
         const hipError_t e = hipStreamEndCapture(c->stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -2833,7 +2937,7 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
             if (fitness) fitness[b0 + k] = h.fitness;
             if (inlier_rmse) inlier_rmse[b0 + k] = h.rmse;
             if (n_iter_done) n_iter_done[b0 + k] = h.iters;
-            c->icp_last_cand += h.sum_tiles * 16 * (NN_SB * 16);
+            c->icp_last_cand += h.sum_tiles * 256;
             c->icp_last_fb += h.sum_fb;
             c->icp_last_passes += h.iters + 1;
         }
@@ -2853,7 +2957,7 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     TargetPrep tp;
-    rc = icp_prepare(c, source, target, prm->max_correspondence_distance, init, 1, tp);
+    rc = icp_prepare(c, source, target, tp);
     if (rc) return rc;
     IcpJob job;
     rc = icp_job_setup(c, source, target, prm, job);
@@ -2886,7 +2990,7 @@ int pedp_icp_batched_ex(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, 
     if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     TargetPrep tp;
-    rc = icp_prepare(c, source, target, r_max, inits, B, tp);
+    rc = icp_prepare(c, source, target, tp);
     if (rc) return rc;
     // The fused path takes a whole group of poses per launch, whatever their radii and criteria (they
     // live in the device state).  The segmented path replays one graph per pose on sub-contexts and
@@ -2984,7 +3088,7 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     w.tgt4 = (const float4 *)target->tgt4;
     w.tile_sph = (const float4 *)target->tile_sph4;
     w.tgt_perm = (const int32_t *)target->perm;
-    rc = ensure_spatial_perm(c, source, nullptr);  // no radius: order over the whole cloud
+    rc = ensure_spatial_perm(c, source);
     if (rc) return rc;
     w.src_perm = (const int32_t *)source->perm;
     IcpState *hp = (IcpState *)c->pinned;

@@ -19,7 +19,8 @@ int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes);
 // after the data are in `dst` (the stream has been drained up to and including the copy).
 int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes);
 struct pedp_ctx_s;
-int pedp_stable_sort_by_key(pedp_ctx_s *c, unsigned *d_keys, int64_t N, int bits, int32_t *d_perm);
+int pedp_sort_keys64_begin(pedp_ctx_s *c, int64_t N, int bits, unsigned long long **d_keys);
+int pedp_sort_keys64_run(pedp_ctx_s *c, int64_t N, int bits, int32_t *d_perm);
 
 #define PEDP_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
@@ -97,6 +98,7 @@ struct pedp_ctx_s {
     // ICP
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
+    pedp_scratch sort_ws;    // spatial order of a cloud: keys + radix-sort buffers (pooled, stream-ordered)
     pedp_scratch ops_in;     // a large cloud's points, uploaded ahead of the workspace sizing (its box comes from the device copy)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
@@ -155,8 +157,7 @@ struct pedp_cloud_s {
     // Built on first use in ICP: spatial order of the points (device int32[N]); as a target
     // additionally the sorted float4 operand (x', y', z', |t'|^2), padded, and one bounding
     // sphere per 16-row tile.
-    void *perm = nullptr;
-    double perm_lo[3] = {0, 0, 0}, perm_hi[3] = {0, 0, 0};  // region the spatial order was built over
+    void *perm = nullptr;       // built from the cloud alone (its own bounding box): never rebuilt
     void *tgt4 = nullptr;
     void *tile_sph = nullptr;   // one sphere per 16 sorted rows
     void *tile_sph4 = nullptr;  // one sphere per 64 sorted rows

@@ -35,22 +35,65 @@ cal = buf[2][1]
 mhz = (cal[2] - cal[0]) / max(cal[3] - cal[1], 1) * 100.0   # s_memtime ticks per s_memrealtime tick (100 MHz)
 print(f"s_memtime runs at {mhz:.0f} MHz (finish kernel: {(cal[3]-cal[1])/100:.2f} us)")
 tick = 1.0 / mhz
-blk = buf[1][buf[1][:, 6] > 0]
-blk = blk[blk[:, 0] > blk[:, 0].max() - 400 * mhz]   # the last pass only
+blk = buf[1][buf[1][:, 5] > 0]
+blk = blk[blk[:, 0] > blk[:, 0].max() - 100 * mhz]   # the last pass only (stamps of earlier passes are overwritten per workgroup)
 if len(blk):
-    d = np.diff(blk[:, :7], axis=1) * tick
-    names = ["transform+pack", "cull", "sweep", "select", "fallback", "accumulate"]
-    print(f"block: {len(blk)} workgroups; span {(blk[:,6].max() - blk[:,0].min()) * tick:.2f} us")
+    d = np.diff(blk[:, :6], axis=1) * tick
+    names = ["transform", "cull+sweep", "select", "exact search", "sums+store"]
+    print(f"pass kernel, wave 0 of each workgroup: {len(blk)} workgroups; span {(blk[:,5].max() - blk[:,0].min()) * tick:.2f} us")
     for k, n in enumerate(names):
         print(f"   {n:12s} median {np.median(d[:,k]):7.2f}  p90 {np.percentile(d[:,k],90):7.2f}  max {d[:,k].max():7.2f} us")
     info = blk[:, 7]
-    tiles, nsurv, nfb, ncand = info >> 32, (info >> 24) & 0xFF, (info >> 16) & 0xFF, info & 0xFFFF
-    tot = (blk[:, 6] - blk[:, 0]) * tick
+    tiles, nfb, nsl = info >> 32, (info >> 16) & 0xFFFF, info & 0xFFFF
+    tot = (blk[:, 5] - blk[:, 0]) * tick
     worst = np.argsort(-tot)[:5]
     for w in worst:
-        print(f"   slowest: total {tot[w]:.2f} us tiles {tiles[w]} words {nsurv[w]} fallback slots {nfb[w]} candidates {ncand[w]}  phases {np.round(d[w],2)}")
-    print(f"   tiles/block median {np.median(tiles)} max {tiles.max()}; fallback slots/block max {nfb.max()} sum {nfb.sum()}")
+        print(f"   slowest: total {tot[w]:.2f} us  wave-0 tiles {tiles[w]} exact searches {nfb[w]} slots {nsl[w]}  phases {np.round(d[w],2)}")
+    print(f"   wave-0 tiles median {np.median(tiles)} max {tiles.max()}")
+    last = blk[blk[:, 6] > 0]
+    if len(last):
+        fin0 = buf[2][0]
+        print(f"   last arriver: ticket taken {(last[0,6] - blk[:,0].min()) * tick:.2f} us after the first workgroup started; finish body {(fin0[3]-fin0[0])*tick:.2f} us")
 sv = buf[2][2]
 print("finish, last solving pass: LDLT %.2f  sincos+T %.2f  T update, motion, stores %.2f us" % tuple(np.diff(sv[:4]) * tick))
 fin = buf[2][0]
-print("finish: reduce %.2f solve %.2f tail %.2f us" % tuple(np.diff(fin[:4]) * tick))
+f5 = buf[2][3]
+if f5[6] > 0:
+    print("finish of pass 5 (us): state read + partial loads %.2f | barrier %.2f | 32-range sum + barrier %.2f | fitness, trace, criteria %.2f | solve + sincos %.2f | pose, bound, state %.2f" % tuple(np.diff(f5[:7]) * tick))
+# device-wide timeline (s_memrealtime, 10-ns ticks) of every pass: first entry -> last chunk done -> pass closed -> next pass's first entry
+rt = np.zeros((32, 512, 8), np.int64)
+if hasattr(lib, "pedp_debug_icp_rt") and lib.pedp_debug_icp_rt(C.c_void_p(rt.ctypes.data)) == 0:
+    prev_close = None
+    for p in range(min(iters + 1, 32)):
+        r = rt[p]
+        on = r[:, 0] > 0
+        if not on.any():
+            continue
+        e0 = r[on, 0].min()
+        last = r[on, 4].max()
+        us = lambda t: (t - e0) / 100.0
+        line = (f"pass {p:2d}: {on.sum():3d} workgroups; entry spread {us(r[on,0].max()):5.2f}; state read (median) {np.median(us(r[on,1])):5.2f}; "
+                f"chunks done median {np.median(us(r[on,2])):6.2f} max {us(r[on,2].max()):6.2f}; ticket back max {us(r[on,3].max()):6.2f}; closed {us(last):6.2f}")
+        if prev_close is not None:
+            line += f"; boundary (closed -> next entry) {(e0 - prev_close) / 100.0:5.2f}"
+        prev_close = last
+        print(line)
+# per-wave view of the last pass
+wvb = np.zeros((512, 8, 8), np.int64)
+if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wvb.ctypes.data)) == 0:
+    w = wvb.reshape(-1, 8)
+    w = w[(w[:, 4] > 0) & (w[:, 2] > 0)]
+    w = w[w[:, 0] > w[:, 0].max() - 60 * mhz]
+    ph = np.diff(w[:, :5], axis=1) * tick
+    words, batches, wide, slots, tiles = w[:, 5] >> 32, (w[:, 5] >> 16) & 0xFFFF, ((w[:, 5] >> 8) & 0xFF) - 1, w[:, 5] & 0xFF, w[:, 6]
+    print(f"waves with slots in the last pass: {len(w)}; wide {int(wide.sum())}")
+    for k, n in enumerate(["slots ready", "cull+sweep", "select", "sums"]):
+        print(f"   {n:12s} median {np.median(ph[:,k]):6.2f} p90 {np.percentile(ph[:,k],90):6.2f} max {ph[:,k].max():6.2f}")
+    print(f"   words median {np.median(words)} p90 {np.percentile(words,90)} max {words.max()}; batches median {np.median(batches)} max {batches.max()}; tiles median {np.median(tiles)} p90 {np.percentile(tiles,90)} max {tiles.max()}")
+    cs = ph[:, 1]
+    for b in sorted(set(batches.tolist())):
+        m = batches == b
+        print(f"   batches {b}: {m.sum():4d} waves, cull+sweep median {np.median(cs[m]):6.2f} max {cs[m].max():6.2f}, tiles median {np.median(tiles[m])}, wide {int(wide[m].sum())}")
+    worst = np.argsort(-cs)[:8]
+    for i in worst:
+        print(f"   slowest cull+sweep {cs[i]:6.2f}: words {words[i]} batches {batches[i]} tiles {tiles[i]} wide {wide[i]} slots {slots[i]}")
