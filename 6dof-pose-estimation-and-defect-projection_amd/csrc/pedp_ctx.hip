@@ -392,6 +392,7 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (cl->normals) (void)hipFree(cl->normals);
     if (cl->tgt4) (void)hipFree(cl->tgt4);
     if (cl->perm) (void)hipFree(cl->perm);
+    if (cl->chunk_sph) (void)hipFree(cl->chunk_sph);
     if (cl->tile_sph) (void)hipFree(cl->tile_sph);
     if (cl->tile_sph4) (void)hipFree(cl->tile_sph4);
     if (cl->tile_sphw) (void)hipFree(cl->tile_sphw);

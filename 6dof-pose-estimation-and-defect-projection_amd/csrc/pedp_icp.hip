@@ -39,6 +39,7 @@
 #include "pedp_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <new>
 
 #ifndef PEDP_NN_EXPERIMENT
@@ -64,14 +65,14 @@ extern "C" int pedp_debug_icp_stamps(long long *out) {
 __device__ long long g_icp_rt[32][512][8];
 // per wave of the pass kernel (last pass that ran): [0] start [1] slots ready [2] culled+swept [3] selected [4] sums done (s_memtime),
 // [5] words << 32 | batches << 16 | wide << 8 | slots, [6] tiles
-__device__ long long g_icp_wave[512][8][8];
+__device__ long long g_icp_wave[512][8][12];
 #define PEDP_WV(slot, val)                                                                         \
     do {                                                                                           \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 512 && blockIdx.y == 0)                        \
             g_icp_wave[blockIdx.x][threadIdx.x >> 6][slot] = (long long)(val);                     \
     } while (0)
 extern "C" int pedp_debug_icp_wave(long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_wave), sizeof(long long) * 512 * 8 * 8) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_wave), sizeof(long long) * 512 * 8 * 12) == hipSuccess ? 0 : -3;
 }
 #define PEDP_RT(pass, slot)                                                                     \
     do {                                                                                        \
@@ -135,7 +136,9 @@ struct IcpState {
     float r1, r_search, wide_radius, r2f;
     int pass, max_iter;        // the pass the fused kernels are in (advanced by icp_finish_kernel), and the limit
     double mu_theta, mu_tau;   // sum of |R - I|_F and of |t + (R - I) c| since the last rebuild
-    unsigned ticket;           // workgroups of the running pass that have stored their partial sums (the last one closes the pass)
+    // tickets and sign-offs are counted on from launch to launch (nothing to reset at the end of a pass): what the
+    // counters read when this launch began
+    unsigned ticket_base, idle_base;
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -198,6 +201,45 @@ __global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, doubl
                                 double sx, double sy, double sz, unsigned long long *__restrict__ key) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) key[i] = point_cell(pts, i, lox, loy, loz, sx, sy, sz);
+}
+// Bounding sphere (centre xyz, radius; float64, the cloud's own frame) of every 128 consecutive points
+// of the spatial order: a rebuild pass of a registration asks the spheres, moved by the pose so far,
+// which chunks can be near the target at all, and touches only those chunks' points.  One wave per
+// chunk, two points per lane.
+__global__ __launch_bounds__(64) void chunk_sphere_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm,
+                                                          int64_t N, double *__restrict__ sph) {
+    const int64_t chunk = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double big = 1.7976931348623157e308;
+    double lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
+    for (int h = 0; h < 2; ++h) {
+        const int64_t k = chunk * 128 + h * 64 + lane;
+        if (k < N) {
+            const int64_t i = perm[k];
+            for (int c = 0; c < 3; ++c) {
+                const double v = pts[3 * i + c];
+                lo[c] = v < lo[c] ? v : lo[c];
+                hi[c] = v > hi[c] ? v : hi[c];
+            }
+        }
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double l2 = __shfl_xor(lo[c], off, 64), h2 = __shfl_xor(hi[c], off, 64);
+            lo[c] = l2 < lo[c] ? l2 : lo[c];
+            hi[c] = h2 > hi[c] ? h2 : hi[c];
+        }
+    if (lane == 0) {
+        double m[3], r2 = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            m[c] = 0.5 * (lo[c] + hi[c]);
+            const double e = hi[c] - m[c];
+            r2 += e * e;
+        }
+        // non-finite coordinates give a non-finite sphere: such a chunk is never skipped
+        sph[4 * chunk] = m[0]; sph[4 * chunk + 1] = m[1]; sph[4 * chunk + 2] = m[2];
+        sph[4 * chunk + 3] = sqrt(r2) * (1.0 + 1e-12) + 1e-300;
+    }
 }
 
 // ------------------------------------------------------------------ target preparation
@@ -1363,9 +1405,11 @@ struct PassArgs {
     int64_t N;
     int n_chunks;
     double *hist;               // [pass + 1][16]: init, then the update of every pass so far
-    double *Pk;                 // N_pad x 3: transformed points in spatial order (live chunks)
-    double *Tprev;              // N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none)
-    unsigned long long *live;
+    double *Pk;                 // 2 x N_pad x 3: transformed points in spatial order (live chunks); pass p reads copy p & 1, writes the other
+    double *Tprev;              // 2 x N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none); likewise
+    size_t pp_stride;           // doubles between the two copies
+    unsigned long long *live;   // live mask (n_lw words), behind it the mask before the last rebuild (n_lw words)
+    const double *chunk_sph;    // bounding sphere of every chunk in the source frame
     int32_t *live_list;         // live chunks ascending (valid outside rebuild passes)
     // target
     const float *tgtf;          // sorted target operand, 64 floats per 16-row tile
@@ -1387,6 +1431,8 @@ struct PassArgs {
     size_t pose_stride;
     // the finish inside the launch (fuse != 0)
     int fuse, n_lw, hand;
+    unsigned *ticket;           // workgroups of the running launch that are through (the last one closes the pass); a line of its own:
+                                // 512 atomics on the state's line held up every wave's reads of the state
     double *packet, *trace;
     double bc[3];               // centre of the target's box (motion bound)
 };
@@ -1414,6 +1460,10 @@ struct FinishArgs {
     int phase, estimator;
     double *trace, *hist;
     double bcx, bcy, bcz;
+    // in-launch finish: sixteen counters (32 words apart) on which the launch's workgroups without a chunk sign off;
+    // the state is rewritten only once all n_idle of them have
+    unsigned *idle = nullptr;
+    int n_idle = 0, n_busy = 0;
 };
 template <int NT, int LCAP>
 struct FinishLds {
@@ -1541,10 +1591,12 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
             if (tid < PACKET) f.packet[tid] = t;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && f.phase == 1) {  // (phase 0 writes these further down, with the rest of the state)
             st->sum_tiles += (long long)L.pk[PACKET];
             st->sum_fb += (long long)L.pk[PACKET + 1];
             st->n_live = L.n_live_s;
+        }
+        if (tid == 0) {
 #if PEDP_ICP_STAMPS
             g_icp_stamps[2][1][2] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -1554,9 +1606,24 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         if (tid < PACKET) L.pk[tid] = f.packet[tid];
         __syncthreads();
     }
+    if (COHERENT && f.n_idle > 0 && tid < 64) {  // normally true at the first look
+        for (unsigned spins = 0;; ++spins) {
+            unsigned c = tid < 16 ? __hip_atomic_load((g_u32 *)(uintptr_t)(f.idle + 32 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (__shfl(c, 0, 64) - st->idle_base >= (unsigned)f.n_idle || spins > (1u << 22)) break;  // (bounded: a lost workgroup must not hang the device)
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
     if (tid == 0) {
         PEDP_STAMP(2, 0, 1);
         if (pass == 5) PEDP_STAMP(2, 3, 3);
+        if (COHERENT) { st->ticket_base += (unsigned)f.n_busy; st->idle_base += (unsigned)f.n_idle; }
+        if (f.phase == 0) {
+            st->sum_tiles += (long long)L.pk[PACKET];
+            st->sum_fb += (long long)L.pk[PACKET + 1];
+            st->n_live = L.n_live_s;
+        }
         L.do_rebuild = 0;
         const double *pk = L.pk;
         const double K = pk[28];
@@ -1648,8 +1715,8 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         PEDP_STAMP(2, 0, 3);
     }
     __syncthreads();
-    if (L.do_rebuild)
-        for (int wi = tid; wi < f.n_lw; wi += NT) f.live[wi] = 0ull;
+    if (L.do_rebuild)  // the next pass lists the live chunks anew; it resets what the old ones leave behind
+        for (int wi = tid; wi < f.n_lw; wi += NT) { f.live[f.n_lw + wi] = load_live<COHERENT>(&f.live[wi]); f.live[wi] = 0ull; }
 }
 
 constexpr int FIN_THREADS = 1024;
@@ -1690,6 +1757,24 @@ __device__ __forceinline__ void scan_near_tiles(unsigned long long near, int uni
             lexmin(bd, bj, dist2(qx, qy, qz, a.tgt_s[6 * row], a.tgt_s[6 * row + 1], a.tgt_s[6 * row + 2]), a.tperm[row]);
     }
 }
+
+// Butterfly partner inside a row of 16 lanes by DPP -- a modifier on a move, no round trip through the LDS
+// crossbar like ds_bpermute.  LEVEL 0: lane ^ 1, 1: lane ^ 2 (quad permutes); 2, 3: lane 7 - i of the half row /
+// 15 - i of the row, i.e. SOME lane of the partner's group: in a symmetric reduction every lane of that group
+// holds what the partner holds once the lower levels are done, so the result is the xor butterfly's, bit for bit.
+template <int LEVEL>
+__device__ __forceinline__ int row_partner(int v) {
+    constexpr int ctrl = LEVEL == 0 ? 0xB1 : (LEVEL == 1 ? 0x4E : (LEVEL == 2 ? 0x141 : 0x140));
+    return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);
+}
+template <int LEVEL>
+__device__ __forceinline__ float row_partner(float v) { return __int_as_float(row_partner<LEVEL>(__float_as_int(v))); }
+template <int LEVEL>
+__device__ __forceinline__ double row_partner(double v) {
+    return __hiloint2double(row_partner<LEVEL>(__double2hiint(v)), row_partner<LEVEL>(__double2loint(v)));
+}
+template <int LEVEL>
+__device__ __forceinline__ double row_sum_step(double v) { return v + row_partner<LEVEL>(v); }
 
 // The MFMA loop of one wave over the n tiles of its LDS list against ITS sub-block (B operand b):
 // per lane -- slot lane & 15, target rows 4 (lane >> 4) .. + 3 of every tile -- the two best tiles
@@ -1759,7 +1844,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         t.Pk = pose_ptr(a0.Pk, pose_off); t.Tprev = pose_ptr(a0.Tprev, pose_off); t.live = pose_ptr(a0.live, pose_off);
         t.live_list = pose_ptr(a0.live_list, pose_off); t.hist = pose_ptr(a0.hist, pose_off);
         t.idx_out = pose_ptr(a0.idx_out, pose_off); t.partials = pose_ptr(a0.partials, pose_off);
-        t.packet = pose_ptr(a0.packet, pose_off);
+        t.packet = pose_ptr(a0.packet, pose_off); t.ticket = pose_ptr(a0.ticket, pose_off);
         sa = t;
     }
     const PassArgs &a = sa;
@@ -1774,10 +1859,21 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     if (st->done) return;
     const bool rebuild = st->rebuild != 0;
     const int n_live = st->n_live, pass = st->pass;
-    // EVERY workgroup of the launch takes a ticket, also those without a chunk: the pass is closed --
-    // and the state rewritten -- only after all of them have read the state (a batch's grid is not
-    // resident at once; a workgroup that starts late must not find the next pass's state)
-    const int n_wg = (int)gridDim.x;
+    const unsigned ticket_base = st->ticket_base;
+    // Workgroups with chunks take a ticket when they are through; the one that draws the last closes the
+    // pass.  The others leave at once -- but sign off first (a counter of sixteen, each on a line of its own:
+    // hundreds of atomics on one word in the first microsecond held up everybody's loads), and the closing
+    // workgroup rewrites the state only after all of them have: a batch's grid is not resident at once, a
+    // workgroup that starts late must not find the next pass's state.
+    int n_wg = rebuild ? a0.n_chunks : n_live;
+    n_wg = n_wg < (int)gridDim.x ? n_wg : (int)gridDim.x;
+    n_wg = n_wg < 1 ? 1 : n_wg;  // (no live chunk at all: workgroup 0 still closes the pass)
+    if ((int)blockIdx.x >= n_wg) {
+        if (a0.fuse && threadIdx.x == 0)
+            __hip_atomic_fetch_add((g_u32 *)(uintptr_t)(pose_ptr(a0.ticket, pose_off) + 32 * (1 + (blockIdx.x & 15))), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 #if PEDP_ICP_STAMPS
     if (threadIdx.x == 0 && pass < 32 && blockIdx.x < 512 && blockIdx.y == 0) g_icp_rt[pass][blockIdx.x][0] = rt_entry;
 #endif
@@ -1788,7 +1884,31 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     const double dnan = __longlong_as_double(0x7FF8000000000000ll);
     const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
     const float r_search = st->r_search;
-    for (int unit = blockIdx.x;; unit += gridDim.x) {
+    const double *Pk_in = a.Pk + (size_t)(pass & 1) * a.pp_stride, *Tp_in = a.Tprev + (size_t)(pass & 1) * a.pp_stride;
+    double *Pk_out = a.Pk + (size_t)((pass + 1) & 1) * a.pp_stride, *Tp_out = a.Tprev + (size_t)((pass + 1) & 1) * a.pp_stride;
+    // A rebuild pass asks the chunks' bounding spheres first (64 of this workgroup's chunks per round, one
+    // per lane, every wave for itself): a sphere moved by the pose so far that stays farther than r + margin
+    // from the target's box holds no live point -- the chunk is not touched (only, if it was live before,
+    // its points' correspondences are withdrawn).  The others are decided point by point as before.
+    unsigned long long todo = 0ull;  // wave-uniform: chunks of the current round still to visit
+    int todo_base = -64, it = 0;
+    double Rs[12], rscale = 1.0, reach = 0.0;
+    if (rebuild) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Rs[k] = st->T[k];
+        // |R x| <= rscale |x|: the square root of the largest row sum of |R^T R| bounds the spectral norm
+        double m = 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            double row = 0.0;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) row += fabs(Rs[u] * Rs[v] + Rs[4 + u] * Rs[4 + v] + Rs[8 + u] * Rs[8 + v]);
+            m = row > m ? row : m;
+        }
+        rscale = sqrt(m) * (1.0 + 1e-9);
+        reach = sqrt(st->r2live) * (1.0 + 1e-9);
+    }
+    for (;;) {
         // The thread index is made opaque per chunk: everything derived from it (LDS addresses, lane
         // masks, role predicates) is then computed where it is used instead of being hoisted out of
         // this loop and kept alive -- spilled -- through every phase.
@@ -1799,13 +1919,44 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         const int j = lane & 15, g = lane >> 4;  // MFMA layout: slot of the sub-block, row group / component
         const int frag = j * 4 + g;              // float offset inside a 16-point target tile
         const unsigned long long lt = (1ull << lane) - 1ull;
-        // a rebuild pass visits every chunk (unit = chunk id), other passes the live list (unit = rank);
+        // a rebuild pass visits chunks (unit = chunk id), other passes the live list (unit = rank);
         // `unit` also indexes the chunk's partial sums (see icp_finish_body)
-        int chunk;
+        int chunk, unit;
         if (rebuild) {
+            bool more = true;
+            while (todo == 0ull) {  // wave-uniform
+                todo_base += 64;
+                if ((long long)blockIdx.x + (long long)todo_base * (long long)gridDim.x >= (long long)a.n_chunks) { more = false; break; }
+                const long long u = (long long)blockIdx.x + (long long)(todo_base + lane) * (long long)gridDim.x;
+                bool visit = false, withdraw = false;
+                if (u < (long long)a.n_chunks) {
+                    const double cx = a.chunk_sph[4 * u], cy = a.chunk_sph[4 * u + 1], cz = a.chunk_sph[4 * u + 2], cr = a.chunk_sph[4 * u + 3];
+                    const bool was_live = (a.live[a.n_lw + (u >> 6)] >> (u & 63)) & 1ull;
+                    const double tx = Rs[0] * cx + Rs[1] * cy + Rs[2] * cz + Rs[3], ty = Rs[4] * cx + Rs[5] * cy + Rs[6] * cz + Rs[7],
+                                 tz = Rs[8] * cx + Rs[9] * cy + Rs[10] * cz + Rs[11];
+                    const double ex = fmax(fmax(a.lo[0] - tx, tx - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - ty, ty - a.hi[1]), 0.0),
+                                 ez = fmax(fmax(a.lo[2] - tz, tz - a.hi[2]), 0.0);
+                    const double lim = cr * rscale + reach + 1e-9 * (fabs(tx) + fabs(ty) + fabs(tz) + 1.0);
+                    visit = !(ex * ex + ey * ey + ez * ez > lim * lim);  // (also when anything is NaN)
+                    withdraw = !visit && was_live;
+                }
+                todo = __builtin_amdgcn_ballot_w64(visit);
+                unsigned long long wd = __builtin_amdgcn_ballot_w64(withdraw);
+                while (wd != 0ull) {  // rare: a chunk that was live and no longer is
+                    const int i = __builtin_ctzll(wd);
+                    wd &= wd - 1ull;
+                    const int64_t k = ((int64_t)blockIdx.x + (int64_t)(todo_base + i) * gridDim.x) * CH + tid;
+                    if (tid < CH && k < a.N) a.idx_out[a.perm[k]] = -1;
+                }
+            }
+            if (!more) break;
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            unit = (int)(blockIdx.x + (unsigned)(todo_base + i) * gridDim.x);
             chunk = unit;
-            if (chunk >= a.n_chunks) break;
         } else {
+            unit = (int)(blockIdx.x + (unsigned)it * gridDim.x);
+            ++it;
             if (unit >= n_live) break;
             chunk = unit == (int)blockIdx.x ? chunk_next : a.live_list[unit];
         }
@@ -1816,10 +1967,6 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         // the half's candidates in ascending position take the half's slots 0.., the wave keeps those
         // whose rank falls into its quarter
         int nsl;  // real slots of this wave's sub-block
-        bool st_valid, st_cand;  // what quarter 0 stores once every wave of the chunk has read its inputs
-        int st_pi;
-        int64_t st_k;
-        double st_x, st_y, st_z;
         {
             bool cand = false, near = false;
             int pi = -1;
@@ -1832,8 +1979,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                     x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
                     for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
                 } else {
-                    x = a.Pk[3 * k]; y = a.Pk[3 * k + 1]; z = a.Pk[3 * k + 2];
-                    const double ux = a.Tprev[3 * k], uy = a.Tprev[3 * k + 1], uz = a.Tprev[3 * k + 2];
+                    x = Pk_in[3 * k]; y = Pk_in[3 * k + 1]; z = Pk_in[3 * k + 2];
+                    const double ux = Tp_in[3 * k], uy = Tp_in[3 * k + 1], uz = Tp_in[3 * k + 2];
                     xform(st->upd, x, y, z);
                     // Temporal coherence: last pass's neighbour is still a target point, so the new nearest
                     // neighbour is no farther than it is now.  NaN (no neighbour last pass) fails the
@@ -1848,8 +1995,13 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             }
             const unsigned long long mc = __builtin_amdgcn_ballot_w64(cand), mn = __builtin_amdgcn_ballot_w64(near);
             const int wc = __builtin_popcountll(mc);
-            if (q4 == 0 && lane == 0) misc[half] = mn != 0ull;
-            st_valid = valid; st_cand = cand; st_pi = pi; st_k = k; st_x = x; st_y = y; st_z = z;
+            if (q4 == 0) {  // (the other copy: a wave of this half that comes late still reads this pass's inputs)
+                if (lane == 0) misc[half] = mn != 0ull;
+                if (valid) {  // (a rebuild pass stores every visited chunk's coordinates; only the live ones are read again)
+                    if (!cand) { a.idx_out[pi] = -1; Tp_out[3 * k] = dnan; }
+                    Pk_out[3 * k] = x; Pk_out[3 * k + 1] = y; Pk_out[3 * k + 2] = z;
+                }
+            }
             const int sl = __builtin_popcountll(mc & lt) - 16 * q4;
             if (cand && sl >= 0 && sl < 16) {
                 const float sx = (float)(x - ccx), sy = (float)(y - ccy), sz = (float)(z - ccz);
@@ -1870,15 +2022,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             nsl = nsl < 0 ? 0 : (nsl > 16 ? 16 : nsl);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
         }
-        // The four waves of a half read the same points and previous neighbours; the one that stores the
-        // transformed points does so only after all of them have (a wave that came late would otherwise
-        // transform a point twice).
-        __syncthreads();
-        if (q4 == 0 && st_valid) {  // (a rebuild pass stores every chunk's coordinates; only the live ones are read again)
-            if (!st_cand) { a.idx_out[st_pi] = -1; a.Tprev[3 * st_k] = dnan; }
-            a.Pk[3 * st_k] = st_x; a.Pk[3 * st_k + 1] = st_y; a.Pk[3 * st_k + 2] = st_z;
-        }
         if (rebuild) {  // is the chunk live?  (both halves' flags)
+            __syncthreads();
             const bool is_live = (misc[0] | misc[1]) != 0;
             if (!is_live) {  // workgroup-uniform: the chunk stays outside the live set
                 __syncthreads();  // (the flags are rewritten by the next chunk)
@@ -1915,24 +2060,28 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 bool open = real;   // no level of this lane's chain is in the cover yet
                 bool mine = false;  // this lane holds a node of the cover
                 int cut = 0;        // a chain inside this lane's current node has been closed
-#pragma unroll
-                for (int lev = 1; lev <= 4; ++lev) {
-                    const int off = 1 << (lev - 1);
-                    lx = fminf(lx, __shfl_xor(lx, off, 64)); hx = fmaxf(hx, __shfl_xor(hx, off, 64));
-                    ly = fminf(ly, __shfl_xor(ly, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64));
-                    lz = fminf(lz, __shfl_xor(lz, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
-                    rmx = fmaxf(rmx, __shfl_xor(rmx, off, 64));
+                auto level = [&](auto LV) {
+                    constexpr int lv = decltype(LV)::value;  // butterfly level 0..3: nodes of 2 << lv slots
+                    constexpr int off = 1 << lv;
+                    lx = fminf(lx, row_partner<lv>(lx)); hx = fmaxf(hx, row_partner<lv>(hx));
+                    ly = fminf(ly, row_partner<lv>(ly)); hy = fmaxf(hy, row_partner<lv>(hy));
+                    lz = fminf(lz, row_partner<lv>(lz)); hz = fmaxf(hz, row_partner<lv>(hz));
+                    rmx = fmaxf(rmx, row_partner<lv>(rmx));
                     const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
                     const float ex = hx - mx, ey = hy - my, ez = hz - mz;
                     const float rad = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f * (fabsf(mx) + fabsf(my) + fabsf(mz)) + 1e-30f;
                     // a node is cut where its sphere is wider than r -- or where a part of it has been cut already
                     // (so that rounding can never leave a slot outside the cover); lanes of one node agree
-                    cut |= __shfl_xor(cut, off, 64);
+                    cut |= row_partner<lv>(cut);
                     const bool wide_here = rad > wr || cut != 0;
                     // the level below is in the cover where this level is cut: its nodes close their chains
                     if (open && wide_here) { mine = (j & (off - 1)) == 0; open = false; cut = 1; }
                     if (open) { node = make_float4(mx, my, mz, rad); node_r = rmx; }
-                }
+                };
+                level(std::integral_constant<int, 0>{});
+                level(std::integral_constant<int, 1>{});
+                level(std::integral_constant<int, 2>{});
+                level(std::integral_constant<int, 3>{});
                 if (open) mine = j == 0;  // the whole sub-block is one node
                 const unsigned long long nm = __builtin_amdgcn_ballot_w64(mine && g == 0);
                 nn = __builtin_popcountll(nm);
@@ -1943,6 +2092,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
             }
+            PEDP_WV(7, __builtin_amdgcn_s_memtime());
             const float4 node0 = wnode[wv][0];
             const float node0_r = wnode_r[wv][0];
             // Can a target sphere ts (a tile's, or a whole mask word's) hold the nearest neighbour of a slot
@@ -2013,6 +2163,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                     }
                 }
             }
+            PEDP_WV(8, __builtin_amdgcn_s_memtime());
             if (lane < 2 * SW_G) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             sweep_sub_block(wtl[wv], n, a.tgtf, frag, bfrag, b1, t1, b2, t2, b3);
@@ -2150,7 +2301,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 const int64_t kp = (int64_t)chunk * CH + wkk[wv][j];
                 if (g == 0) {
                     a.idx_out[i] = jn;
-                    if (jn < 0) a.Tprev[3 * kp] = dnan;
+                    if (jn < 0) Tp_out[3 * kp] = dnan;
                 }
                 if (jn >= 0) {
                     const double sx = wp[wv][0][j], sy = wp[wv][1][j], sz = wp[wv][2][j];
@@ -2161,7 +2312,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                             nx = a.nrm[3 * (int64_t)jn]; ny = a.nrm[3 * (int64_t)jn + 1]; nz = a.nrm[3 * (int64_t)jn + 2];
                         }
                     }
-                    if (g == 0) { a.Tprev[3 * kp] = tx; a.Tprev[3 * kp + 1] = ty; a.Tprev[3 * kp + 2] = tz; }
+                    if (g == 0) { Tp_out[3 * kp] = tx; Tp_out[3 * kp + 1] = ty; Tp_out[3 * kp + 2] = tz; }
                     // entry k of the packet goes to lane group g = k % 4, accumulator k / 4
 #define PEDP_PUT(K, V)                                   \
     do {                                                 \
@@ -2196,7 +2347,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             for (int k = 0; k < 8; ++k) {
                 double v = acc[k];
 #pragma unroll
-                for (int off = 1; off <= 8; off <<= 1) v += __shfl_xor(v, off, 64);
+                for (int once = 0; once < 1; ++once) v = row_sum_step<3>(row_sum_step<2>(row_sum_step<1>(row_sum_step<0>(v))));
                 if (j == 0) accsh[wv][4 * k + g] = v;
             }
             // (entries 29, 30 of the tree are zero: the statistics replace them)
@@ -2229,8 +2380,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add((g_u32 *)(uintptr_t)&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        misc[4] = prev == (unsigned)(n_wg - 1);
+        const unsigned prev = __hip_atomic_fetch_add((g_u32 *)(uintptr_t)a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[4] = prev - ticket_base == (unsigned)(n_wg - 1);
     }
     __syncthreads();
     PEDP_RT(pass, 3);
@@ -2246,9 +2397,11 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     FinishArgs f;
     f.live = a.live; f.live_list = a.live_list; f.n_lw = a.n_lw; f.partials = a.partials; f.packet = a.packet; f.phase = 0;
     f.estimator = a.estimator; f.trace = a.trace; f.hist = a.hist; f.bcx = a.bc[0]; f.bcy = a.bc[1]; f.bcz = a.bc[2];
+    f.idle = a.ticket + 32;
+    f.n_idle = (int)gridDim.x - n_wg;
+    f.n_busy = n_wg;
     icp_finish_body<W * 64, 2048, true>(st, f, fin, threadIdx.x);
     PEDP_RT(pass, 4);
-    if (threadIdx.x == 0) __hip_atomic_store((g_u32 *)(uintptr_t)&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ host side
@@ -2280,6 +2433,7 @@ struct IcpWorkspace {
     // fused pass (qt == 1 inside a registration)
     bool fused;
     double *Pk, *hist, *cpart, *Tprev;
+    unsigned *ticket;
     unsigned long long *live;
     int32_t *live_list;
     int n_lw, n_chunks;
@@ -2346,14 +2500,15 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     size_t o_b1 = take(sizeof(float) * tr);
     size_t o_t1 = take(sizeof(int32_t) * tr);
     size_t o_b2 = take(sizeof(float) * tr);
-    size_t o_Pk = 0, o_hist = 0, o_cpart = 0, o_live = 0, o_llist = 0, o_tprev = 0;
+    size_t o_Pk = 0, o_hist = 0, o_cpart = 0, o_live = 0, o_llist = 0, o_tprev = 0, o_ticket = 0;
     if (fused) {
-        o_Pk = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
-        o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad);
+        o_Pk = take(sizeof(double) * 3 * (size_t)w.Ns_pad * 2);     // read from [pass & 1], written to the other: no wave
+        o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad * 2);  // ever reads what a faster wave of the same pass has rewritten
         o_hist = take(sizeof(double) * 16 * (size_t)iter_capacity(max_iter));
         o_cpart = take(sizeof(double) * PSTRIDE * (size_t)w.blocks_cap);
-        o_live = take(sizeof(unsigned long long) * (size_t)w.n_lw);
+        o_live = take(sizeof(unsigned long long) * 2 * (size_t)w.n_lw);  // live mask + the mask before the last rebuild
         o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
+        o_ticket = take(17 * 128);  // the ticket and the sixteen sign-off counters, a line each
     }
     off = align_up(off, 4096);
     w.pose_stride = off;  // a batch lays `poses` such blocks one behind the other
@@ -2388,6 +2543,7 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     w.cpart = (double *)(b + o_cpart);
     w.live = (unsigned long long *)(b + o_live);
     w.live_list = (int32_t *)(b + o_llist);
+    w.ticket = (unsigned *)(b + o_ticket);
     // the per-block survivor counters start at zero (the segment kernel re-zeroes them per pass)
     if (!fused) PEDP_HIP_CHECK(hipMemsetAsync(w.blk_cnt, 0, sizeof(int32_t) * (size_t)w.blocks_cap, c->stream));
     return PEDP_OK;
@@ -2463,6 +2619,8 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     PassArgs pa;
     pa.src = src->pts; pa.perm = w.src_perm; pa.N = src->N; pa.n_chunks = w.n_chunks;
     pa.hist = w.hist; pa.Pk = w.Pk; pa.Tprev = w.Tprev; pa.live = w.live; pa.live_list = w.live_list;
+    pa.chunk_sph = (const double *)src->chunk_sph;
+    pa.pp_stride = 3 * (size_t)w.Ns_pad;
     pa.tgtf = (const float *)w.tgt4; pa.n_tiles = (int)(w.Nt_pad / 16); pa.n_words = w.n_words;
     pa.tile_sph = w.tile_sph; pa.word_sph = w.word_sph; pa.tgt_s = w.tgt_s; pa.tperm = w.tgt_perm; pa.Nt = tgt->N;
     pa.tgt = tgt->pts; pa.nrm = tgt->normals;
@@ -2472,7 +2630,7 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     pa.pose_stride = poses > 1 ? w.pose_stride : 0;
     const int hand_env = handoff_mode();  // experiment
     pa.hand = hand_env;
-    pa.fuse = fuse && hand_env != 9 ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace;
+    pa.fuse = fuse && hand_env != 9 ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace; pa.ticket = w.ticket;
     // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
     int64_t g = w.n_chunks;
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
@@ -2512,7 +2670,18 @@ int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
         if (!rcs) { pedp_set_error("pedp_icp: spatial order: launch failed"); rcs = PEDP_ERR_HIP; }
         return rcs;
     }
+    const int64_t n_chunks = (cl->N + 127) / 128;
+    void *sph = nullptr;
+    if (hipMalloc(&sph, sizeof(double) * 4 * (size_t)n_chunks) != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(perm);
+        pedp_set_error("pedp_icp: chunk spheres: allocation failed");
+        return PEDP_ERR_ALLOC;
+    }
+    hipLaunchKernelGGL(chunk_sphere_kernel, dim3((unsigned)n_chunks), dim3(64), 0, c->stream, cl->pts, (const int32_t *)perm, cl->N,
+                       (double *)sph);
     cl->perm = perm;
+    cl->chunk_sph = sph;
     return PEDP_OK;
 }
 
@@ -2690,7 +2859,9 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     if (fused) {
         // history slot 0 = the start transformation; the live mask starts empty
         PEDP_HIP_CHECK(hipMemcpyAsync(w.hist, hp->T, sizeof(double) * 16, hipMemcpyHostToDevice, x->stream));
-        PEDP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(unsigned long long) * (size_t)w.n_lw, x->stream));
+        PEDP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(unsigned long long) * 2 * (size_t)w.n_lw, x->stream));
+        PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, x->stream));  // chunks a rebuild pass never touches have no correspondences
+        PEDP_HIP_CHECK(hipMemsetAsync(w.ticket, 0, 17 * 128, x->stream));
         for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
     }
     if (job.timed_pass != -1) x->nn_pairs = 0;
@@ -2920,7 +3091,9 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
                                         hipMemcpyHostToDevice, c->stream));
         PEDP_HIP_CHECK(hipMemcpy2DAsync(w.hist, w.pose_stride, up[0].T, sizeof(IcpState), sizeof(double) * 16, (size_t)G,
                                         hipMemcpyHostToDevice, c->stream));
-        PEDP_HIP_CHECK(hipMemset2DAsync(w.live, w.pose_stride, 0, sizeof(unsigned long long) * (size_t)w.n_lw, (size_t)G, c->stream));
+        PEDP_HIP_CHECK(hipMemset2DAsync(w.live, w.pose_stride, 0, sizeof(unsigned long long) * 2 * (size_t)w.n_lw, (size_t)G, c->stream));
+        PEDP_HIP_CHECK(hipMemset2DAsync(w.idx, w.pose_stride, 0xFF, sizeof(int32_t) * (size_t)job.Ns, (size_t)G, c->stream));
+        PEDP_HIP_CHECK(hipMemset2DAsync(w.ticket, w.pose_stride, 0, 17 * 128, (size_t)G, c->stream));
         bool finished = false;
         for (int guard = 0; guard < (1 << 20) && !finished; ++guard) {
             PEDP_HIP_CHECK(hipGraphLaunch(c->icp_bgraph[slot], c->stream));

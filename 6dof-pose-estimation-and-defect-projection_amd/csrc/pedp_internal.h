@@ -158,6 +158,7 @@ struct pedp_cloud_s {
     // additionally the sorted float4 operand (x', y', z', |t'|^2), padded, and one bounding
     // sphere per 16-row tile.
     void *perm = nullptr;       // built from the cloud alone (its own bounding box): never rebuilt
+    void *chunk_sph = nullptr;  // with it: bounding sphere (float64 x 4) of every 128 consecutive points of that order
     void *tgt4 = nullptr;
     void *tile_sph = nullptr;   // one sphere per 16 sorted rows
     void *tile_sph4 = nullptr;  // one sphere per 64 sorted rows

@@ -79,9 +79,9 @@ if hasattr(lib, "pedp_debug_icp_rt") and lib.pedp_debug_icp_rt(C.c_void_p(rt.cty
         prev_close = last
         print(line)
 # per-wave view of the last pass
-wvb = np.zeros((512, 8, 8), np.int64)
+wvb = np.zeros((512, 8, 12), np.int64)
 if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wvb.ctypes.data)) == 0:
-    w = wvb.reshape(-1, 8)
+    w = wvb.reshape(-1, 12)
     w = w[(w[:, 4] > 0) & (w[:, 2] > 0)]
     w = w[w[:, 0] > w[:, 0].max() - 60 * mhz]
     ph = np.diff(w[:, :5], axis=1) * tick
@@ -89,6 +89,7 @@ if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wv
     print(f"waves with slots in the last pass: {len(w)}; wide {int(wide.sum())}")
     for k, n in enumerate(["slots ready", "cull+sweep", "select", "sums"]):
         print(f"   {n:12s} median {np.median(ph[:,k]):6.2f} p90 {np.percentile(ph[:,k],90):6.2f} max {ph[:,k].max():6.2f}")
+    print(f"   inside cull+sweep: cover {np.median((w[:,7]-w[:,1])*tick):5.2f} (p90 {np.percentile((w[:,7]-w[:,1])*tick,90):5.2f}) | word + tile tests, list {np.median((w[:,8]-w[:,7])*tick):5.2f} (p90 {np.percentile((w[:,8]-w[:,7])*tick,90):5.2f}) | sweep {np.median((w[:,2]-w[:,8])*tick):5.2f} (p90 {np.percentile((w[:,2]-w[:,8])*tick,90):5.2f})")
     print(f"   words median {np.median(words)} p90 {np.percentile(words,90)} max {words.max()}; batches median {np.median(batches)} max {batches.max()}; tiles median {np.median(tiles)} p90 {np.percentile(tiles,90)} max {tiles.max()}")
     cs = ph[:, 1]
     for b in sorted(set(batches.tolist())):
