@@ -202,43 +202,46 @@ __global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, doubl
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) key[i] = point_cell(pts, i, lox, loy, loz, sx, sy, sz);
 }
-// Bounding sphere (centre xyz, radius; float64, the cloud's own frame) of every 128 consecutive points
-// of the spatial order: a rebuild pass of a registration asks the spheres, moved by the pose so far,
-// which chunks can be near the target at all, and touches only those chunks' points.  One wave per
-// chunk, two points per lane.
+// Bounding spheres (centre xyz, radius; float64, the cloud's own frame) of the eight runs of 16 consecutive
+// points of every 128-point chunk of the spatial order: a rebuild pass of a registration asks the spheres,
+// moved by the pose so far, which chunks can be near the target at all, and touches only those chunks'
+// points.  (One sphere per chunk let through twice as many chunks as are live; with eight the workgroups of a
+// rebuild pass mostly get one chunk each.)  One wave per chunk: lane = point of a half, 16 lanes = a run.
 __global__ __launch_bounds__(64) void chunk_sphere_kernel(const double *__restrict__ pts, const int32_t *__restrict__ perm,
-                                                          int64_t N, double *__restrict__ sph) {
+                                                          int64_t N, double *__restrict__ sph /* [chunk][8][4] */) {
     const int64_t chunk = blockIdx.x;
     const int lane = threadIdx.x;
     const double big = 1.7976931348623157e308;
-    double lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
     for (int h = 0; h < 2; ++h) {
+        double lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
         const int64_t k = chunk * 128 + h * 64 + lane;
         if (k < N) {
             const int64_t i = perm[k];
-            for (int c = 0; c < 3; ++c) {
-                const double v = pts[3 * i + c];
-                lo[c] = v < lo[c] ? v : lo[c];
-                hi[c] = v > hi[c] ? v : hi[c];
+            for (int c = 0; c < 3; ++c) lo[c] = hi[c] = pts[3 * i + c];
+        }
+        for (int c = 0; c < 3; ++c)
+            for (int off = 8; off >= 1; off >>= 1) {
+                const double l2 = __shfl_xor(lo[c], off, 64), h2 = __shfl_xor(hi[c], off, 64);
+                lo[c] = l2 < lo[c] ? l2 : lo[c];
+                hi[c] = h2 > hi[c] ? h2 : hi[c];
+            }
+        if ((lane & 15) == 0) {
+            double *o = sph + ((chunk * 8) + h * 4 + (lane >> 4)) * 4;
+            if (!(hi[0] >= lo[0])) {  // a run behind the cloud's last point: matches nothing
+                o[0] = o[1] = o[2] = 0.0;
+                o[3] = -1.0;
+            } else {
+                double m[3], r2 = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    m[c] = 0.5 * (lo[c] + hi[c]);
+                    const double e = hi[c] - m[c];
+                    r2 += e * e;
+                }
+                // non-finite coordinates give a non-finite sphere: such a chunk is never skipped
+                o[0] = m[0]; o[1] = m[1]; o[2] = m[2];
+                o[3] = sqrt(r2) * (1.0 + 1e-12) + 1e-300;
             }
         }
-    }
-    for (int c = 0; c < 3; ++c)
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double l2 = __shfl_xor(lo[c], off, 64), h2 = __shfl_xor(hi[c], off, 64);
-            lo[c] = l2 < lo[c] ? l2 : lo[c];
-            hi[c] = h2 > hi[c] ? h2 : hi[c];
-        }
-    if (lane == 0) {
-        double m[3], r2 = 0.0;
-        for (int c = 0; c < 3; ++c) {
-            m[c] = 0.5 * (lo[c] + hi[c]);
-            const double e = hi[c] - m[c];
-            r2 += e * e;
-        }
-        // non-finite coordinates give a non-finite sphere: such a chunk is never skipped
-        sph[4 * chunk] = m[0]; sph[4 * chunk + 1] = m[1]; sph[4 * chunk + 2] = m[2];
-        sph[4 * chunk + 3] = sqrt(r2) * (1.0 + 1e-12) + 1e-300;
     }
 }
 
@@ -1409,7 +1412,7 @@ struct PassArgs {
     double *Tprev;              // 2 x N_pad x 3: last pass's nearest neighbour of the point at that position (x = NaN: none); likewise
     size_t pp_stride;           // doubles between the two copies
     unsigned long long *live;   // live mask (n_lw words), behind it the mask before the last rebuild (n_lw words)
-    const double *chunk_sph;    // bounding sphere of every chunk in the source frame
+    const double *chunk_sph;    // [chunk][8][4]: bounding spheres of the chunk's eight 16-point runs in the source frame
     int32_t *live_list;         // live chunks ascending (valid outside rebuild passes)
     // target
     const float *tgtf;          // sorted target operand, 64 floats per 16-row tile
@@ -1506,6 +1509,13 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
     static_assert(NT % 32 == 0 && PARTS % TPARTS == 0, "thread count");
     if (tid == 0) PEDP_STAMP(2, 0, 0);
     if (tid == 0 && pass == 5) PEDP_STAMP(2, 3, 0);
+    // what the solving thread needs of the state is requested now, ahead of the sums
+    double T0[16], fit0 = 0.0, rmse0 = 0.0, mu_th0 = 0.0, mu_ta0 = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T0[k] = st->T[k];
+        fit0 = st->fitness; rmse0 = st->rmse; mu_th0 = st->mu_theta; mu_ta0 = st->mu_tau;
+    }
 #if PEDP_ICP_STAMPS
     if (tid == 0) { g_icp_stamps[2][1][0] = (long long)__builtin_amdgcn_s_memtime(); g_icp_stamps[2][1][1] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -1629,18 +1639,18 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         const double K = pk[28];
         double fit = 0.0, rmse = 0.0;
         if (K > 0.0) { fit = K / n_source; rmse = sqrt(pk[27] / K); }
-        st->prev_fitness = st->fitness;
-        st->prev_rmse = st->rmse;
+        st->prev_fitness = fit0;
+        st->prev_rmse = rmse0;
         st->fitness = fit;
         st->rmse = rmse;
         if (f.trace) {
             double *tr = f.trace + 18 * pass;
             tr[0] = fit; tr[1] = rmse;
-            for (int k = 0; k < 16; ++k) tr[2 + k] = st->T[k];
+            for (int k = 0; k < 16; ++k) tr[2 + k] = T0[k];
         }
         st->iters = pass;
         bool stop = pass >= max_iter;
-        if (pass > 0 && fabs(st->prev_fitness - fit) < rel_fitness && fabs(st->prev_rmse - rmse) < rel_rmse) stop = true;
+        if (pass > 0 && fabs(fit0 - fit) < rel_fitness && fabs(rmse0 - rmse) < rel_rmse) stop = true;
         if (stop) {
             st->done = 1;
         } else {
@@ -1685,7 +1695,11 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
             PEDP_STAMP(2, 0, 2);
             if (pass == 5) PEDP_STAMP(2, 3, 5);
             for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; f.hist[16 * (pass + 1) + k] = upd[k]; }
-            mat4_mul_dev(upd, st->T, st->T);
+            {
+                double Tn[16];
+                mat4_mul_dev(upd, T0, Tn);
+                for (int k = 0; k < 16; ++k) st->T[k] = Tn[k];
+            }
             // how far this update can move a point near the target: |R - I|_F (>= the spectral norm) and
             // |t + (R - I) c| about the box centre c
             double th2 = 0.0, tv[3];
@@ -1698,15 +1712,16 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
                     tv[u] += dlt * cc[v];
                 }
             }
-            st->mu_theta += sqrt(th2);
-            st->mu_tau += sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
-            const double mu = st->mu_theta * reachE + st->mu_tau;
+            double mu_th = mu_th0 + sqrt(th2), mu_ta = mu_ta0 + sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+            const double mu = mu_th * reachE + mu_ta;
             if (!(mu < 0.95 * margin)) {  // also when mu is NaN
                 L.do_rebuild = 1;
-                st->mu_theta = 0.0;
-                st->mu_tau = 0.0;
+                mu_th = 0.0;
+                mu_ta = 0.0;
                 st->n_rebuilds += 1;
             }
+            st->mu_theta = mu_th;
+            st->mu_tau = mu_ta;
             st->rebuild = L.do_rebuild;
             st->pass = pass + 1;
             PEDP_STAMP(2, 2, 3);
@@ -1837,7 +1852,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     __shared__ float wcs[W][3][16], weps[W][16], wS[W][16], wrho[W][16];
     __shared__ int wpi[W][16], wkk[W][16], misc[8];
     __shared__ unsigned wtl[W][WTL + 2 * SW_G];
-    __shared__ float4 wnode[W][16];
+    __shared__ float4 wnode[W][16], wsph0[64];
+    __shared__ double rbs[16];  // rebuild passes: the pose so far (3 x 4), its norm bound, the reach
     __shared__ float wnode_r[W][16];
     if (threadIdx.x == 0) {
         PassArgs t = a0;
@@ -1854,8 +1870,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     // the first unit's live-list entry is requested together with the state (the list has one entry
     // per chunk, so the index is always inside it; the value is used only when it is valid)
     int chunk_next = pose_ptr(a0.live_list, pose_off)[blockIdx.x < (unsigned)a0.n_chunks ? blockIdx.x : 0];
-    // word spheres do not depend on the chunk: the first 64 are requested before anything else (lane l: word l)
-    const float4 ws0 = a0.word_sph[(int)(threadIdx.x & 63) < a0.n_words ? (threadIdx.x & 63) : 0];
+    // word spheres do not depend on the chunk: the first 64 are requested before anything else and parked in LDS
+    if (threadIdx.x < 64) wsph0[threadIdx.x] = a0.word_sph[(int)threadIdx.x < a0.n_words ? threadIdx.x : 0];
     if (st->done) return;
     const bool rebuild = st->rebuild != 0;
     const int n_live = st->n_live, pass = st->pass;
@@ -1878,24 +1894,21 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     if (threadIdx.x == 0 && pass < 32 && blockIdx.x < 512 && blockIdx.y == 0) g_icp_rt[pass][blockIdx.x][0] = rt_entry;
 #endif
     PEDP_RT(pass, 1);
-    __syncthreads();  // the argument block is in LDS
     const float inf = __uint_as_float(0x7F800000u);
     const double dinf = __longlong_as_double(0x7FF0000000000000ll);
     const double dnan = __longlong_as_double(0x7FF8000000000000ll);
     const double ccx = st->centroid[0], ccy = st->centroid[1], ccz = st->centroid[2];
     const float r_search = st->r_search;
-    const double *Pk_in = a.Pk + (size_t)(pass & 1) * a.pp_stride, *Tp_in = a.Tprev + (size_t)(pass & 1) * a.pp_stride;
-    double *Pk_out = a.Pk + (size_t)((pass + 1) & 1) * a.pp_stride, *Tp_out = a.Tprev + (size_t)((pass + 1) & 1) * a.pp_stride;
     // A rebuild pass asks the chunks' bounding spheres first (64 of this workgroup's chunks per round, one
     // per lane, every wave for itself): a sphere moved by the pose so far that stays farther than r + margin
     // from the target's box holds no live point -- the chunk is not touched (only, if it was live before,
     // its points' correspondences are withdrawn).  The others are decided point by point as before.
     unsigned long long todo = 0ull;  // wave-uniform: chunks of the current round still to visit
     int todo_base = -64, it = 0;
-    double Rs[12], rscale = 1.0, reach = 0.0;
-    if (rebuild) {
+    if (rebuild && threadIdx.x == 0) {
+        double Rs[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) Rs[k] = st->T[k];
+        for (int k = 0; k < 12; ++k) { Rs[k] = st->T[k]; rbs[k] = Rs[k]; }
         // |R x| <= rscale |x|: the square root of the largest row sum of |R^T R| bounds the spectral norm
         double m = 0.0;
 #pragma unroll
@@ -1905,9 +1918,10 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             for (int v = 0; v < 3; ++v) row += fabs(Rs[u] * Rs[v] + Rs[4 + u] * Rs[4 + v] + Rs[8 + u] * Rs[8 + v]);
             m = row > m ? row : m;
         }
-        rscale = sqrt(m) * (1.0 + 1e-9);
-        reach = sqrt(st->r2live) * (1.0 + 1e-9);
+        rbs[12] = sqrt(m) * (1.0 + 1e-9);
+        rbs[13] = sqrt(st->r2live) * (1.0 + 1e-9);
     }
+    __syncthreads();  // the argument block, the word spheres (and the rebuild constants) are in LDS
     for (;;) {
         // The thread index is made opaque per chunk: everything derived from it (LDS addresses, lane
         // masks, role predicates) is then computed where it is used instead of being hoisted out of
@@ -1921,6 +1935,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         const unsigned long long lt = (1ull << lane) - 1ull;
         // a rebuild pass visits chunks (unit = chunk id), other passes the live list (unit = rank);
         // `unit` also indexes the chunk's partial sums (see icp_finish_body)
+        const double *Pk_in = a.Pk + (size_t)(pass & 1) * a.pp_stride, *Tp_in = a.Tprev + (size_t)(pass & 1) * a.pp_stride;
+        double *Pk_out = a.Pk + (size_t)((pass + 1) & 1) * a.pp_stride, *Tp_out = a.Tprev + (size_t)((pass + 1) & 1) * a.pp_stride;
         int chunk, unit;
         if (rebuild) {
             bool more = true;
@@ -1930,14 +1946,22 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 const long long u = (long long)blockIdx.x + (long long)(todo_base + lane) * (long long)gridDim.x;
                 bool visit = false, withdraw = false;
                 if (u < (long long)a.n_chunks) {
-                    const double cx = a.chunk_sph[4 * u], cy = a.chunk_sph[4 * u + 1], cz = a.chunk_sph[4 * u + 2], cr = a.chunk_sph[4 * u + 3];
+                    double Rs[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) Rs[k] = rbs[k];
+                    const double rscale = rbs[12], reach = rbs[13];
                     const bool was_live = (a.live[a.n_lw + (u >> 6)] >> (u & 63)) & 1ull;
-                    const double tx = Rs[0] * cx + Rs[1] * cy + Rs[2] * cz + Rs[3], ty = Rs[4] * cx + Rs[5] * cy + Rs[6] * cz + Rs[7],
-                                 tz = Rs[8] * cx + Rs[9] * cy + Rs[10] * cz + Rs[11];
-                    const double ex = fmax(fmax(a.lo[0] - tx, tx - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - ty, ty - a.hi[1]), 0.0),
-                                 ez = fmax(fmax(a.lo[2] - tz, tz - a.hi[2]), 0.0);
-                    const double lim = cr * rscale + reach + 1e-9 * (fabs(tx) + fabs(ty) + fabs(tz) + 1.0);
-                    visit = !(ex * ex + ey * ey + ez * ez > lim * lim);  // (also when anything is NaN)
+#pragma unroll 2
+                    for (int sb = 0; sb < 8; ++sb) {
+                        const double *sp8 = a.chunk_sph + (size_t)(8 * u + sb) * 4;
+                        const double cx = sp8[0], cy = sp8[1], cz = sp8[2], cr = sp8[3];
+                        const double tx = Rs[0] * cx + Rs[1] * cy + Rs[2] * cz + Rs[3], ty = Rs[4] * cx + Rs[5] * cy + Rs[6] * cz + Rs[7],
+                                     tz = Rs[8] * cx + Rs[9] * cy + Rs[10] * cz + Rs[11];
+                        const double ex = fmax(fmax(a.lo[0] - tx, tx - a.hi[0]), 0.0), ey = fmax(fmax(a.lo[1] - ty, ty - a.hi[1]), 0.0),
+                                     ez = fmax(fmax(a.lo[2] - tz, tz - a.hi[2]), 0.0);
+                        const double lim = cr * rscale + reach + 1e-9 * (fabs(tx) + fabs(ty) + fabs(tz) + 1.0);
+                        visit |= !(cr < 0.0) && !(ex * ex + ey * ey + ez * ez > lim * lim);  // (also when anything is NaN)
+                    }
                     withdraw = !visit && was_live;
                 }
                 todo = __builtin_amdgcn_ballot_w64(visit);
@@ -2124,7 +2148,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             int n = 0;
             for (int R = 0; R * 64 < a.n_words; ++R) {
                 const int wi = R * 64 + lane;
-                const float4 wsR = R == 0 ? ws0 : a.word_sph[wi < a.n_words ? wi : 0];
+                const float4 wsR = R == 0 ? wsph0[lane] : a.word_sph[wi < a.n_words ? wi : 0];
                 unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_sb(wsR));
 #if PEDP_ICP_STAMPS
                 dbg_words += __builtin_popcountll(km);
@@ -2177,6 +2201,16 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             // four rows it saw of its best tile (and of its second best, if that is inside the window too) in
             // float64 with the oracle's formula, lexicographic (d^2, index); a third tile of one lane inside
             // the window sends the slot to the exact search.
+            auto load_rows = [&](int tile, double (&rw)[4][6], int (&ri)[4]) {
+                const int64_t row0 = (int64_t)tile * 16 + 4 * g;  // this lane's rows of the tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r < a.Nt ? row0 + r : 0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) rw[r][c] = a.tgt_s[6 * row + c];
+                    ri[r] = a.tperm[row];
+                }
+            };
             const float e = real ? weps[wv][j] : 0.f, Si = real ? wS[wv][j] : 3e38f;
             const double qx = wp[wv][0][j], qy = wp[wv][1][j], qz = wp[wv][2][j];
             float mg = fminf(b1, __shfl_xor(b1, 16, 64));
@@ -2185,17 +2219,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             const float win = mg + 2.0f * e;
             double bd = dinf;
             int bj = 0x7FFFFFFF;
-            auto rescore = [&](int tile) {
-                const int64_t row0 = (int64_t)tile * 16 + 4 * g;  // this lane's rows of the tile
-                double rw[4][6];
-                int ri[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + r < a.Nt ? row0 + r : 0;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) rw[r][c] = a.tgt_s[6 * row + c];
-                    ri[r] = a.tperm[row];
-                }
+            auto eval_rows = [&](int tile, const double (&rw)[4][6], const int (&ri)[4]) {
+                const int64_t row0 = (int64_t)tile * 16 + 4 * g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (row0 + r < a.Nt) {
@@ -2208,9 +2233,19 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                     }
                 }
             };
-            if (maybe && b1 <= win) rescore(t1);
+            if (maybe && b1 <= win) {
+                double rw1[4][6];
+                int ri1[4];
+                load_rows(t1, rw1, ri1);
+                eval_rows(t1, rw1, ri1);
+            }
             if (__builtin_amdgcn_ballot_w64(maybe && b2 <= win) != 0ull) {  // (about one lane in a hundred)
-                if (maybe && b2 <= win) rescore(t2);
+                if (maybe && b2 <= win) {
+                    double rw2[4][6];
+                    int ri2[4];
+                    load_rows(t2, rw2, ri2);
+                    eval_rows(t2, rw2, ri2);
+                }
             }
             // the slot's winner over its four lanes; the lane that holds it hands neighbour and normal over
             fd = bd;
@@ -2260,7 +2295,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 int xj = 0x7FFFFFFF;
                 for (int R = 0; R * 64 < a.n_words; ++R) {
                     const int wi = R * 64 + lane;
-                    const float4 wsR = R == 0 ? ws0 : a.word_sph[wi < a.n_words ? wi : 0];
+                    const float4 wsR = R == 0 ? wsph0[lane] : a.word_sph[wi < a.n_words ? wi : 0];
                     unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_pt(wsR));
                     while (km != 0ull) {
                         const int word = R * 64 + __builtin_ctzll(km);
@@ -2672,7 +2707,7 @@ int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
     }
     const int64_t n_chunks = (cl->N + 127) / 128;
     void *sph = nullptr;
-    if (hipMalloc(&sph, sizeof(double) * 4 * (size_t)n_chunks) != hipSuccess) {
+    if (hipMalloc(&sph, sizeof(double) * 32 * (size_t)n_chunks) != hipSuccess) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(perm);
         pedp_set_error("pedp_icp: chunk spheres: allocation failed");
