@@ -1271,6 +1271,9 @@ __device__ __forceinline__ void swap_if(bool c, double &x, double &y) {
     y = c ? t : y;
 }
 __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__restrict__ b, double *__restrict__ x) {
+    // ONE thread runs this; its pivot index is made wave-uniform (readfirstlane: the only active lane), so the
+    // exchange of step k is a scalar branch to the one pair of rows and columns concerned instead of a
+    // predicated swap for every candidate row (5 + 4 + 3 + 2 + 1 times 12 swaps: a third of the solve).
     double A[6][6], y[6];
     int tr[6];
 #pragma unroll
@@ -1284,14 +1287,16 @@ __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__
 #pragma unroll
         for (int i = k + 1; i < 6; ++i)
             if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
+        p = __builtin_amdgcn_readfirstlane(p);
         tr[k] = p;
 #pragma unroll
         for (int q = k + 1; q < 6; ++q) {
-            const bool sw = p == q;
+            if (p == q) {  // scalar branch
 #pragma unroll
-            for (int j = 0; j < 6; ++j) swap_if(sw, A[k][j], A[q][j]);
+                for (int j = 0; j < 6; ++j) { const double t = A[k][j]; A[k][j] = A[q][j]; A[q][j] = t; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) swap_if(sw, A[i][k], A[i][q]);
+                for (int i = 0; i < 6; ++i) { const double t = A[i][k]; A[i][k] = A[i][q]; A[i][q] = t; }
+            }
         }
         if (k > 0) {
             double tmp[6];
@@ -1320,7 +1325,8 @@ __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int q = k + 1; q < 6; ++q) swap_if(tr[k] == q, y[k], y[q]);
+        for (int q = k + 1; q < 6; ++q)
+            if (tr[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -1337,7 +1343,8 @@ __device__ bool solve6_ldlt_reg(const double *__restrict__ Ain, const double *__
 #pragma unroll
     for (int k = 5; k >= 0; --k)
 #pragma unroll
-        for (int q = k + 1; q < 6; ++q) swap_if(tr[k] == q, y[k], y[q]);
+        for (int q = k + 1; q < 6; ++q)
+            if (tr[k] == q) { const double t = y[k]; y[k] = y[q]; y[q] = t; }
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1433,7 +1440,7 @@ struct PassArgs {
     // b * pose_stride bytes behind pose 0's.
     size_t pose_stride;
     // the finish inside the launch (fuse != 0)
-    int fuse, n_lw, hand;
+    int fuse, n_lw;
     unsigned *ticket;           // workgroups of the running launch that are through (the last one closes the pass); a line of its own:
                                 // 512 atomics on the state's line held up every wave's reads of the state
     double *packet, *trace;
@@ -2002,6 +2009,10 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 if (rebuild) {
                     x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
                     for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                    // a chunk that was live in the pass before has that pass's neighbours (every point of a live
+                    // chunk gets one, or NaN): the search radii need not start from r again
+                    if ((a.live[a.n_lw + (chunk >> 6)] >> (chunk & 63)) & 1ull)
+                        dprev = sqrt(dist2(x, y, z, Tp_in[3 * k], Tp_in[3 * k + 1], Tp_in[3 * k + 2]));
                 } else {
                     x = Pk_in[3 * k]; y = Pk_in[3 * k + 1]; z = Pk_in[3 * k + 2];
                     const double ux = Tp_in[3 * k], uy = Tp_in[3 * k + 1], uz = Tp_in[3 * k + 2];
@@ -2410,10 +2421,6 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     // ---- the pass is closed by the workgroup that finishes last
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
     __syncthreads();
-    if (threadIdx.x == 0 && (a.hand & 2)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add((g_u32 *)(uintptr_t)a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         misc[4] = prev - ticket_base == (unsigned)(n_wg - 1);
@@ -2421,13 +2428,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     __syncthreads();
     PEDP_RT(pass, 3);
     if (!misc[4]) return;
-    if (a.hand & 1) {
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
+
     if (threadIdx.x == 0) PEDP_STAMP(1, blockIdx.x, 6);
     FinishArgs f;
     f.live = a.live; f.live_list = a.live_list; f.n_lw = a.n_lw; f.partials = a.partials; f.packet = a.packet; f.phase = 0;
@@ -2643,8 +2644,10 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
 // Margin of the live set beyond the correspondence radius (see the fused-pass comment).
 inline double fused_margin(double r) { return 2.0 * r; }
 
-inline int handoff_mode() {
-    static const int m = getenv("PEDP_ICP_HANDOFF") ? atoi(getenv("PEDP_ICP_HANDOFF")) : 0;
+// Test hook (tests/test_icp_gpu.py): PEDP_ICP_UNFUSED_FINISH=1 closes every pass with a launch of
+// icp_finish_kernel instead of the in-launch hand-over -- the results must not differ in any bit.
+inline bool unfused_finish() {
+    static const bool m = getenv("PEDP_ICP_UNFUSED_FINISH") && atoi(getenv("PEDP_ICP_UNFUSED_FINISH")) != 0;
     return m;
 }
 // Enqueue the kernel of a fused pass.  fuse: the workgroup that finishes last closes the pass
@@ -2663,9 +2666,7 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     for (int k = 0; k < 3; ++k) { pa.lo[k] = tp.lo[k]; pa.hi[k] = tp.hi[k]; pa.bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]); }
     pa.estimator = estimator; pa.idx_out = w.idx; pa.partials = w.cpart;
     pa.pose_stride = poses > 1 ? w.pose_stride : 0;
-    const int hand_env = handoff_mode();  // experiment
-    pa.hand = hand_env;
-    pa.fuse = fuse && hand_env != 9 ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace; pa.ticket = w.ticket;
+    pa.fuse = fuse && !unfused_finish() ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace; pa.ticket = w.ticket;
     // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
     int64_t g = w.n_chunks;
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
@@ -2915,7 +2916,7 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
         if (fused) {
             rc = enqueue_fused_pass(x, w, source, target, prm->estimator, tp, ev0, ev1, !exchange, want_trace ? w.trace : nullptr);
             if (rc) return rc;
-            if (!exchange && handoff_mode() == 9)
+            if (!exchange && unfused_finish())
                 hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(FIN_THREADS), 0, x->stream, w.st, w.live, w.live_list, w.n_lw, w.cpart, w.packet, 0,
                                    prm->estimator, want_trace ? w.trace : nullptr, w.hist, bc[0], bc[1], bc[2], (size_t)0);
             if (exchange) {  // sum -> all-reduce over the ranks -> solve
@@ -3091,7 +3092,7 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
         PEDP_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         for (int p = 0; p < key.seg && !rc; ++p) {
             rc = enqueue_fused_pass(c, w, source, target, prms[0].estimator, tp, nullptr, nullptr, true, nullptr, G);
-            if (handoff_mode() == 9)
+            if (unfused_finish())
                 hipLaunchKernelGGL(icp_finish_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, c->stream, w.st, w.live, w.live_list,
                                    w.n_lw, w.cpart, w.packet, 0, prms[0].estimator, (double *)nullptr, w.hist,
                                    0.5 * (tp.lo[0] + tp.hi[0]), 0.5 * (tp.lo[1] + tp.hi[1]), 0.5 * (tp.lo[2] + tp.hi[2]),

@@ -256,17 +256,16 @@ def test_two_ranks_on_one_gpu_product_backend(oracle, tmp_path):
         assert not bool(r["native"])             # two ranks on one GPU: RCCL refuses, torch collectives stay
     assert np.array_equal(r0["T"], r1["T"])      # every rank holds the identical pose
     assert np.array_equal(r0["sT"], r1["sT"])
-    # batched-pose sharding: both ranks hold all 5 results, equal to single calls (same correspondences,
-    # hence the same fitness; the float64 sums follow the scene's spatial order, which a rank builds
-    # over ITS poses' region, so the pose agrees to rounding, not to the bit)
+    # batched-pose sharding: both ranks hold all 5 results, equal to single calls BIT FOR BIT: the scene's
+    # spatial order -- and with it the order of every float64 sum -- is a function of the cloud alone
     from pedp_hip import _lib
     ctx = _lib.default_context()
     src, tgt = _lib.Cloud(ctx, g["scene_noisy"]), _lib.Cloud(ctx, g["model"], g["normals"])
     assert np.array_equal(r0["bT"], r1["bT"]) and np.array_equal(r0["bfit"], r1["bfit"])
     for b in range(5):
         one = _lib.icp(ctx, src, tgt, 10.0, r0["binits"][b], max_iteration=4, relative_fitness=-1, relative_rmse=-1)
-        assert np.abs(r0["bT"][b] - one["T"]).max() < 1e-9 and r0["bfit"][b] == one["fitness"]
-        assert abs(r0["brmse"][b] - one["inlier_rmse"]) < 1e-12
+        assert np.array_equal(r0["bT"][b], one["T"]) and r0["bfit"][b] == one["fitness"]
+        assert r0["brmse"][b] == one["inlier_rmse"]
 
 
 def test_native_rccl_communicator_single_rank(oracle):

@@ -54,17 +54,26 @@ def test_bench_100k_icp_matches_oracle_and_ground_truth(ctx, oracle, frame100k):
     depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
     scene = f.scene(depth)
     src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
-    res = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=4, relative_fitness=-1, relative_rmse=-1,
+    # the bench's workload -- 20 iterations -- against the oracle's KD-tree run: every one of the 21 passes
+    # (fitness equal, rmse and pose to rounding) and the final correspondence set
+    res = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1,
                    want_corr=True, want_trace=True)
-    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=4, rel_fitness=-1, rel_rmse=-1)
+    ref = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=20, rel_fitness=-1, rel_rmse=-1)
+    assert res["trace"].shape == (21, 18) and ref["trace"].shape == (21, 18)
     assert np.array_equal(res["corr"], ref["corr"])
     assert res["fitness"] == ref["fitness"] and abs(res["inlier_rmse"] - ref["inlier_rmse"]) < 1e-9
-    assert np.abs(res["trace"][:, 2:] - ref["trace"][:, 2:]).max() < 1e-5
+    assert np.array_equal(res["trace"][:, 0], ref["trace"][:, 0])            # same inlier count in every pass
+    assert np.abs(res["trace"][:, 1] - ref["trace"][:, 1]).max() < 1e-9
+    assert np.abs(res["trace"][:, 2:] - ref["trace"][:, 2:]).max() < 1e-5    # the 1e-5 bar of north_star (observed ~1e-12)
+    assert np.abs(res["T"] - ref["T"]).max() < 1e-5
     passes, pairs, fb = _lib.icp_last_stats(ctx)
-    assert passes == 5 and 0 < pairs < 5 * len(scene) * len(f.model_points) * 0.25   # bounding-box culling at work
-    # 20 iterations land on the ground-truth pose (0.5 mm depth noise)
-    full = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=20, relative_fitness=-1, relative_rmse=-1)
-    assert np.abs(np.linalg.inv(full["T"]) - f.T_gt).max() < 0.05
+    assert passes == 21 and 0 < pairs < 21 * len(scene) * len(f.model_points) * 0.01   # culling at work: under 1 % of all pairs
+    # ... and they land on the ground-truth pose (0.5 mm depth noise)
+    assert np.abs(np.linalg.inv(res["T"]) - f.T_gt).max() < 0.05
+    # the correspondence sets of the early passes too (4 iterations: the passes with the large updates)
+    r4 = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=4, relative_fitness=-1, relative_rmse=-1, want_corr=True)
+    o4 = oracle.icp(scene, f.model_points, f.normals, 10.0, f.icp_init(), max_iter=4, rel_fitness=-1, rel_rmse=-1)
+    assert np.array_equal(r4["corr"], o4["corr"]) and r4["fitness"] == o4["fitness"]
     # exact NN over ALL pairs (no radius): indices and float64 distances equal the KD-tree oracle
     idx, d2 = _lib.nn(ctx, src, tgt, f.icp_init())
     ridx, rd2 = oracle.nn(oracle.transform(f.icp_init(), scene), f.model_points, kdtree=True)

@@ -312,3 +312,81 @@ def test_batched_ex_per_pose_radius_and_criteria(ctx, oracle):
     T2, fit2, _, its2 = _lib.icp_batched_ex(ctx, src, tgt, radii2, inits, max_iteration=6)
     one = _lib.icp(ctx, src, tgt, 500.0, inits[3], max_iteration=6)
     assert np.array_equal(T2[3], one["T"]) and fit2[3] == one["fitness"] and its2[3] == one["iters"]
+
+
+def test_batched_graphs_survive_a_change_of_the_iteration_limit(ctx, oracle):
+    """Two batched calls on the same handles and group size whose iteration limits differ (50, then 40): the
+    per-pose workspace layout a cached batch graph bakes in depends on the limit's capacity class only, so
+    the second call must neither replay a graph with stale offsets nor differ from the single calls
+    (the key used to ignore the limit)."""
+    from pedp_hip import _lib, synth
+
+    f, scene = _frame_scene(oracle, "parity")
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(5)])
+    radii = np.full(5, 8.0)
+    for limit in (50, 40, 70, 3):    # 70 + 2 crosses into the next capacity class: captured again
+        T, fit, rmse, its = _lib.icp_batched_ex(ctx, src, tgt, radii, inits, max_iteration=limit)
+        for b in range(5):
+            one = _lib.icp(ctx, src, tgt, radii[b], inits[b], max_iteration=limit)
+            assert np.array_equal(T[b], one["T"]) and fit[b] == one["fitness"] and rmse[b] == one["inlier_rmse"]
+            assert its[b] == one["iters"] <= limit
+
+
+def test_results_do_not_depend_on_a_handles_history(ctx, oracle):
+    """The scene's spatial order -- the order of every float64 sum of a registration -- is built from the cloud
+    alone.  Two fresh handles of the same data, first touched by registrations from very different start
+    poses (and one of them by a batch), then give identical bits for the same registration."""
+    from pedp_hip import _lib, synth
+
+    f, scene = _frame_scene(oracle, "parity")
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    init = f.icp_init()
+    far = init.copy()
+    far[:3, 3] += np.array([400.0, -250.0, 300.0])           # a first registration somewhere else entirely
+    poses = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(4)])
+    a, b, c = (_lib.Cloud(ctx, scene) for _ in range(3))
+    _lib.icp(ctx, a, tgt, 10.0, far, max_iteration=2)
+    _lib.icp_batched(ctx, b, tgt, 6.0, poses, max_iteration=3)
+    res = [_lib.icp(ctx, h, tgt, 10.0, init, max_iteration=12, relative_fitness=-1, relative_rmse=-1, want_corr=True, want_trace=True)
+           for h in (a, b, c)]
+    for r in res[1:]:
+        assert np.array_equal(r["T"], res[0]["T"]) and np.array_equal(r["trace"], res[0]["trace"])
+        assert np.array_equal(r["corr"], res[0]["corr"]) and r["inlier_rmse"] == res[0]["inlier_rmse"]
+
+
+_FINISH_PROBE = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+from pedp_hip import _lib, synth
+ctx = _lib.Context(0)
+f = synth.Frame("parity")
+mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+scene = f.scene(mesh.cast_rays(f.rays6, want_uv=False)["t_hit"])
+src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(9)])
+one = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=15, relative_fitness=-1, relative_rmse=-1, want_corr=True, want_trace=True)
+p2p = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=5, estimator=_lib.POINT_TO_POINT)
+T, fit, rmse, its = _lib.icp_batched_ex(ctx, src, tgt, np.full(9, 7.0), inits, max_iteration=30)
+np.savez(sys.argv[2], T=one["T"], trace=one["trace"], corr=one["corr"], pT=p2p["T"], bT=T, bfit=fit, brmse=rmse, bits=its)
+"""
+
+
+def test_in_launch_finish_equals_the_finish_kernel(tmp_path):
+    """The pass is closed inside the launch by the workgroup that finishes last (partial sums handed over with
+    write-through stores, a ticket and sc1 loads).  PEDP_ICP_UNFUSED_FINISH=1 closes it with a launch of its
+    own behind a kernel boundary instead: every result must agree in every bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"finish{flag}.npz")
+        env = dict(os.environ, PEDP_ICP_UNFUSED_FINISH=flag)
+        p = subprocess.run([sys.executable, "-c", _FINISH_PROBE, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
