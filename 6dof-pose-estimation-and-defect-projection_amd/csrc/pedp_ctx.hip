@@ -4,11 +4,50 @@
 #include <new>
 
 #include <atomic>
+#include <mutex>
+#include <set>
 
 static thread_local char g_err[512] = "";
 static std::atomic<uint64_t> g_generation{0};
 
 uint64_t pedp_next_generation() { return ++g_generation; }
+
+// live contexts: a cloud handle destroyed after its context hands its buffers to hipFree, not to a pool that is gone
+static std::mutex g_ctx_mutex;
+static std::set<pedp_ctx_s *> g_ctx_live;
+bool pedp_ctx_is_live(pedp_ctx_t c) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    return g_ctx_live.count(c) != 0;
+}
+
+void *pedp_pool::take(size_t bytes, size_t *cap) {
+    int best = -1;
+    for (int i = 0; i < (int)free_.size(); ++i)
+        if (free_[i].cap >= bytes && free_[i].cap <= 2 * bytes + 4096 && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
+    if (best >= 0) {
+        void *p = free_[best].p;
+        *cap = free_[best].cap;
+        free_.erase(free_.begin() + best);
+        return p;
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 16 + 256;   // a little headroom: frames of a stream differ by a few points
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *cap = want;
+    return p;
+}
+void pedp_pool::give(void *p, size_t cap) {
+    if (!p) return;
+    if (free_.size() >= 24) {  // keep the pool small: drop the oldest entry
+        (void)hipFree(free_.front().p);
+        free_.erase(free_.begin());
+    }
+    free_.push_back({p, cap});
+}
+void pedp_pool::clear() {
+    for (auto &e : free_) (void)hipFree(e.p);
+    free_.clear();
+}
 
 void pedp_set_error(const char *fmt, ...) {
     va_list ap;
@@ -153,12 +192,14 @@ int pedp_ctx_create(int device, void *stream, pedp_ctx_t *out) {
         pedp_ctx_destroy(c);
         return PEDP_ERR_ALLOC;
     }
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_ctx_live.insert(c); }
     *out = c;
     return PEDP_OK;
 }
 
 void pedp_ctx_destroy(pedp_ctx_t c) {
     if (!c) return;
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_ctx_live.erase(c); }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)pedp_comm_destroy(c);
@@ -176,6 +217,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_order.release();
     c->ray_rast.release();
     c->ops_in.release();
+    c->cloud_pool.clear();
     c->sort_ws.release();
     if (c->rast_status) (void)hipHostFree(c->rast_status);
     c->icp_ws.release();
@@ -204,58 +246,6 @@ int pedp_ctx_synchronize(pedp_ctx_t c) {
 }
 
 // ---------------------------------------------------------------- clouds
-
-int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
-                      pedp_cloud_t *out) {
-    PEDP_REQUIRE(c && out, "pedp_cloud_create: null context/output");
-    *out = nullptr;
-    PEDP_REQUIRE(N >= 0 && N < (int64_t)0x7FFFFFF0, "pedp_cloud_create: N=%lld out of range", (long long)N);
-    PEDP_REQUIRE(pts || N == 0, "pedp_cloud_create: null points");
-    PEDP_HIP_CHECK(hipSetDevice(c->device));
-    pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
-    if (!cl) { pedp_set_error("pedp_cloud_create: out of host memory"); return PEDP_ERR_ALLOC; }
-    cl->ctx = c;
-    cl->device = c->device;
-    cl->gen = pedp_next_generation();
-    cl->N = N;
-    if (N > 0) {
-        double sum[3] = {0, 0, 0};
-        for (int64_t i = 0; i < N; ++i) { sum[0] += pts[3 * i]; sum[1] += pts[3 * i + 1]; sum[2] += pts[3 * i + 2]; }
-        for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
-        for (int k = 0; k < 3; ++k) { cl->lo[k] = pts[k]; cl->hi[k] = pts[k]; }
-        float Tn = 0.f, T2 = 0.f;
-        for (int64_t i = 0; i < N; ++i) {
-            for (int k = 0; k < 3; ++k) {
-                if (pts[3 * i + k] < cl->lo[k]) cl->lo[k] = pts[3 * i + k];
-                if (pts[3 * i + k] > cl->hi[k]) cl->hi[k] = pts[3 * i + k];
-            }
-            float x = (float)(pts[3 * i] - cl->centroid[0]), y = (float)(pts[3 * i + 1] - cl->centroid[1]),
-                  z = (float)(pts[3 * i + 2] - cl->centroid[2]);
-            float n1 = fabsf(x) + fabsf(y) + fabsf(z), n2 = x * x + y * y + z * z;
-            if (n1 > Tn) Tn = n1;
-            if (n2 > T2) T2 = n2;
-        }
-        cl->Tn = Tn * 1.0001f;
-        cl->T2 = T2 * 1.0001f;
-    }
-    size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
-    hipError_t e = hipMalloc((void **)&cl->pts, bytes);
-    if (e == hipSuccess && N > 0 && pedp_upload(c, cl->pts, pts, sizeof(double) * 3 * (size_t)N) != PEDP_OK) e = hipErrorUnknown;
-    if (e == hipSuccess && normals) {
-        cl->has_normals = true;
-        e = hipMalloc((void **)&cl->normals, bytes);
-        if (e == hipSuccess && N > 0 && pedp_upload(c, cl->normals, normals, sizeof(double) * 3 * (size_t)N) != PEDP_OK)
-            e = hipErrorUnknown;
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) {
-        pedp_set_error("pedp_cloud_create: %s", hipGetErrorString(e));
-        pedp_cloud_destroy(cl);
-        return PEDP_ERR_HIP;
-    }
-    *out = cl;
-    return PEDP_OK;
-}
 
 }  // extern "C"
 
@@ -296,6 +286,27 @@ __global__ __launch_bounds__(CS_THREADS) void cloud_sum_kernel(const double *__r
     }
 }
 
+// the box alone, folded on the device into the cloud's own six doubles: nothing comes back to the host
+__global__ __launch_bounds__(64) void cloud_box_fold_kernel(const double *__restrict__ part /* CS_BLOCKS x 9 */, double *__restrict__ box) {
+    const int lane = threadIdx.x;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = part[lane * 9 + 3 + k]; hi[k] = part[lane * 9 + 6 + k]; }
+    for (int b = lane + 64; b < CS_BLOCKS; b += 64)
+        for (int k = 0; k < 3; ++k) {
+            const double l2 = part[b * 9 + 3 + k], h2 = part[b * 9 + 6 + k];
+            lo[k] = l2 < lo[k] ? l2 : lo[k];
+            hi[k] = h2 > hi[k] ? h2 : hi[k];
+        }
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double l2 = __shfl_xor(lo[k], off, 64), h2 = __shfl_xor(hi[k], off, 64);
+            lo[k] = l2 < lo[k] ? l2 : lo[k];
+            hi[k] = h2 > hi[k] ? h2 : hi[k];
+        }
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { box[k] = lo[k]; box[3 + k] = hi[k]; }
+}
+
 // largest |t'|_1 and |t'|_2^2 of the centred float32 coordinates (the NN filter's magnitudes)
 __global__ __launch_bounds__(CS_THREADS) void cloud_norm_kernel(const double *__restrict__ pts, int64_t N, double cx, double cy,
                                                                 double cz, float *__restrict__ part /* CS_BLOCKS x 2 */) {
@@ -319,65 +330,141 @@ __global__ __launch_bounds__(CS_THREADS) void cloud_norm_kernel(const double *__
     }
 }
 
+pedp_cloud_s *new_cloud(pedp_ctx_t c, int64_t N) {
+    pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
+    if (!cl) { pedp_set_error("pedp_cloud_create: out of host memory"); return nullptr; }
+    cl->ctx = c;
+    cl->device = c->device;
+    cl->gen = pedp_next_generation();
+    cl->N = N;
+    return cl;
+}
+
 }  // namespace
+
+// Centroid, bounding box and the filter's magnitudes of a cloud made from device memory, on the host: two
+// reductions and two read-backs, paid when -- and only if -- the cloud is used as a registration target.
+int pedp_cloud_host_stats(pedp_ctx_t c, pedp_cloud_s *cl) {
+    if (cl->host_stats || cl->N == 0) { cl->host_stats = true; return PEDP_OK; }
+    const int64_t N = cl->N;
+    double part[CS_BLOCKS * 9];
+    float fpart[CS_BLOCKS * 2];
+    int st = c->ops.reserve(sizeof(double) * CS_BLOCKS * 9 + sizeof(float) * CS_BLOCKS * 2 + 512);
+    if (st) return st;
+    double *d_part = (double *)c->ops.ptr;
+    float *d_fpart = (float *)(d_part + CS_BLOCKS * 9);
+    hipLaunchKernelGGL(cloud_sum_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N, d_part);
+    PEDP_HIP_CHECK(hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    double sum[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) { cl->lo[k] = part[3 + k]; cl->hi[k] = part[6 + k]; }
+    for (int b = 0; b < CS_BLOCKS; ++b)
+        for (int k = 0; k < 3; ++k) {
+            sum[k] += part[b * 9 + k];
+            if (part[b * 9 + 3 + k] < cl->lo[k]) cl->lo[k] = part[b * 9 + 3 + k];
+            if (part[b * 9 + 6 + k] > cl->hi[k]) cl->hi[k] = part[b * 9 + 6 + k];
+        }
+    for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
+    hipLaunchKernelGGL(cloud_norm_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N,
+                       cl->centroid[0], cl->centroid[1], cl->centroid[2], d_fpart);
+    PEDP_HIP_CHECK(hipMemcpyAsync(fpart, d_fpart, sizeof(fpart), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    float Tn = 0.f, T2 = 0.f;
+    for (int b = 0; b < CS_BLOCKS; ++b) { Tn = fmaxf(Tn, fpart[2 * b]); T2 = fmaxf(T2, fpart[2 * b + 1]); }
+    cl->Tn = Tn * 1.0001f;
+    cl->T2 = T2 * 1.0001f;
+    cl->host_stats = true;
+    return PEDP_OK;
+}
 
 extern "C" {
 
+int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
+                      pedp_cloud_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_cloud_create: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE(N >= 0 && N < (int64_t)0x7FFFFFF0, "pedp_cloud_create: N=%lld out of range", (long long)N);
+    PEDP_REQUIRE(pts || N == 0, "pedp_cloud_create: null points");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    pedp_cloud_s *cl = new_cloud(c, N);
+    if (!cl) return PEDP_ERR_ALLOC;
+    if (N > 0) {
+        double sum[3] = {0, 0, 0};
+        for (int64_t i = 0; i < N; ++i) { sum[0] += pts[3 * i]; sum[1] += pts[3 * i + 1]; sum[2] += pts[3 * i + 2]; }
+        for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
+        for (int k = 0; k < 3; ++k) { cl->lo[k] = pts[k]; cl->hi[k] = pts[k]; }
+        float Tn = 0.f, T2 = 0.f;
+        for (int64_t i = 0; i < N; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                if (pts[3 * i + k] < cl->lo[k]) cl->lo[k] = pts[3 * i + k];
+                if (pts[3 * i + k] > cl->hi[k]) cl->hi[k] = pts[3 * i + k];
+            }
+            float x = (float)(pts[3 * i] - cl->centroid[0]), y = (float)(pts[3 * i + 1] - cl->centroid[1]),
+                  z = (float)(pts[3 * i + 2] - cl->centroid[2]);
+            float n1 = fabsf(x) + fabsf(y) + fabsf(z), n2 = x * x + y * y + z * z;
+            if (n1 > Tn) Tn = n1;
+            if (n2 > T2) T2 = n2;
+        }
+        cl->Tn = Tn * 1.0001f;
+        cl->T2 = T2 * 1.0001f;
+    }
+    cl->host_stats = true;
+    const size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
+    bool ok = (cl->pts = (double *)c->cloud_pool.take(bytes, &cl->pts_cap)) != nullptr;
+    ok = ok && (cl->d_box = (double *)c->cloud_pool.take(64, &cl->box_cap)) != nullptr;
+    if (ok && N > 0 && pedp_upload(c, cl->pts, pts, sizeof(double) * 3 * (size_t)N) != PEDP_OK) ok = false;
+    if (ok && normals) {
+        cl->has_normals = true;
+        ok = (cl->normals = (double *)c->cloud_pool.take(bytes, &cl->normals_cap)) != nullptr;
+        if (ok && N > 0 && pedp_upload(c, cl->normals, normals, sizeof(double) * 3 * (size_t)N) != PEDP_OK) ok = false;
+    }
+    if (ok) {  // the box on the device too (the spatial order reads it there)
+        double *hb = (double *)((char *)c->pinned + 12288);
+        for (int k = 0; k < 3; ++k) { hb[k] = cl->lo[k]; hb[3 + k] = cl->hi[k]; }
+        ok = hipMemcpyAsync(cl->d_box, hb, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    }
+    if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;   // the caller's arrays (and the pinned block) are free again
+    if (!ok) {
+        if (!pedp_last_error()[0]) pedp_set_error("pedp_cloud_create: allocation or copy failed");
+        pedp_cloud_destroy(cl);
+        return PEDP_ERR_HIP;
+    }
+    *out = cl;
+    return PEDP_OK;
+}
+
+// Cloud from device memory (a scene back-projected on the GPU): one device-to-device copy and the bounding box
+// by two small kernels, all on the context's stream -- no read-back, no synchronisation, buffers from the pool.
 int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_normals, int64_t N, pedp_cloud_t *out) {
     PEDP_REQUIRE(c && out, "pedp_cloud_create_device: null context/output");
     *out = nullptr;
     PEDP_REQUIRE(N >= 0 && N < (int64_t)0x7FFFFF00, "pedp_cloud_create_device: N out of range");
     PEDP_REQUIRE(d_pts || N == 0, "pedp_cloud_create_device: null points");
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    pedp_cloud_s *cl = new (std::nothrow) pedp_cloud_s();
-    if (!cl) { pedp_set_error("pedp_cloud_create_device: out of host memory"); return PEDP_ERR_ALLOC; }
-    cl->ctx = c;
-    cl->device = c->device;
-    cl->gen = pedp_next_generation();
-    cl->N = N;
+    pedp_cloud_s *cl = new_cloud(c, N);
+    if (!cl) return PEDP_ERR_ALLOC;
     const size_t bytes = sizeof(double) * 3 * (size_t)(N > 0 ? N : 1);
-    hipError_t e = hipMalloc((void **)&cl->pts, bytes);
-    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->pts, d_pts, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess && d_normals) {
+    hipError_t e = hipSuccess;
+    bool ok = (cl->pts = (double *)c->cloud_pool.take(bytes, &cl->pts_cap)) != nullptr;
+    ok = ok && (cl->d_box = (double *)c->cloud_pool.take(64, &cl->box_cap)) != nullptr;
+    if (ok && N > 0) e = hipMemcpyAsync(cl->pts, d_pts, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
+    if (ok && e == hipSuccess && d_normals) {
         cl->has_normals = true;
-        e = hipMalloc((void **)&cl->normals, bytes);
-        if (e == hipSuccess && N > 0) e = hipMemcpyAsync(cl->normals, d_normals, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
+        ok = (cl->normals = (double *)c->cloud_pool.take(bytes, &cl->normals_cap)) != nullptr;
+        if (ok && N > 0) e = hipMemcpyAsync(cl->normals, d_normals, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
     }
-    double part[CS_BLOCKS * 9];
-    float fpart[CS_BLOCKS * 2];
-    if (e == hipSuccess && N > 0) {
-        int st = c->ops.reserve(sizeof(double) * CS_BLOCKS * 9 + sizeof(float) * CS_BLOCKS * 2 + 512);
+    if (ok && e == hipSuccess && N > 0) {
+        const int st = c->sort_ws.reserve(sizeof(double) * CS_BLOCKS * 9 + 512);   // (the order's scratch: next in line on this stream)
         if (st) { pedp_cloud_destroy(cl); return st; }
-        double *d_part = (double *)c->ops.ptr;
-        float *d_fpart = (float *)(d_part + CS_BLOCKS * 9);
+        double *d_part = (double *)c->sort_ws.ptr;
         hipLaunchKernelGGL(cloud_sum_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N, d_part);
-        e = hipMemcpyAsync(part, d_part, sizeof(part), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) {
-            double sum[3] = {0, 0, 0};
-            for (int k = 0; k < 3; ++k) { cl->lo[k] = part[3 + k]; cl->hi[k] = part[6 + k]; }
-            for (int b = 0; b < CS_BLOCKS; ++b)
-                for (int k = 0; k < 3; ++k) {
-                    sum[k] += part[b * 9 + k];
-                    if (part[b * 9 + 3 + k] < cl->lo[k]) cl->lo[k] = part[b * 9 + 3 + k];
-                    if (part[b * 9 + 6 + k] > cl->hi[k]) cl->hi[k] = part[b * 9 + 6 + k];
-                }
-            for (int k = 0; k < 3; ++k) cl->centroid[k] = sum[k] / (double)N;
-            hipLaunchKernelGGL(cloud_norm_kernel, dim3(CS_BLOCKS), dim3(CS_THREADS), 0, c->stream, (const double *)cl->pts, N,
-                               cl->centroid[0], cl->centroid[1], cl->centroid[2], d_fpart);
-            e = hipMemcpyAsync(fpart, d_fpart, sizeof(fpart), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e == hipSuccess) {
-                float Tn = 0.f, T2 = 0.f;
-                for (int b = 0; b < CS_BLOCKS; ++b) { Tn = fmaxf(Tn, fpart[2 * b]); T2 = fmaxf(T2, fpart[2 * b + 1]); }
-                cl->Tn = Tn * 1.0001f;
-                cl->T2 = T2 * 1.0001f;
-            }
-        }
+        hipLaunchKernelGGL(cloud_box_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const double *)d_part, cl->d_box);
+        e = hipGetLastError();
+    } else if (N == 0) {
+        cl->host_stats = true;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) {
-        pedp_set_error("pedp_cloud_create_device: %s", hipGetErrorString(e));
+    if (!ok || e != hipSuccess) {
+        pedp_set_error("pedp_cloud_create_device: %s", ok ? hipGetErrorString(e) : "allocation failed");
         pedp_cloud_destroy(cl);
         return PEDP_ERR_HIP;
     }
@@ -388,11 +475,20 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
 void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (!cl) return;
     (void)hipSetDevice(cl->device);
-    if (cl->pts) (void)hipFree(cl->pts);
-    if (cl->normals) (void)hipFree(cl->normals);
+    // points, normals, order, chunk spheres and box go back to the context's pool (the next frame's cloud takes
+    // them: reuse is ordered by the stream); everything else, and all of it if the context is gone, is freed
+    pedp_pool *pool = pedp_ctx_is_live(cl->ctx) ? &cl->ctx->cloud_pool : nullptr;
+    auto drop = [&](void *p, size_t cap) {
+        if (!p) return;
+        if (pool && cap) pool->give(p, cap);
+        else (void)hipFree(p);
+    };
+    drop(cl->pts, cl->pts_cap);
+    drop(cl->normals, cl->normals_cap);
+    drop(cl->perm, cl->perm_cap);
+    drop(cl->chunk_sph, cl->sph_cap);
+    drop(cl->d_box, cl->box_cap);
     if (cl->tgt4) (void)hipFree(cl->tgt4);
-    if (cl->perm) (void)hipFree(cl->perm);
-    if (cl->chunk_sph) (void)hipFree(cl->chunk_sph);
     if (cl->tile_sph) (void)hipFree(cl->tile_sph);
     if (cl->tile_sph4) (void)hipFree(cl->tile_sph4);
     if (cl->tile_sphw) (void)hipFree(cl->tile_sphw);

@@ -197,10 +197,18 @@ __device__ __forceinline__ unsigned long long point_cell(const double *__restric
     if (!(fx >= 0.0 && fx < top && fy >= 0.0 && fy < top && fz >= 0.0 && fz < top)) return 1ull << (3 * SORT_BITS);
     return hilbert3((unsigned)(int)fx, (unsigned)(int)fy, (unsigned)(int)fz);
 }
-__global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz,
-                                double sx, double sy, double sz, unsigned long long *__restrict__ key) {
+// the box is read where it was made: on the device (lo xyz, hi xyz)
+__global__ void cell_key_kernel(const double *__restrict__ pts, int64_t N, const double *__restrict__ box,
+                                unsigned long long *__restrict__ key) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) key[i] = point_cell(pts, i, lox, loy, loz, sx, sy, sz);
+    if (i >= N) return;
+    double sc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double ext = box[3 + k] - box[k];
+        sc[k] = ext > 0.0 && isfinite(ext) ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
+    }
+    key[i] = point_cell(pts, i, box[0], box[1], box[2], sc[0], sc[1], sc[2]);
 }
 // Bounding spheres (centre xyz, radius; float64, the cloud's own frame) of the eight runs of 16 consecutive
 // points of every 128-point chunk of the spatial order: a rebuild pass of a registration asks the spheres,
@@ -2686,44 +2694,37 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
 // itself, no synchronisation).
 int ensure_spatial_perm(pedp_ctx_t c, pedp_cloud_t cl) {
     if (cl->N == 0 || cl->perm) return PEDP_OK;
-    void *perm = nullptr;
-    PEDP_HIP_CHECK(hipMalloc(&perm, sizeof(int32_t) * (size_t)cl->N));
+    const int64_t n_chunks = (cl->N + 127) / 128;
+    size_t perm_cap = 0, sph_cap = 0;
+    void *perm = c->cloud_pool.take(sizeof(int32_t) * (size_t)cl->N, &perm_cap);
+    void *sph = c->cloud_pool.take(sizeof(double) * 32 * (size_t)n_chunks, &sph_cap);
+    auto fail = [&](int rc, const char *what) {
+        (void)hipStreamSynchronize(c->stream);
+        c->cloud_pool.give(perm, perm_cap);
+        c->cloud_pool.give(sph, sph_cap);
+        if (what) pedp_set_error("pedp_icp: spatial order: %s", what);
+        return rc;
+    };
+    if (!perm || !sph) return fail(PEDP_ERR_ALLOC, "allocation failed");
     unsigned long long *keys = nullptr;
     int rcs = pedp_sort_keys64_begin(c, cl->N, SORT_KEY_BITS, &keys);
-    if (rcs) { (void)hipFree(perm); return rcs; }
-    double sc[3];
-    for (int k = 0; k < 3; ++k) {
-        const double ext = cl->hi[k] - cl->lo[k];
-        sc[k] = ext > 0.0 && std::isfinite(ext) ? (double)(1 << SORT_BITS) / ext * (1.0 - 1e-9) : 0.0;
-    }
+    if (rcs) return fail(rcs, nullptr);
     const unsigned grid = (unsigned)((cl->N + 255) / 256);
-    hipLaunchKernelGGL(cell_key_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, cl->lo[0], cl->lo[1], cl->lo[2],
-                       sc[0], sc[1], sc[2], keys);
+    hipLaunchKernelGGL(cell_key_kernel, dim3(grid), dim3(256), 0, c->stream, cl->pts, cl->N, (const double *)cl->d_box, keys);
     rcs = pedp_sort_keys64_run(c, cl->N, SORT_KEY_BITS, (int32_t *)perm);
-    if (rcs || hipGetLastError() != hipSuccess) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(perm);
-        if (!rcs) { pedp_set_error("pedp_icp: spatial order: launch failed"); rcs = PEDP_ERR_HIP; }
-        return rcs;
-    }
-    const int64_t n_chunks = (cl->N + 127) / 128;
-    void *sph = nullptr;
-    if (hipMalloc(&sph, sizeof(double) * 32 * (size_t)n_chunks) != hipSuccess) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(perm);
-        pedp_set_error("pedp_icp: chunk spheres: allocation failed");
-        return PEDP_ERR_ALLOC;
-    }
+    if (rcs) return fail(rcs, nullptr);
     hipLaunchKernelGGL(chunk_sphere_kernel, dim3((unsigned)n_chunks), dim3(64), 0, c->stream, cl->pts, (const int32_t *)perm, cl->N,
                        (double *)sph);
-    cl->perm = perm;
-    cl->chunk_sph = sph;
+    if (hipGetLastError() != hipSuccess) return fail(PEDP_ERR_HIP, "launch failed");
+    cl->perm = perm; cl->perm_cap = perm_cap;
+    cl->chunk_sph = sph; cl->sph_cap = sph_cap;
     return PEDP_OK;
 }
 
 // Target-side operand of the sweep, built once per cloud and kept in the handle (the
 // reference re-runs ICP ~50x per frame against the same model, pose_estimation.py:577-613).
 int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
+    { const int rs = pedp_cloud_host_stats(c, tgt); if (rs) return rs; }
     for (int k = 0; k < 3; ++k) tp.c[k] = tgt->centroid[k];
     tp.Tn = tgt->Tn;
     tp.T2 = tgt->T2;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include "../../include/pedp.h"
 
 void pedp_set_error(const char *fmt, ...);
@@ -48,6 +49,17 @@ struct pedp_scratch {
     void release();
 };
 
+// Device buffers of cloud handles that have been destroyed, kept for the next cloud of about that size: a scene
+// cloud per camera frame would otherwise pay hipMalloc and a device-synchronising hipFree for each of its
+// buffers.  Reuse is ordered by the context's stream (every use of a cloud's buffers is enqueued there).
+struct pedp_pool {
+    struct entry { void *p; size_t cap; };
+    std::vector<entry> free_;
+    void *take(size_t bytes, size_t *cap);   // a pooled buffer of cap >= bytes (not wastefully larger), or a new one
+    void give(void *p, size_t cap);
+    void clear();
+};
+
 #define PEDP_MAX_SUB 8
 
 // What a captured registration graph depends on besides device-memory contents: if any of it
@@ -65,6 +77,9 @@ struct pedp_icp_graph_key {
 
 struct pedp_comm_s;  // pedp_comm.hip: RCCL communicator of this rank
 int pedp_comm_allreduce_sum_f64(pedp_ctx_t c, double *buf, int64_t n);
+struct pedp_cloud_s;
+int pedp_cloud_host_stats(pedp_ctx_t c, pedp_cloud_s *cl);  // makes centroid / lo / hi / Tn / T2 valid on the host
+bool pedp_ctx_is_live(pedp_ctx_t c);
 
 struct pedp_ctx_s {
     int device = 0;
@@ -99,6 +114,7 @@ struct pedp_ctx_s {
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
     pedp_scratch sort_ws;    // spatial order of a cloud: keys + radix-sort buffers (pooled, stream-ordered)
+    pedp_pool cloud_pool;    // buffers of destroyed cloud handles
     pedp_scratch ops_in;     // a large cloud's points, uploaded ahead of the workspace sizing (its box comes from the device copy)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
@@ -148,6 +164,12 @@ struct pedp_cloud_s {
     bool has_normals = false;
     double *pts = nullptr;      // N x 3 f64 (device)
     double *normals = nullptr;  // N x 3 f64 (device) or null
+    size_t pts_cap = 0, normals_cap = 0, perm_cap = 0, sph_cap = 0, box_cap = 0;  // capacities (the buffers may come from the pool)
+    double *d_box = nullptr;    // device: lo xyz, hi xyz of the points (what the spatial order is laid over)
+    // centroid, box and the filter's magnitudes ON THE HOST: at creation for clouds made from host arrays, on first
+    // use as a registration TARGET for clouds made from device memory (a scene cloud never needs them: no read-back
+    // and no synchronisation between the camera frame and its registration)
+    bool host_stats = false;
     // Set at creation (host pass over the points): centroid and the two magnitudes of the
     // centred cloud that the NN filter's error bound needs when this cloud is the target.
     double centroid[3] = {0, 0, 0};
