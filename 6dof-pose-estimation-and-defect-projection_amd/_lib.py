@@ -16,6 +16,14 @@ LIB_PATH = os.environ.get("PEDP_LIB", os.path.join(_HERE, "libpedp_hip.so"))
 HOST, DEVICE = 0, 1
 POINT_TO_PLANE, POINT_TO_POINT = 0, 1
 
+
+class PreprocessParams(C.Structure):
+    """pedp_preprocess_params (include/pedp.h)."""
+    _fields_ = [("voxel_size", C.c_double), ("plane_distance", C.c_double), ("plane_iterations", C.c_int32),
+                ("first_frame", C.c_int32), ("seed", C.c_uint64), ("normal_radius", C.c_double), ("normal_max_nn", C.c_int32),
+                ("cluster_min_points", C.c_int32), ("cluster_eps", C.c_double), ("outlier_neighbors", C.c_int32),
+                ("reserved", C.c_int32), ("outlier_std_ratio", C.c_double)]
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
 
@@ -62,6 +70,8 @@ PROTOTYPES = {
                                          C.c_int64, _P(C.c_int64)]),
     "pedp_voxel_down_sample_device_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
                                                    _P(C.c_int64)]),
+    "pedp_preprocess_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         _P(C.c_int64), _P(C.c_int64), _P(C.c_int)]),
     "pedp_cluster_dbscan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
     "pedp_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pedp_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),

@@ -37,22 +37,66 @@ def voxel_down_sample(points, voxel_size, normals=None, ctx=None):
         if normals is not None and len(normals):
             raise NotImplementedError("voxel_down_sample: device points with normals")
         t = points.reshape(-1, 3)
+        if t.device.index != ctx.device:   # a pointer of another GPU would be a fault inside the kernels, not an error
+            raise _lib.PedpError(f"voxel_down_sample: the points are on cuda:{t.device.index}, the context on cuda:{ctx.device}")
         if t.dtype != torch.float64 or not t.is_contiguous():
-            t = t.to(torch.float64).contiguous()
+            t = t.to(torch.float64).contiguous()              # (a float32 or strided tensor is copied on the device)
         torch.cuda.current_stream(t.device).synchronize()     # the library reads the array on its own stream
         out = np.empty((len(t), 3), np.float64)
         m = C.c_int64()
         _lib.check(_lib.load().pedp_voxel_down_sample_device_in(ctx._h, C.c_void_p(t.data_ptr()), len(t), float(voxel_size),
                                                                 _lib._ptr(out), len(t), C.byref(m)),
                    "pedp_voxel_down_sample_device_in")
-        return out[:m.value], None
+        return out[:m.value].copy(), None          # (a copy: the N x 3 output buffer is not kept alive by a small result)
     p = _pts(points)
     n = None if normals is None or len(normals) == 0 else _pts(normals)
     out, outn = np.empty_like(p), (np.empty_like(p) if n is not None else None)
     m = C.c_int64()
     _lib.check(_lib.load().pedp_voxel_down_sample(ctx._h, _lib._ptr(p), _lib._ptr(n), len(p), float(voxel_size), _lib._ptr(out),
                                                   _lib._ptr(outn), len(p), C.byref(m)), "pedp_voxel_down_sample")
-    return out[:m.value], (None if outn is None else outn[:m.value])     # (views of the call's output buffers)
+    # copies: a down-sampled cloud must not keep the full-resolution output buffers alive
+    return out[:m.value].copy(), (None if outn is None else outn[:m.value].copy())
+
+
+def preprocess_source_fused(points, voxel_size, plane_distance, plane_iterations, first_frame, seed=None, normal_radius=2.0,
+                            normal_max_nn=5, cluster_eps=10.0, cluster_min_points=10, outlier_neighbors=75, outlier_std_ratio=0.01,
+                            ctx=None):
+    """pedp_preprocess_source: the reference's preprocess_source chain (pose_estimation.py:186-268, no box / mesh / background)
+    with the scene staying on the device between the stages.  `points`: N x 3 float64 numpy array, or a float64 torch
+    tensor on the GPU.  Returns (points, normals or None, stage_counts, status); status != 0: nothing was produced (no
+    cluster / fewer than three points) and the caller takes the step-by-step path to reproduce the reference's behaviour."""
+    ctx = ctx or _lib.default_context()
+    prm = _lib.PreprocessParams(float(voxel_size), float(plane_distance), int(plane_iterations), 1 if first_frame else 0,
+                                int(_SEED if seed is None else seed), float(normal_radius), int(normal_max_nn), int(cluster_min_points),
+                                float(cluster_eps), int(outlier_neighbors), 0, float(outlier_std_ratio))
+    if _is_device_tensor(points):
+        import torch
+
+        t = points.reshape(-1, 3)
+        if t.device.index != ctx.device:
+            raise _lib.PedpError(f"preprocess_source: the points are on cuda:{t.device.index}, the context on cuda:{ctx.device}")
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            t = t.to(torch.float64).contiguous()
+        torch.cuda.current_stream(t.device).synchronize()     # the library reads the array on its own stream
+        n, ptr, on_dev, keep = len(t), C.c_void_p(t.data_ptr()), 1, t
+    else:
+        p = _pts(points)
+        n, ptr, on_dev, keep = len(p), _lib._ptr(p), 0, p
+    # the result is a small fraction of the frame: room for a tenth (at least 64 k points), the whole cloud if that is short
+    for cap in (max(n // 10, 65536), n):
+        cap = min(cap, max(n, 1))
+        out = np.empty((cap, 3), np.float64)
+        outn = np.empty((cap, 3), np.float64) if first_frame else None
+        m, status = C.c_int64(), C.c_int()
+        counts = (C.c_int64 * 4)()
+        rc = _lib.load().pedp_preprocess_source(ctx._h, ptr, n, on_dev, C.byref(prm), _lib._ptr(out), _lib._ptr(outn), cap,
+                                                C.byref(m), counts, C.byref(status))
+        if rc != 0 and m.value > cap and cap < n:
+            continue                                           # (more points survived than a tenth: once more with full room)
+        _lib.check(rc, "pedp_preprocess_source")
+        break
+    del keep
+    return out[:m.value].copy(), (None if outn is None else outn[:m.value].copy()), list(counts), status.value
 
 
 def cluster_dbscan(points, eps, min_points, ctx=None):

@@ -1046,10 +1046,348 @@ int make_grid(const double lo[3], const double hi[3], double cell, Grid &g, int6
 
 }  // namespace
 
+// ------------------------------------------------------------------ device-to-device cores
+// Every operation below takes its points where they already are -- in device memory -- and leaves its result
+// there (inside the context's `ops` scratch, valid until the next operation).  The C entry points with host
+// arrays are thin wrappers (upload, core, download); pedp_preprocess_source chains the cores without the
+// points ever visiting the host.
+namespace {
+
+// a small device block of the context for partial bounds and counters (never inside `ops`, which the cores re-carve)
+int small_block(pedp_ctx_t c, double **d_part) {
+    int st = c->ops_small.reserve(a256(sizeof(double) * 6 * BND_BLOCKS) + 4096);
+    if (st) return st;
+    *d_part = (double *)c->ops_small.ptr;
+    return PEDP_OK;
+}
+
+int voxel_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N, double voxel_size, double **out_pts,
+               double **out_nrm, int64_t *n_out) {
+    double lo[3], hi[3], *d_part = nullptr;
+    int rc = small_block(c, &d_part);
+    if (rc) return rc;
+    rc = bounds_device(c, d_pts, N, d_part, lo, hi);
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k) {
+        PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
+        lo[k] = lo[k] - voxel_size * 0.5;
+        PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
+    }
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                           (int *)nullptr, (int *)nullptr, n, 0, 63, c->stream));
+    PEDP_ROCPRIM(rocprim::run_length_encode(nullptr, tmp_rle, (unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
+                                            (unsigned *)nullptr, (unsigned *)nullptr, c->stream));
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
+                                         rocprim::plus<unsigned>(), c->stream));
+    size_t tmp = tmp_sort > tmp_rle ? tmp_sort : tmp_rle;
+    if (tmp_scan > tmp) tmp = tmp_scan;
+    const size_t need = a256(sizeof(double) * 3 * N) * 2 + a256(sizeof(unsigned long long) * N) * 3 + a256(sizeof(int) * N) * 2 +
+                        a256(sizeof(unsigned) * N) * 2 + 256 + a256(tmp) + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    double *d_out = cv.take<double>(3 * (size_t)N), *d_outn = cv.take<double>(3 * (size_t)N);
+    unsigned long long *key = cv.take<unsigned long long>(N), *key_s = cv.take<unsigned long long>(N),
+                       *uniq = cv.take<unsigned long long>(N);
+    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
+    unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
+    void *d_tmp = cv.take<char>(tmp);
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
+    PEDP_ROCPRIM(rocprim::run_length_encode(d_tmp, tmp_rle, key_s, n, uniq, counts, n_runs, c->stream));
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, counts, offsets, 0u, n, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(voxel_average_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, d_nrm, val_s, counts, offsets, n_runs,
+                       d_out, d_outn);
+    PEDP_HIP_CHECK(hipGetLastError());
+    unsigned *h_runs = (unsigned *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_runs, n_runs, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *n_out = *h_runs;
+    *out_pts = d_out;
+    *out_nrm = d_nrm ? d_outn : nullptr;
+    return PEDP_OK;
+}
+
+// the uniform grid of a cloud on the device: cells, sorted order, ranges, points gathered in that order
+struct GridIndex {
+    Grid g;
+    double *sp;
+    int *val_s, *cell_start, *cell_end;
+    void *tmp;  // the sort's scratch, free once the index stands
+    size_t tmp_bytes;
+};
+// carves the index out of cv (the caller has reserved room: grid_index_bytes) and builds it
+size_t grid_index_bytes(pedp_ctx_t c, int64_t N, int64_t n_cells, size_t *tmp_sort) {
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, *tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr, (int *)nullptr,
+                                           (unsigned)N, 0, 32, c->stream));
+    return a256(sizeof(double) * 3 * N) + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 2 + a256(sizeof(int) * n_cells) * 2 +
+           a256(*tmp_sort < 256 ? 256 : *tmp_sort);
+}
+int grid_index_build(pedp_ctx_t c, Carver &cv, const double *d_pts, int64_t N, const Grid &g, int64_t n_cells, size_t tmp_sort,
+                     GridIndex &ix) {
+    ix.g = g;
+    ix.sp = cv.take<double>(3 * (size_t)N);
+    unsigned *cell = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
+    int *val = cv.take<int>(N);
+    ix.val_s = cv.take<int>(N);
+    ix.cell_start = cv.take<int>(n_cells);
+    ix.cell_end = cv.take<int>(n_cells);
+    ix.tmp = cv.take<char>(tmp_sort < 256 ? 256 : tmp_sort);
+    ix.tmp_bytes = tmp_sort;
+    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
+    PEDP_ROCPRIM(rocprim::radix_sort_pairs(ix.tmp, tmp_sort, cell, cell_s, val, ix.val_s, (unsigned)N, 0, 32, c->stream));
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, ix.val_s, d_pts, N, ix.cell_start, ix.cell_end,
+                       ix.sp);
+    PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
+int dbscan_core(pedp_ctx_t c, const double *d_pts, int64_t N, double eps, int min_points, const double lo[3], const double hi[3],
+                int32_t **out_labels) {
+    Grid g;
+    int64_t n_cells = 0;
+    // cell >= eps with margin: neighbours within eps are never two cells apart
+    int rc = make_grid(lo, hi, eps * (1.0 + 1e-9), g, n_cells, "pedp_cluster_dbscan");
+    if (rc) return rc;
+    const unsigned n = (unsigned)N;
+    size_t tmp_sort = 0, tmp_scan = 0;
+    const size_t ix_bytes = grid_index_bytes(c, N, n_cells, &tmp_sort);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
+                                         rocprim::plus<unsigned>(), c->stream));
+    const size_t need = ix_bytes + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 4 + a256(tmp_scan) + 4096;
+    int st = c->ops.reserve(need);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    GridIndex ix;
+    rc = grid_index_build(c, cv, d_pts, N, g, n_cells, tmp_sort, ix);
+    if (rc) return rc;
+    unsigned *is_rep = cv.take<unsigned>(N), *rank = cv.take<unsigned>(N);
+    int *core = cv.take<int>(N), *parent = cv.take<int>(N), *root = cv.take<int>(N);
+    int32_t *d_labels = cv.take<int32_t>(N);
+    void *d_tmp = cv.take<char>(tmp_scan);
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    const double e2 = eps * eps;
+    const unsigned grid_w = (unsigned)((N + DB_WPB - 1) / DB_WPB);
+    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
+                       min_points, ix.val_s, core, parent);
+    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
+                       ix.val_s, core, parent);
+    hipLaunchKernelGGL(dbscan_root_kernel, dim3(grid), dim3(256), 0, c->stream, N, core, parent, root, is_rep);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, is_rep, rank, 0u, n, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2, ix.val_s,
+                       root, rank, d_labels);
+    PEDP_HIP_CHECK(hipGetLastError());
+    *out_labels = d_labels;
+    return PEDP_OK;
+}
+
+int knn_core(pedp_ctx_t c, const double *d_pts, int64_t N, int k, const double lo[3], const double hi[3], double **out_avg) {
+    if (N <= KNN_SMALL_MAX) {  // a wave per query, all distances in LDS
+        int st0 = c->ops.reserve(a256(sizeof(double) * N) + 512);
+        if (st0) return st0;
+        double *d_avg0 = (double *)c->ops.ptr;
+        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(double) * KNN_SMALL_MAX)));
+        hipLaunchKernelGGL(knn_mean_small_kernel, dim3((unsigned)N), dim3(64), sizeof(double) * (size_t)N, c->stream, d_pts, (int)N, k,
+                           d_avg0);
+        PEDP_HIP_CHECK(hipGetLastError());
+        *out_avg = d_avg0;
+        return PEDP_OK;
+    }
+    // cell ~ the radius that holds k points if the cloud were spread over a sheet of the box's
+    // largest extent (scanned surfaces are sheets); any cell size gives the same result
+    double ext = 0.0;
+    for (int d = 0; d < 3; ++d) ext = std::fmax(ext, hi[d] - lo[d]);
+    double cell = ext * std::sqrt((double)k / (3.14159265358979 * (double)N));
+    if (!(cell > 0.0) || !std::isfinite(cell)) cell = 1.0;
+    Grid g;
+    int64_t n_cells = 0;
+    int rc = make_grid(lo, hi, cell, g, n_cells, "pedp_knn_mean_distance");
+    if (rc) return rc;
+    size_t tmp_sort = 0;
+    const size_t ix_bytes = grid_index_bytes(c, N, n_cells, &tmp_sort);
+    int st = c->ops.reserve(ix_bytes + a256(sizeof(double) * N) + 4096);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    GridIndex ix;
+    rc = grid_index_build(c, cv, d_pts, N, g, n_cells, tmp_sort, ix);
+    if (rc) return rc;
+    double *d_avg = cv.take<double>(N);
+    // a wave per query; a cloud too dense for the LDS share of some query falls back to a thread per query
+    int *d_over = (int *)ix.tmp;  // the sort is done: its scratch is free
+    int *h_over = (int *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(knn_mean_wave_kernel, dim3((unsigned)((N + KNN_WPB - 1) / KNN_WPB)), dim3(KNN_WPB * 64), 0, c->stream, g, ix.sp, N,
+                       ix.cell_start, ix.cell_end, ix.val_s, k, d_avg, d_over);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*h_over) {
+        const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
+        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream, g,
+                           ix.sp, N, ix.cell_start, ix.cell_end, ix.val_s, k, d_avg);
+        PEDP_HIP_CHECK(hipGetLastError());
+    }
+    *out_avg = d_avg;
+    return PEDP_OK;
+}
+
+int normals_core(pedp_ctx_t c, const double *d_pts, int64_t N, double radius, int max_nn, const double *d_prior, const double lo[3],
+                 const double hi[3], double **out_normals) {
+    Grid g;
+    int64_t n_cells = 0;
+    int rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_estimate_normals");
+    if (rc) return rc;
+    size_t tmp_sort = 0;
+    const size_t ix_bytes = grid_index_bytes(c, N, n_cells, &tmp_sort);
+    int st = c->ops.reserve(ix_bytes + a256(sizeof(double) * 3 * N) + 4096);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    GridIndex ix;
+    rc = grid_index_build(c, cv, d_pts, N, g, n_cells, tmp_sort, ix);
+    if (rc) return rc;
+    double *d_out = cv.take<double>(3 * (size_t)N);
+    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
+    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((N + NRM_THREADS - 1) / NRM_THREADS)), dim3(NRM_THREADS), lds, c->stream, g,
+                       ix.sp, N, ix.cell_start, ix.cell_end, ix.val_s, radius * radius, max_nn, d_pts, d_prior, d_out);
+    PEDP_HIP_CHECK(hipGetLastError());
+    *out_normals = d_out;
+    return PEDP_OK;
+}
+
+// plane RANSAC: inlier counts of every iteration -> the best iteration (most inliers, earliest on ties) and its plane
+int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distance_threshold, int num_iterations, uint64_t seed,
+                    int *best_t, double best[4]) {
+    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + 512);
+    if (st) return st;
+    int *d_cnt = (int *)c->ops.ptr;
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)num_iterations), dim3(256), 0, c->stream, d_pts, (long long)N,
+                       distance_threshold, (unsigned long long)seed, d_cnt);
+    PEDP_HIP_CHECK(hipGetLastError());
+    std::vector<int> counts((size_t)num_iterations);
+    PEDP_HIP_CHECK(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int) * (size_t)num_iterations, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int bt = -1, best_cnt = -1;
+    for (int t = 0; t < num_iterations; ++t)
+        if (counts[t] > best_cnt) { best_cnt = counts[t]; bt = t; }  // most inliers, earliest iteration on ties
+    *best_t = bt;
+    if (bt < 0) return PEDP_OK;
+    long long s[3];
+    sample3(seed, bt, N, s);
+    double p3[9];  // the three sampled points (72 bytes back)
+    for (int q = 0; q < 3; ++q)
+        PEDP_HIP_CHECK(hipMemcpyAsync(p3 + 3 * q, d_pts + 3 * s[q], sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    triangle_plane(p3, p3 + 3, p3 + 6, best);
+    return PEDP_OK;
+}
+
+// ---- selection in index order: flags -> exclusive scan -> scatter
+__global__ void plane_keep_kernel(const double *__restrict__ pts, int64_t N, double a, double b, double cc, double d, double thr,
+                                  int inliers, unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double pl[4] = {a, b, cc, d};
+    const bool in = plane_dist(pl, pts + 3 * i) < thr;
+    flag[i] = (in == (inliers != 0)) ? 1u : 0u;
+}
+__global__ void label_keep_kernel(const int32_t *__restrict__ labels, int64_t N, int32_t label, unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = labels[i] == label ? 1u : 0u;
+}
+__global__ void range_keep_kernel(const double *__restrict__ avg, int64_t N, double limit, unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = (avg[i] > 0.0 && avg[i] < limit) ? 1u : 0u;   // Open3D: 0 < mean distance < mean + ratio * std
+}
+__global__ void scatter_kept_kernel(const double *__restrict__ pts, const double *__restrict__ nrm, int64_t N,
+                                    const unsigned *__restrict__ flag, const unsigned *__restrict__ pos, double *__restrict__ out_pts,
+                                    double *__restrict__ out_nrm, unsigned *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (flag[i]) {
+        const size_t o = pos[i];
+        out_pts[3 * o] = pts[3 * i]; out_pts[3 * o + 1] = pts[3 * i + 1]; out_pts[3 * o + 2] = pts[3 * i + 2];
+        if (nrm) { out_nrm[3 * o] = nrm[3 * i]; out_nrm[3 * o + 1] = nrm[3 * i + 1]; out_nrm[3 * o + 2] = nrm[3 * i + 2]; }
+    }
+    if (i == N - 1) *count = pos[i] + flag[i];
+}
+// d_flag (N unsigned, in the chain's own buffers) -> kept points (and normals) in index order at out_*; one 4-byte read-back
+int select_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N, const unsigned *d_flag, double *out_pts,
+                double *out_nrm, int64_t *n_out) {
+    *n_out = 0;
+    if (N == 0) return PEDP_OK;
+    size_t tmp_scan = 0;
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, (unsigned)N,
+                                         rocprim::plus<unsigned>(), c->stream));
+    int st = c->ops.reserve(a256(sizeof(unsigned) * N) + a256(tmp_scan) + 512);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    unsigned *pos = cv.take<unsigned>(N), *count = cv.take<unsigned>(1);
+    void *d_tmp = cv.take<char>(tmp_scan);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, d_flag, pos, 0u, (unsigned)N, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(scatter_kept_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_pts, d_nrm, N, d_flag, pos,
+                       out_pts, out_nrm, count);
+    PEDP_HIP_CHECK(hipGetLastError());
+    unsigned *h = (unsigned *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemcpyAsync(h, count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *n_out = *h;
+    return PEDP_OK;
+}
+
+// upload of a wrapper's host array into the context's input scratch (its own allocation: the cores re-carve `ops`)
+int upload_in(pedp_ctx_t c, const double *pts, const double *second, int64_t N, double **d_a, double **d_b) {
+    const size_t bytes = a256(sizeof(double) * 3 * (size_t)N);
+    int st = c->ops_in.reserve(bytes * (second ? 2 : 1) + 256);
+    if (st) return st;
+    *d_a = (double *)c->ops_in.ptr;
+    { int up_ = pedp_upload(c, *d_a, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
+    if (second) {
+        *d_b = (double *)((char *)c->ops_in.ptr + bytes);
+        int up_ = pedp_upload(c, *d_b, second, sizeof(double) * 3 * (size_t)N);
+        if (up_) return up_;
+    } else if (d_b) {
+        *d_b = nullptr;
+    }
+    return PEDP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 static int voxel_down_sample_impl(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
-                                  double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, bool pts_on_device);
+                                  double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, bool pts_on_device) {
+    int rc = check_cloud(c, pts, N, "pedp_voxel_down_sample");
+    if (rc) return rc;
+    PEDP_REQUIRE(n_out, "pedp_voxel_down_sample: null count");
+    *n_out = 0;
+    PEDP_REQUIRE(voxel_size > 0.0, "pedp_voxel_down_sample: voxel_size <= 0");  // Open3D raises too
+    if (N == 0) return PEDP_OK;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    double *d_pts = const_cast<double *>(pts), *d_nrm = nullptr;
+    if (!pts_on_device) { rc = upload_in(c, pts, normals, N, &d_pts, &d_nrm); if (rc) return rc; }
+    double *d_out = nullptr, *d_outn = nullptr;
+    int64_t m = 0;
+    rc = voxel_core(c, d_pts, d_nrm, N, voxel_size, &d_out, &d_outn, &m);
+    if (rc) return rc;
+    *n_out = m;
+    PEDP_REQUIRE(m <= capacity, "pedp_voxel_down_sample: %lld voxels exceed the output capacity %lld", (long long)m,
+                 (long long)capacity);
+    PEDP_REQUIRE(out_pts && (out_normals || !normals), "pedp_voxel_down_sample: null output arrays");
+    { int dn_ = pedp_download(c, out_pts, d_out, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
+    if (normals) { int dn_ = pedp_download(c, out_normals, d_outn, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PEDP_OK;
+}
 
 int pedp_voxel_down_sample(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
                            double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out) {
@@ -1061,71 +1399,6 @@ int pedp_voxel_down_sample_device_in(pedp_ctx_t c, const double *d_pts, int64_t 
     return voxel_down_sample_impl(c, d_pts, nullptr, N, voxel_size, out_pts, nullptr, capacity, n_out, true);
 }
 
-static int voxel_down_sample_impl(pedp_ctx_t c, const double *pts, const double *normals, int64_t N, double voxel_size,
-                                  double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, bool pts_on_device) {
-    int rc = check_cloud(c, pts, N, "pedp_voxel_down_sample");
-    if (rc) return rc;
-    PEDP_REQUIRE(n_out, "pedp_voxel_down_sample: null count");
-    *n_out = 0;
-    PEDP_REQUIRE(voxel_size > 0.0, "pedp_voxel_down_sample: voxel_size <= 0");  // Open3D raises too
-    if (N == 0) return PEDP_OK;
-    double lo[3], hi[3];
-    PEDP_HIP_CHECK(hipSetDevice(c->device));
-    const unsigned n = (unsigned)N;
-    size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                           (int *)nullptr, (int *)nullptr, n, 0, 63, c->stream));
-    PEDP_ROCPRIM(rocprim::run_length_encode(nullptr, tmp_rle, (unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
-                                            (unsigned *)nullptr, (unsigned *)nullptr, c->stream));
-    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
-                                         rocprim::plus<unsigned>(), c->stream));
-    size_t tmp = tmp_sort > tmp_rle ? tmp_sort : tmp_rle;
-    if (tmp_scan > tmp) tmp = tmp_scan;
-    const size_t need = a256(sizeof(double) * 3 * N) * 4 + a256(sizeof(unsigned long long) * N) * 3 + a256(sizeof(int) * N) * 2 +
-                        a256(sizeof(unsigned) * N) * 2 + 256 + a256(tmp) + a256(sizeof(double) * 6 * BND_BLOCKS) + 4096;
-    int st = c->ops.reserve(need);
-    if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N), *d_nrm = cv.take<double>(3 * (size_t)N);
-    double *d_out = cv.take<double>(3 * (size_t)N), *d_outn = cv.take<double>(3 * (size_t)N);
-    unsigned long long *key = cv.take<unsigned long long>(N), *key_s = cv.take<unsigned long long>(N),
-                       *uniq = cv.take<unsigned long long>(N);
-    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
-    unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
-    void *d_tmp = cv.take<char>(tmp);
-    double *d_part = cv.take<double>(6 * BND_BLOCKS);
-    if (pts_on_device) d_pts = const_cast<double *>(pts);  // the caller's device array, read only
-    else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    if (normals) { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    rc = bounds_device(c, d_pts, N, d_part, lo, hi);   // (the box of the points just uploaded: no host pass over them)
-    if (rc) return rc;
-    for (int k = 0; k < 3; ++k) {
-        PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
-        lo[k] = lo[k] - voxel_size * 0.5;
-        PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
-    }
-    const unsigned grid = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
-    PEDP_ROCPRIM(rocprim::run_length_encode(d_tmp, tmp_rle, key_s, n, uniq, counts, n_runs, c->stream));
-    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, counts, offsets, 0u, n, rocprim::plus<unsigned>(), c->stream));
-    hipLaunchKernelGGL(voxel_average_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, normals ? d_nrm : nullptr, val_s, counts,
-                       offsets, n_runs, d_out, d_outn);
-    PEDP_HIP_CHECK(hipGetLastError());
-    unsigned *h_runs = (unsigned *)((char *)c->pinned + 8192);
-    PEDP_HIP_CHECK(hipMemcpyAsync(h_runs, n_runs, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    const int64_t m = *h_runs;
-    *n_out = m;
-    PEDP_REQUIRE(m <= capacity, "pedp_voxel_down_sample: %lld voxels exceed the output capacity %lld", (long long)m,
-                 (long long)capacity);
-    PEDP_REQUIRE(out_pts && (out_normals || !normals), "pedp_voxel_down_sample: null output arrays");
-    { int dn_ = pedp_download(c, out_pts, d_out, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
-    if (normals) { int dn_ = pedp_download(c, out_normals, d_outn, sizeof(double) * 3 * (size_t)m); if (dn_) return dn_; }
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return PEDP_OK;
-}
-
 int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, int min_points, int32_t *labels) {
     int rc = check_cloud(c, pts, N, "pedp_cluster_dbscan");
     if (rc) return rc;
@@ -1134,48 +1407,13 @@ int pedp_cluster_dbscan(pedp_ctx_t c, const double *pts, int64_t N, double eps, 
     PEDP_REQUIRE(labels, "pedp_cluster_dbscan: null labels");
     double lo[3], hi[3];
     bounds(pts, N, lo, hi);
-    Grid g;
-    int64_t n_cells = 0;
-    // cell >= eps with margin: neighbours within eps are never two cells apart
-    rc = make_grid(lo, hi, eps * (1.0 + 1e-9), g, n_cells, "pedp_cluster_dbscan");
-    if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    const unsigned n = (unsigned)N;
-    size_t tmp_sort = 0, tmp_scan = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
-                                           (int *)nullptr, n, 0, 32, c->stream));
-    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
-                                         rocprim::plus<unsigned>(), c->stream));
-    const size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
-    const size_t need = a256(sizeof(double) * 3 * N) * 2 + a256(sizeof(unsigned) * N) * 4 + a256(sizeof(int) * N) * 6 +
-                        a256(sizeof(int) * n_cells) * 2 + a256(tmp) + 4096;
-    int st = c->ops.reserve(need);
-    if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N);
-    unsigned *cell = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N), *is_rep = cv.take<unsigned>(N), *rank = cv.take<unsigned>(N);
-    int *val = cv.take<int>(N), *val_s = cv.take<int>(N), *core = cv.take<int>(N), *parent = cv.take<int>(N), *root = cv.take<int>(N);
-    int32_t *d_labels = cv.take<int32_t>(N);
-    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
-    void *d_tmp = cv.take<char>(tmp);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    const unsigned grid = (unsigned)((N + 255) / 256);
-    const double e2 = eps * eps;
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell, cell_s, val, val_s, n, 0, 32, c->stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    const unsigned grid_w = (unsigned)((N + DB_WPB - 1) / DB_WPB);
-    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, sp, N, cell_start, cell_end, e2,
-                       min_points, val_s, core, parent);
-    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s,
-                       core, parent);
-    hipLaunchKernelGGL(dbscan_root_kernel, dim3(grid), dim3(256), 0, c->stream, N, core, parent, root, is_rep);
-    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, is_rep, rank, 0u, n, rocprim::plus<unsigned>(), c->stream));
-    hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, sp, N, cell_start, cell_end, e2, val_s, root,
-                       rank, d_labels);
-    PEDP_HIP_CHECK(hipGetLastError());
+    double *d_pts = nullptr;
+    rc = upload_in(c, pts, nullptr, N, &d_pts, nullptr);
+    if (rc) return rc;
+    int32_t *d_labels = nullptr;
+    rc = dbscan_core(c, d_pts, N, eps, min_points, lo, hi, &d_labels);
+    if (rc) return rc;
     { int dn_ = pedp_download(c, labels, d_labels, sizeof(int32_t) * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
@@ -1187,72 +1425,15 @@ int pedp_knn_mean_distance(pedp_ctx_t c, const double *pts, int64_t N, int k, do
     PEDP_REQUIRE(k >= 1 && k <= 300, "pedp_knn_mean_distance: k must be in 1..300");  // k x 64 doubles of LDS per workgroup
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(avg, "pedp_knn_mean_distance: null output");
-    if (N <= KNN_SMALL_MAX) {  // a wave per query, all distances in LDS
-        PEDP_HIP_CHECK(hipSetDevice(c->device));
-        int st0 = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(double) * N) + 512);
-        if (st0) return st0;
-        Carver cv0{(char *)c->ops.ptr};
-        double *d_pts0 = cv0.take<double>(3 * (size_t)N), *d_avg0 = cv0.take<double>(N);
-        { int up_ = pedp_upload(c, d_pts0, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(double) * KNN_SMALL_MAX)));
-        hipLaunchKernelGGL(knn_mean_small_kernel, dim3((unsigned)N), dim3(64), sizeof(double) * (size_t)N, c->stream, d_pts0, (int)N,
-                           k, d_avg0);
-        PEDP_HIP_CHECK(hipGetLastError());
-        { int dn_ = pedp_download(c, avg, d_avg0, sizeof(double) * (size_t)N); if (dn_) return dn_; }
-        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-        return PEDP_OK;
-    }
     double lo[3], hi[3];
     bounds(pts, N, lo, hi);
-    // cell ~ the radius that holds k points if the cloud were spread over a sheet of the box's
-    // largest extent (scanned surfaces are sheets); any cell size gives the same result
-    double ext = 0.0;
-    for (int d = 0; d < 3; ++d) ext = std::fmax(ext, hi[d] - lo[d]);
-    double cell = ext * std::sqrt((double)k / (3.14159265358979 * (double)N));
-    if (!(cell > 0.0) || !std::isfinite(cell)) cell = 1.0;
-    Grid g;
-    int64_t n_cells = 0;
-    rc = make_grid(lo, hi, cell, g, n_cells, "pedp_knn_mean_distance");
-    if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    const unsigned n = (unsigned)N;
-    size_t tmp_sort = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
-                                           (int *)nullptr, n, 0, 32, c->stream));
-    const size_t need = a256(sizeof(double) * 3 * N) * 2 + a256(sizeof(double) * N) + a256(sizeof(unsigned) * N) * 2 +
-                        a256(sizeof(int) * N) * 2 + a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + 4096;
-    int st = c->ops.reserve(need);
-    if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_avg = cv.take<double>(N);
-    unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
-    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
-    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
-    void *d_tmp = cv.take<char>(tmp_sort);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    const unsigned grid = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    // a wave per query; a cloud too dense for the LDS share of some query falls back to a thread per query
-    int *d_over = (int *)((char *)d_tmp);  // the sort is done: its scratch is free
-    int *h_over = (int *)((char *)c->pinned + 8192);
-    PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(knn_mean_wave_kernel, dim3((unsigned)((N + KNN_WPB - 1) / KNN_WPB)), dim3(KNN_WPB * 64), 0, c->stream, g, sp, N,
-                       cell_start, cell_end, val_s, k, d_avg, d_over);
-    PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipMemcpyAsync(h_over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*h_over) {
-        const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
-        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds,
-                           c->stream, g, sp, N, cell_start, cell_end, val_s, k, d_avg);
-        PEDP_HIP_CHECK(hipGetLastError());
-    }
+    double *d_pts = nullptr;
+    rc = upload_in(c, pts, nullptr, N, &d_pts, nullptr);
+    if (rc) return rc;
+    double *d_avg = nullptr;
+    rc = knn_core(c, d_pts, N, k, lo, hi, &d_avg);
+    if (rc) return rc;
     { int dn_ = pedp_download(c, avg, d_avg, sizeof(double) * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
@@ -1266,43 +1447,23 @@ int pedp_estimate_normals(pedp_ctx_t c, const double *pts, int64_t N, double rad
     PEDP_REQUIRE(max_nn >= 1 && max_nn <= 128, "pedp_estimate_normals: max_nn must be in 1..128");
     if (N == 0) return PEDP_OK;
     PEDP_REQUIRE(normals, "pedp_estimate_normals: null output");
-    double lo[3], hi[3], *d_in = nullptr;
-    rc = bounds_of(c, pts, N, lo, hi, &d_in);
-    if (rc) return rc;
-    Grid g;
-    int64_t n_cells = 0;
-    rc = make_grid(lo, hi, radius * (1.0 + 1e-9), g, n_cells, "pedp_estimate_normals");
-    if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    const unsigned n = (unsigned)N;
-    size_t tmp_sort = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr,
-                                           (int *)nullptr, n, 0, 32, c->stream));
-    const size_t need = a256(sizeof(double) * 3 * N) * 4 + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 2 +
-                        a256(sizeof(int) * n_cells) * 2 + a256(tmp_sort) + 4096;
-    int st = c->ops.reserve(need);
-    if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_prior = cv.take<double>(3 * (size_t)N),
-           *d_out = cv.take<double>(3 * (size_t)N);
-    unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
-    int *val = cv.take<int>(N), *val_s = cv.take<int>(N);
-    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
-    void *d_tmp = cv.take<char>(tmp_sort);
-    if (d_in) d_pts = d_in;  // already up (bounds_of)
-    else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    if (prior) { int up_ = pedp_upload(c, d_prior, prior, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    const unsigned grid = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, val_s, d_pts, N, cell_start, cell_end, sp);
-    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)max_nn * NRM_THREADS;
-    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((N + NRM_THREADS - 1) / NRM_THREADS)), dim3(NRM_THREADS), lds, c->stream, g,
-                       sp, N, cell_start, cell_end, val_s, radius * radius, max_nn, d_pts, prior ? d_prior : nullptr, d_out);
-    PEDP_HIP_CHECK(hipGetLastError());
+    double *d_pts = nullptr, *d_prior = nullptr;
+    rc = upload_in(c, pts, prior, N, &d_pts, &d_prior);
+    if (rc) return rc;
+    double lo[3], hi[3];
+    if (N < BND_DEVICE_MIN) {
+        bounds(pts, N, lo, hi);
+    } else {  // the box of a large cloud from its device copy: no host pass over the caller's array
+        double *d_part = nullptr;
+        rc = small_block(c, &d_part);
+        if (rc) return rc;
+        rc = bounds_device(c, d_pts, N, d_part, lo, hi);
+        if (rc) return rc;
+    }
+    double *d_out = nullptr;
+    rc = normals_core(c, d_pts, N, radius, max_nn, d_prior, lo, hi, &d_out);
+    if (rc) return rc;
     { int dn_ = pedp_download(c, normals, d_out, sizeof(double) * 3 * (size_t)N); if (dn_) return dn_; }
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
@@ -1420,31 +1581,161 @@ int pedp_segment_plane(pedp_ctx_t c, const double *pts, int64_t N, double distan
     if (N < 3 || num_iterations == 0) return PEDP_OK;
     PEDP_REQUIRE(inliers, "pedp_segment_plane: null inlier array");
     PEDP_HIP_CHECK(hipSetDevice(c->device));
-    int st = c->ops.reserve(a256(sizeof(double) * 3 * N) + a256(sizeof(int) * (size_t)num_iterations) + 512);
-    if (st) return st;
-    Carver cv{(char *)c->ops.ptr};
-    double *d_pts = cv.take<double>(3 * (size_t)N);
-    int *d_cnt = cv.take<int>(num_iterations);
-    { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)num_iterations), dim3(256), 0, c->stream, d_pts, (long long)N,
-                       distance_threshold, (unsigned long long)seed, d_cnt);
-    PEDP_HIP_CHECK(hipGetLastError());
-    std::vector<int> counts((size_t)num_iterations);
-    PEDP_HIP_CHECK(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int) * (size_t)num_iterations, hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int best_t = -1, best_cnt = -1;
-    for (int t = 0; t < num_iterations; ++t)
-        if (counts[t] > best_cnt) { best_cnt = counts[t]; best_t = t; }  // most inliers, earliest iteration on ties
-    if (best_t < 0) return PEDP_OK;
-    long long s[3];
+    double *d_pts = nullptr;
+    rc = upload_in(c, pts, nullptr, N, &d_pts, nullptr);
+    if (rc) return rc;
+    int best_t = -1;
     double best[4];
-    sample3(seed, best_t, N, s);
-    triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], best);
+    rc = plane_best_core(c, d_pts, N, distance_threshold, num_iterations, seed, &best_t, best);
+    if (rc) return rc;
+    if (best_t < 0) return PEDP_OK;
     int64_t n = 0;
     for (int64_t i = 0; i < N; ++i)
         if (plane_dist(best, pts + 3 * i) < distance_threshold) inliers[n++] = (int32_t)i;
     plane_from_points(pts, inliers, n, plane);
     *n_inliers = n;
+    return PEDP_OK;
+}
+
+// ------------------------------------------------------------------ preprocess_source, device resident
+// The reference's scene preprocessing (src/pose_estimation.py:186-268, the branch without param['box'] /
+// param['mesh'] / background): voxel grid -> table plane by RANSAC -> [normals of the down-sampled cloud] ->
+// plane removed -> DBSCAN, largest cluster -> statistical outlier filter -> [normals, oriented like the first
+// ones].  The same kernels as the single operations above, chained on the device: what crosses PCIe is the
+// input cloud (if it is not on the device already), a few counters and small arrays the host decides on
+// (RANSAC inlier counts, three sampled points, cluster labels of the ~7 k points left, their mean neighbour
+// distances) and the processed cloud.  Results are bit for bit those of the step-by-step calls.
+int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
+                           double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
+                           int *status) {
+    int rc = check_cloud(c, pts, N, "pedp_preprocess_source");
+    if (rc) return rc;
+    PEDP_REQUIRE(prm && n_out && status && out_pts, "pedp_preprocess_source: null argument");
+    PEDP_REQUIRE(prm->voxel_size > 0.0, "pedp_preprocess_source: voxel_size <= 0");
+    PEDP_REQUIRE(prm->plane_iterations >= 1 && prm->plane_iterations <= 10000000, "pedp_preprocess_source: plane_iterations out of range");
+    PEDP_REQUIRE(prm->cluster_eps > 0.0 && std::isfinite(prm->cluster_eps), "pedp_preprocess_source: cluster_eps must be positive");
+    PEDP_REQUIRE(prm->outlier_neighbors >= 1 && prm->outlier_neighbors <= 300, "pedp_preprocess_source: outlier_neighbors must be in 1..300");
+    PEDP_REQUIRE(!prm->first_frame || (prm->normal_radius > 0.0 && prm->normal_max_nn >= 1 && prm->normal_max_nn <= 128 && out_normals),
+                 "pedp_preprocess_source: normals (first frame) need a radius, max_nn in 1..128 and an output array");
+    *n_out = 0;
+    *status = PEDP_PREPROCESS_OK;
+    if (stage_counts) stage_counts[0] = stage_counts[1] = stage_counts[2] = stage_counts[3] = 0;
+    if (N < 3) { *status = PEDP_PREPROCESS_DEGENERATE; return PEDP_OK; }
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const bool nrm = prm->first_frame != 0;
+    double *d_in = const_cast<double *>(pts);
+    if (!pts_on_device) { rc = upload_in(c, pts, nullptr, N, &d_in, nullptr); if (rc) return rc; }
+    // ---- voxel grid
+    double *v_pts = nullptr, *v_nrm = nullptr, *d_part = nullptr;
+    int64_t m1 = 0;
+    rc = voxel_core(c, d_in, nullptr, N, prm->voxel_size, &v_pts, &v_nrm, &m1);
+    if (rc) return rc;
+    if (stage_counts) stage_counts[0] = m1;
+    if (m1 < 3) { *status = PEDP_PREPROCESS_DEGENERATE; return PEDP_OK; }
+    // the clouds between the stages: three (points, normals) pairs and a flag array, sized by the down-sampled cloud
+    const size_t one = a256(sizeof(double) * 3 * (size_t)m1);
+    rc = c->chain.reserve(6 * one + a256(sizeof(unsigned) * (size_t)m1) + 256);
+    if (rc) return rc;
+    rc = small_block(c, &d_part);
+    if (rc) return rc;
+    char *cb = (char *)c->chain.ptr;
+    double *A_pts = (double *)cb, *A_nrm = (double *)(cb + one), *B_pts = (double *)(cb + 2 * one), *B_nrm = (double *)(cb + 3 * one),
+           *C_pts = (double *)(cb + 4 * one), *C_nrm = (double *)(cb + 5 * one);
+    unsigned *flag = (unsigned *)(cb + 6 * one);
+    PEDP_HIP_CHECK(hipMemcpyAsync(A_pts, v_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
+    // ---- table plane: the best of the sampled planes (the refit plane of segment_plane has no reader on this branch)
+    int best_t = -1;
+    double best[4] = {0, 0, 0, 0};
+    rc = plane_best_core(c, A_pts, m1, prm->plane_distance, prm->plane_iterations, prm->seed, &best_t, best);
+    if (rc) return rc;
+    double lo[3], hi[3];
+    // ---- normals of the down-sampled cloud (they orient the final ones)
+    if (nrm) {
+        rc = bounds_device(c, A_pts, m1, d_part, lo, hi);
+        if (rc) return rc;
+        double *n_out_d = nullptr;
+        rc = normals_core(c, A_pts, m1, prm->normal_radius, prm->normal_max_nn, nullptr, lo, hi, &n_out_d);
+        if (rc) return rc;
+        PEDP_HIP_CHECK(hipMemcpyAsync(A_nrm, n_out_d, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // ---- the plane's inliers removed (no plane found: nothing removed, like select_by_index of an empty list)
+    int64_t m2 = m1;
+    if (best_t >= 0) {
+        hipLaunchKernelGGL(plane_keep_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1, best[0], best[1],
+                           best[2], best[3], prm->plane_distance, 0, flag);
+        rc = select_core(c, A_pts, nrm ? A_nrm : nullptr, m1, flag, B_pts, B_nrm, &m2);
+        if (rc) return rc;
+    } else {
+        PEDP_HIP_CHECK(hipMemcpyAsync(B_pts, A_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
+        if (nrm) PEDP_HIP_CHECK(hipMemcpyAsync(B_nrm, A_nrm, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (stage_counts) stage_counts[1] = m2;
+    if (m2 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
+    // ---- DBSCAN, largest cluster (np.unique + argmax: the lowest label among the largest)
+    rc = bounds_device(c, B_pts, m2, d_part, lo, hi);
+    if (rc) return rc;
+    int32_t *d_labels = nullptr;
+    rc = dbscan_core(c, B_pts, m2, prm->cluster_eps, prm->cluster_min_points, lo, hi, &d_labels);
+    if (rc) return rc;
+    std::vector<int32_t> labels((size_t)m2);
+    { int dn_ = pedp_download(c, labels.data(), d_labels, sizeof(int32_t) * (size_t)m2); if (dn_) return dn_; }
+    int32_t top = -1;
+    for (int64_t i = 0; i < m2; ++i) top = labels[i] > top ? labels[i] : top;
+    if (top < 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
+    std::vector<int64_t> members((size_t)top + 1, 0);
+    for (int64_t i = 0; i < m2; ++i)
+        if (labels[i] >= 0) ++members[labels[i]];
+    int32_t largest = 0;
+    for (int32_t l = 1; l <= top; ++l)
+        if (members[l] > members[largest]) largest = l;
+    hipLaunchKernelGGL(label_keep_kernel, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_labels, m2,
+                       largest, flag);
+    int64_t m3 = 0;
+    rc = select_core(c, B_pts, nrm ? B_nrm : nullptr, m2, flag, C_pts, C_nrm, &m3);
+    if (rc) return rc;
+    if (stage_counts) stage_counts[2] = m3;
+    // ---- statistical outlier filter: mean distance to the k nearest on the device, Open3D's global step on the host
+    // in index order (cloud_ops.statistical_outlier_indices: sequential sums), the cut again on the device
+    if (m3 > KNN_SMALL_MAX) {
+        rc = bounds_device(c, C_pts, m3, d_part, lo, hi);
+        if (rc) return rc;
+    }
+    double *d_avg = nullptr;
+    rc = knn_core(c, C_pts, m3, prm->outlier_neighbors, lo, hi, &d_avg);
+    if (rc) return rc;
+    std::vector<double> avg((size_t)m3);
+    { int dn_ = pedp_download(c, avg.data(), d_avg, sizeof(double) * (size_t)m3); if (dn_) return dn_; }
+    int64_t valid = 0;
+    for (int64_t i = 0; i < m3; ++i) valid += avg[i] >= 0.0 ? 1 : 0;
+    int64_t m4 = 0;
+    if (valid > 0) {
+        double sum = 0.0;
+        for (int64_t i = 0; i < m3; ++i) sum += avg[i] > 0.0 ? avg[i] : 0.0;
+        const double mean = sum / (double)valid;
+        double sq = 0.0;
+        for (int64_t i = 0; i < m3; ++i) sq += avg[i] > 0.0 ? (avg[i] - mean) * (avg[i] - mean) : 0.0;
+        const double sd = valid > 1 ? std::sqrt(sq / (double)(valid - 1)) : std::nan("");
+        const double limit = mean + prm->outlier_std_ratio * sd;
+        hipLaunchKernelGGL(range_keep_kernel, dim3((unsigned)((m3 + 255) / 256)), dim3(256), 0, c->stream, (const double *)d_avg, m3, limit,
+                           flag);
+        rc = select_core(c, C_pts, nrm ? C_nrm : nullptr, m3, flag, A_pts, A_nrm, &m4);
+        if (rc) return rc;
+    }
+    if (stage_counts) stage_counts[3] = m4;
+    *n_out = m4;
+    PEDP_REQUIRE(m4 <= capacity, "pedp_preprocess_source: %lld points exceed the output capacity %lld", (long long)m4, (long long)capacity);
+    if (m4 == 0) return PEDP_OK;
+    // ---- normals of the processed cloud, oriented like the ones it carries
+    if (nrm) {
+        rc = bounds_device(c, A_pts, m4, d_part, lo, hi);
+        if (rc) return rc;
+        double *n_fin = nullptr;
+        rc = normals_core(c, A_pts, m4, prm->normal_radius, prm->normal_max_nn, A_nrm, lo, hi, &n_fin);
+        if (rc) return rc;
+        { int dn_ = pedp_download(c, out_normals, n_fin, sizeof(double) * 3 * (size_t)m4); if (dn_) return dn_; }
+    }
+    { int dn_ = pedp_download(c, out_pts, A_pts, sizeof(double) * 3 * (size_t)m4); if (dn_) return dn_; }
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PEDP_OK;
 }
 

@@ -217,6 +217,8 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ray_order.release();
     c->ray_rast.release();
     c->ops_in.release();
+    c->ops_small.release();
+    c->chain.release();
     c->cloud_pool.clear();
     c->sort_ws.release();
     if (c->rast_status) (void)hipHostFree(c->rast_status);

@@ -2901,12 +2901,16 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
         PEDP_HIP_CHECK(hipMemsetAsync(w.ticket, 0, 17 * 128, x->stream));
         for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
     }
-    if (job.timed_pass != -1) x->nn_pairs = 0;
+    if (job.timed_pass != -1) { x->nn_pairs = 0; x->nn_span_launches = 1; }
     for (int pass = 0; pass <= max_iter; ++pass) {
         // timing: one chosen pass (pair nn_ev0/1), or -- timed_pass = -2 -- every fourth pass from
         // pass 1 on, up to eight pairs, whose mean pedp_nn_last_sweep_ms reports
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (pass == job.timed_pass) { ev0 = x->nn_ev0; ev1 = x->nn_ev1; }
+        if (job.timed_pass == -3) {  // ONE pair around all the passes' launches: the mean launch-to-launch span
+            if (pass == 0) { ev0 = x->nn_ev0; x->nn_span_launches = max_iter + 1; }
+            if (pass == max_iter) ev1 = x->nn_ev1;
+        }
         if (job.timed_pass == -2 && (pass & 3) == 1 && x->nn_pairs < 8) {
             for (int k = 0; k < 2; ++k)
                 if (!x->nn_evs[2 * x->nn_pairs + k]) PEDP_HIP_CHECK(hipEventCreate(&x->nn_evs[2 * x->nn_pairs + k]));
@@ -3385,6 +3389,7 @@ int pedp_nn_last_sweep_ms(pedp_ctx_t c, float *ms) {
     }
     PEDP_HIP_CHECK(hipEventSynchronize(c->nn_ev1));
     PEDP_HIP_CHECK(hipEventElapsedTime(ms, c->nn_ev0, c->nn_ev1));
+    if (c->nn_span_launches > 1) *ms /= (float)c->nn_span_launches;
     return PEDP_OK;
 }
 

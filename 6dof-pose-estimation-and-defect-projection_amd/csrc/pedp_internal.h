@@ -110,11 +110,14 @@ struct pedp_ctx_s {
     // pairs around the sweep kernel of every fourth pass, created on first use
     hipEvent_t nn_evs[16] = {};
     int nn_pairs = 0;  // pairs recorded by the last timed registration (0: the single pair above)
+    int nn_span_launches = 1;  // timed_pass = -3: launches between the single pair's two events
     // ICP
     pedp_scratch icp_ws;
     pedp_scratch ops;        // point-cloud operations (voxel grid, DBSCAN, kNN, plane RANSAC)
     pedp_scratch sort_ws;    // spatial order of a cloud: keys + radix-sort buffers (pooled, stream-ordered)
     pedp_pool cloud_pool;    // buffers of destroyed cloud handles
+    pedp_scratch ops_small;  // partial bounds and counters of the point-cloud operations
+    pedp_scratch chain;      // pedp_preprocess_source: the clouds between its stages
     pedp_scratch ops_in;     // a large cloud's points, uploaded ahead of the workspace sizing (its box comes from the device copy)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)

@@ -158,9 +158,9 @@ def preprocess_source(pcd, background, param, i=0):
     The point-cloud operations run on the GPU (pedp_hip.cloud_ops).  Returns (processed, filtered,
     fpfh) with filtered is processed, as in the reference.
 
-    Not built: FPFH features (:254-260) are only read by the global-registration path, the slot is
-    None (i == 0) or 0 (i > 0); param['mesh'] (Poisson re-meshing, :240-245) raises
-    NotImplementedError.
+    FPFH features (:254-260) are computed when the section names fpfh_radius / fpfh_max_nn (only the
+    global-registration path reads them), else the slot is None (i == 0) or 0 (i > 0).  Not built:
+    param['mesh'] (Poisson re-meshing, :240-245) raises NotImplementedError.
     A param dict without a 'preprocess_source' section means "already preprocessed": the cloud is
     passed through (the tracking-frame mutation down_sample = 5 is still applied)."""
     if "preprocess_source" not in param:
@@ -171,6 +171,21 @@ def preprocess_source(pcd, background, param, i=0):
     if i > 0:
         params["down_sample"] = 5
     pcd, background = as_holder(pcd), as_holder(background)  # Open3D inputs: the GPU methods, not Open3D's
+    # The branch run.py takes -- no box, no mesh, no background cloud, nobody reading the INFO lines -- runs as ONE
+    # library call with the scene on the device between the stages (pedp_preprocess_source): the same kernels and
+    # rules as the calls below, bit for bit the same cloud (tests/test_cloudops_gpu.py).  Anything else, and a
+    # frame that leaves no cluster, goes through the steps, whose behaviour is then the reference's to the letter.
+    if (background is None and not param.get("box") and not param.get("mesh")
+            and not logging.getLogger().isEnabledFor(logging.INFO) and not _FORCE_STEPS):
+        from . import cloud_ops
+
+        src_pts = pcd._dev_points if getattr(pcd, "_points", 0) is None and pcd._dev_points is not None else points_of(pcd)
+        plane = params["plane_removal"]
+        out_p, out_n, _, status = cloud_ops.preprocess_source_fused(src_pts, params["down_sample"], plane["distance_threshold"],
+                                                                    plane["num_iterations"], first_frame=(i == 0))
+        if status == 0:
+            source_processed = PointCloud(out_p, out_n)
+            return source_processed, source_processed, (fpfh_of(source_processed, params) if i == 0 else 0)
     if background is not None:
         background = background.voxel_down_sample(voxel_size=params["down_sample"] * 2)
     pcd_down = pcd.voxel_down_sample(voxel_size=params["down_sample"])
@@ -204,6 +219,8 @@ def preprocess_source(pcd, background, param, i=0):
         source_fpfh = fpfh_of(source_processed, params)
     return source_processed, source_processed, source_fpfh
 
+
+_FORCE_STEPS = False   # tests: preprocess_source through the single operations
 
 Z_LOOKAHEAD = 3   # probes tried ahead per batch: 2^3 - 1 = 7 start poses share the launches of one
 

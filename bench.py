@@ -15,14 +15,24 @@ The two stages are independent (scene cloud vs mesh): each runs on its own conte
 stream and they overlap on the device; a step ends when both have finished.
 
 N > 1, --mode shard (default; SURVEY s8e, north_star): ONE frame is split over the ranks --
-rays in contiguous blocks with an all-gather of the 8-byte hit records, scene points in
-contiguous blocks with one 29-double all-reduce per correspondence pass; the collectives are
-issued by the library on its own streams (RCCL over xGMI).  Total work is fixed: strong scaling.
+rays in contiguous blocks with an all-gather of the 8-byte hit records (RCCL over xGMI, issued by the
+library on its own stream).  The frame's ONE registration is replicated on every rank for scenes below
+a million points (a pass is ~35 us: 21 all-reduces cost more than they save; every rank gets the identical
+pose without a collective); larger scenes are sharded with one 29-double all-reduce per pass, and that
+variant is timed beside it ("icp_scene_sharded").  The ICP lever across GPUs at these sizes is the pose
+batch (BASELINE config 3): "icp_batched" shards 32 start poses over the ranks.  Total work is fixed: strong scaling.
 --mode replica: every rank processes its own whole frame, no collective (weak scaling); in shard
 mode the replica rate of the same ranks is measured too and reported under "replica".
 
 Timed regions, each bracketed by barrier + synchronize, max over ranks:
-    headline     K steps of the default path (culled ray stage, block-sparse ICP)  -> value
+    headline     K steps of the default path (triangle-driven ray stage, chunked ICP: one launch per pass)
+                 on ONE resident frame                                              -> value
+    fresh_frame  (N = 1) K steps in which everything a new camera frame brings is inside the step: a new scene
+                 cloud handle from a device array with new noise (copy, box, spatial order, chunk spheres),
+                 a new mesh pose (records rebuilt on the device), then the same ICP + cast   -> "fresh_frame"
+    frame_chain  (N = 1) K frames of BASELINE config 5's geometry chain (pedp_hip.frame_chain: depth filters,
+                 back-projection, preprocess_source, z search, randomised restarts, posed mesh, heat-map
+                 projection, viewer message), a new depth image per frame              -> "frame_chain"
     exhaustive   a few steps of the all-pairs path north_star's targets are set on: every ray x
                  every triangle (sweep variant 1) and every scene point x every model point in
                  every ICP pass (pedp_icp_configure(exhaustive))                    -> "exhaustive"
@@ -51,7 +61,8 @@ FLOP_PER_TEST = 46        # Moeller-Trumbore with stored (v0, e1, e2
 FLOP_PER_TEST_EXECUTED = 21  # shared-origin form: three dot products + the inside test per triangle
 FLOP_PER_PAIR = 8         # one K=4 fp32 MFMA dot per (scene, model) pair
 ICP_ITERS = 20
-TIMED_PASS = -2           # HIP events around the sweep kernel of every fourth pass (1, 5, 9, 13, 17): their mean
+TIMED_PASS = -3           # headline: ONE HIP-event pair around all 21 launches of the pass kernel: span / 21
+TIMED_PASS_EX = -2        # exhaustive region: events around the sweep kernel of every fourth pass (1, 5, 9, 13, 17): their mean
 
 
 def parse():
@@ -231,10 +242,15 @@ def run(args):
         ray_ctx.synchronize()                      # the step ends when both stages have finished
         return res
 
-    def step_sharded():
+    replicate_icp = n_scene < 1_000_000   # one registration of a camera-size scene: every rank runs it whole
+
+    def step_sharded(force_scene_shards=False):
         sharded.cast()                             # this rank's ray block + all-gather, on the ray stream
         a = time.perf_counter()
-        res = sharded.icp(init, radius, max_iteration=ICP_ITERS, rel_fitness=-1.0, rel_rmse=-1.0)
+        if replicate_icp and not force_scene_shards:
+            res = _lib.icp(ctx, src, tgt, radius, init, **icp_kw)
+        else:
+            res = sharded.icp(init, radius, max_iteration=ICP_ITERS, rel_fitness=-1.0, rel_rmse=-1.0)
         icp_wall[0] = 1e3 * (time.perf_counter() - a)
         ray_ctx.synchronize()
         return res
@@ -270,13 +286,14 @@ def run(args):
     elapsed, res, rows = timed_region(step, args.steps, args.warmup)
     passes, pairs_swept, fb_points = _lib.icp_last_stats(ctx)
     ms_per_step = 1e3 * elapsed / args.steps
+    ray_variant, grid_status = _lib.raycast_last_variant(ray_ctx)   # which ray stage answered the timed casts
 
     extras = {}
     if not args.no_extras:
         # ---- exhaustive region: the all-pairs path, same resident inputs, same sharding
         ex_steps = max(2, min(args.steps, 4))
         _lib.raycast_configure(ray_ctx, 0, 1)
-        _lib.icp_configure(ctx, exhaustive=True, timed_pass=TIMED_PASS)
+        _lib.icp_configure(ctx, exhaustive=True, timed_pass=TIMED_PASS_EX)
         try:
             ex_elapsed, ex_res, ex_rows = timed_region(step_serial, ex_steps, 1)
             ex_passes, ex_pairs, _ = _lib.icp_last_stats(ctx)
@@ -288,6 +305,62 @@ def run(args):
         if mode == "shard":
             rp_elapsed, _, rp_rows = timed_region(step_whole, args.steps, 1)
             extras["replica"] = (rp_elapsed, rp_rows)
+            if replicate_icp:   # the scene-sharded registration (one all-reduce per pass) beside the replicated one
+                ss_elapsed, ss_res, ss_rows = timed_region(lambda: step_sharded(True), max(2, min(args.steps, 4)), 1)
+                extras["scene_sharded"] = (max(2, min(args.steps, 4)), ss_elapsed, ss_res, ss_rows)
+        if world == 1:
+            # ---- fresh_frame region: what a NEW camera frame costs -- scene handle from a device array with new
+            # noise, new mesh pose, then the same ICP + cast
+            base_dev = torch.from_numpy(scene).to(dev)
+            noise_dev = [torch.from_numpy(np.random.default_rng(100 + k).normal(0.0, 0.05, scene.shape)).to(dev) for k in range(4)]
+            poses = []
+            for k in range(4):
+                D = np.eye(4)
+                D[:3, :3] = synth.axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(0.01 * k))
+                poses.append(frame.T_gt @ D)
+            pmesh = _lib.Mesh(ray_ctx, frame.model_points, frame.tris, posable=True)
+            fresh_wall = []
+
+            def step_fresh():
+                k = len(fresh_wall)
+                a = time.perf_counter()
+                pts = base_dev + noise_dev[k % 4]                 # the frame's new points (torch's stream) ...
+                torch.cuda.current_stream().synchronize()         # ... are complete before the library reads them
+                pmesh.set_pose(poses[k % 4])                      # records rebuilt on the device (ray stream)
+                pmesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
+                b = time.perf_counter()
+                s_k = _lib.Cloud.from_device(ctx, pts.data_ptr(), len(pts))   # copy, box, then (inside pedp_icp) order + spheres
+                r_k = _lib.icp(ctx, s_k, tgt, radius, init, **icp_kw)
+                c = time.perf_counter()
+                ray_ctx.synchronize()
+                s_k.close()                                       # buffers back to the context's pool
+                icp_wall[0] = 1e3 * (c - b)
+                fresh_wall.append((1e3 * (b - a), 1e3 * (c - b)))
+                return r_k
+
+            fr_elapsed, fr_res, _ = timed_region(step_fresh, args.steps, 2)
+            extras["fresh_frame"] = (fr_elapsed, fr_res, np.array(fresh_wall[-args.steps:]), _lib.raycast_last_variant(ray_ctx))
+            del pmesh, base_dev, noise_dev
+            # ---- frame_chain region: BASELINE config 5's geometry chain, a new depth image per frame
+            import queue as _queue
+            from pedp_hip import viewer_wire
+            from pedp_hip.frame_chain import bench_frame_setup
+            chain, depth_m, heat, init_pose = bench_frame_setup(frame, depth)
+            viewer_wire.attach_queues(_queue.Queue())
+            drng = np.random.default_rng(7)
+            depth_k = [(depth_m + drng.normal(0.0, 2e-4, depth_m.shape)).astype(np.float32) for _ in range(4)]
+            n_done = [0]
+
+            def step_chain():
+                out_k = chain.process(depth_k[n_done[0] % 4], init_pose(), heat, seed=n_done[0])
+                n_done[0] += 1
+                return {"T": out_k["icp"].transformation, "fitness": out_k["icp"].fitness, "n_hits": len(out_k["cloud"].points)}
+
+            fc_steps = max(3, min(args.steps, 10))
+            fc_elapsed, fc_res, _ = timed_region(step_chain, fc_steps, 2)
+            chain.process(depth_k[0], init_pose(), heat, seed=0, timed=True)     # stage times, outside the timed region
+            extras["frame_chain"] = (fc_steps, fc_elapsed, fc_res, dict(chain.stage_ms))
+            viewer_wire.attach_queues(None)
         # ---- BASELINE config 3 in small: 32 start poses refined concurrently, poses sharded over the ranks
         inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(32)])
         lo, hi = pdist.shard_bounds(len(inits), rank, world)
@@ -318,7 +391,7 @@ def run(args):
 
     if rank == 0:
         traffic = {}
-        for name in ("r02_traffic.json", "r01_traffic.json"):   # PMC passes committed under profiles/
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # PMC passes committed under profiles/
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     traffic = json.load(fh)
@@ -326,7 +399,7 @@ def run(args):
             except OSError:
                 pass
         trace_us = None     # the same kernel in the committed rocprofv3 kernel trace of this command
-        for name in ("r02_bench_kernel_stats_v4.csv", "r02_bench_kernel_stats_v5.csv"):   # the newest one present wins
+        for name in ("r02_bench_kernel_stats_v5.csv", "r03_bench_kernel_stats.csv"):   # the newest one present wins
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in csv.DictReader(fh):
@@ -362,8 +435,9 @@ def run(args):
             "icp_fitness": res["fitness"], "icp_inlier_rmse": res["inlier_rmse"],
             "pose_error_vs_gt": float(np.abs(np.linalg.inv(res["T"]) - frame.T_gt).max()),
             # dominant kernel of the HEADLINE step as it runs there (rank 0's share in shard mode)
-            "roofline": {"kernel": "icp_pass_kernel (fused per-chunk pass: transform, culling, MFMA sweep, selection, partial "
-                                   "sums)", "region": "headline", "bound": "mfma",
+            "ray_variant": ray_variant, "ray_grid_status": grid_status,
+            "roofline": {"kernel": "icp_pass_kernel (one launch per pass: per-chunk transform, culling, MFMA sweep, selection, partial "
+                                   "sums; the last workgroup sums, solves and updates the pose)", "region": "headline", "bound": "mfma",
                          "achieved": sweep_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": sweep_tflops / PEAK_FP32_TFLOPS,
                          "traffic": traffic.get("icp_pass_kernel", {}).get("hbm_bytes_per_launch"),
@@ -372,12 +446,13 @@ def run(args):
                          "kernel_ms_x_launches": sweep_ms * passes, "region_ms_per_step": ms_per_step,
                          "kernel_us_committed_kernel_trace": trace_us,
                          "note": f"{FLOP_PER_PAIR} flop x {pairs_pass:.4g} (scene slot, model point) pairs the kernel swept per "
-                                 "pass (mean over the passes) / mean HIP-event duration of its launches in passes 1, 5, 9, "
-                                 "13, 17 of every registration of the timed loop (an event pair brackets the launch with two "
-                                 "barrier packets, several us more than the dispatch-to-completion span a kernel trace "
-                                 "records; kernel_us_committed_kernel_trace is that span from profiles/).  The kernel is one workgroup per "
-                                 "live scene chunk and is bound by its chain of dependent memory accesses (DESIGN s4.2), "
-                                 "not by the matrix pipe: the MFMA fraction says how little of the pass is arithmetic"},
+                                 "pass (16 x 16 per MFMA, mean over the passes) / mean launch-to-launch time of the kernel: ONE "
+                                 "HIP-event pair around the 21 launches of every registration of the timed loop, span / 21, "
+                                 "launch boundaries included (kernel_us_committed_kernel_trace is its mean dispatch-to-completion "
+                                 "span in the rocprofv3 kernel trace under profiles/).  The launch is "
+                                 "the WHOLE pass (the finish kernel of round 2 is inside it); it is one workgroup per live scene "
+                                 "chunk and is bound by its chain of dependent memory accesses and by the serial close of the "
+                                 "pass (DESIGN s4.2), not by the matrix pipe: the MFMA fraction says how little of it is arithmetic"},
         }
         if "exhaustive" in extras:
             ex_steps, ex_elapsed, ex_res, ex_rows, ex_passes, ex_pairs = extras["exhaustive"]
@@ -421,6 +496,50 @@ def run(args):
                         "SURVEY s8d is the side field.  north_star's >= 50 % of the HBM roofline (triangle-stream "
                         "accounting, ceil(N_r/64) x N_f x 36 B per launch) is NOT met: the records are L2-resident and "
                         "the kernel is FP32-VALU-bound (SURVEY s0 D5)"}
+        rast = traffic.get("ray_stage_rast")
+        ray_bytes = 24.0 * n_rays + 48.0 * n_tris + 8.0 * n_rays       # rays in, triangle records in, (t, id) out
+        if mode != "shard":
+            out["roofline_ray_stage"] = {
+                "kernel": "triangle-driven ray stage (rast_bounds / rast_insert / rast_tri / rast_item / ray_finalize)" if ray_variant == 4
+                          else f"ray stage, variant {ray_variant}", "region": "headline", "bound": "hbm",
+                "achieved": ray_bytes / (ray_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ray_bytes / (ray_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": None if not rast else rast.get("hbm_bytes_per_cast"),
+                "kernel_ms": ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ray_ms, "region_ms_per_step": ms_per_step,
+                "pmc": rast,
+                "note": "algorithmic bytes of one cast = 24 B per ray in + 48 B per triangle record in + 8 B per ray out "
+                        f"= {ray_bytes / 1e6:.1f} MB, over the HIP-event span of the cast's kernels.  Five short launches: the "
+                        "stage is bound by launch boundaries and by the chains of dependent accesses inside them (cell "
+                        "heads -> nodes -> atomicMin keys), not by HBM; see DESIGN s4.1 for the PMC reading"}
+        if "fresh_frame" in extras:
+            fr_elapsed, fr_res, fr_wall, fr_variant = extras["fresh_frame"]
+            out["fresh_frame"] = {
+                "ms_per_frame": 1e3 * fr_elapsed / args.steps, "value_mrays_per_s": n_rays * args.steps / fr_elapsed / 1e6,
+                "new_points_pose_cast_enqueue_ms": float(fr_wall[:, 0].mean()), "cloud_order_icp_ms": float(fr_wall[:, 1].mean()),
+                "icp_iters_per_s": ICP_ITERS / (float(fr_wall[:, 1].mean()) * 1e-3),
+                "ray_variant": fr_variant[0], "ray_grid_status": fr_variant[1],
+                "icp_fitness": fr_res["fitness"], "pose_error_vs_gt": float(np.abs(np.linalg.inv(fr_res["T"]) - frame.T_gt).max()),
+                "note": "every step: new scene points on the device (base + fresh noise), pedp_cloud_create_device (copy, box), "
+                        "spatial order + chunk spheres of the new handle, pedp_mesh_set_pose with a new pose (records rebuilt), "
+                        f"{ICP_ITERS}-iteration registration, full-frame cast; the handle's buffers go back to the pool"}
+        if "frame_chain" in extras:
+            fc_steps, fc_elapsed, fc_res, fc_stage = extras["frame_chain"]
+            out["frame_chain"] = {
+                "frames": fc_steps, "ms_per_frame": 1e3 * fc_elapsed / fc_steps, "frames_per_s": fc_steps / fc_elapsed,
+                "stage_ms": fc_stage, "icp_fitness": fc_res["fitness"], "projected_hits": fc_res["n_hits"],
+                "pose_error_vs_gt": float(np.abs(np.linalg.inv(fc_res["T"]) - frame.T_gt).max()),
+                "note": "BASELINE config 5, geometry part (pedp_hip.frame_chain; tests/test_stream_gpu.py checks every stage "
+                        "against the oracle): a new 640x576 depth image per frame -> depth filters -> back-projection -> "
+                        "preprocess_source -> z search -> randomised ICP restarts -> posed mesh -> heat-map projection -> "
+                        "viewer message.  stage_ms from one extra, synchronised frame outside the timed region"}
+        if "scene_sharded" in extras:
+            ss_steps, ss_elapsed, ss_res, ss_rows = extras["scene_sharded"]
+            out["icp_scene_sharded"] = {
+                "ms_per_step": 1e3 * ss_elapsed / ss_steps, "icp_iters_per_s": ICP_ITERS / (float(ss_rows[:, 0].mean()) * 1e-3),
+                "pose_equals_headline": bool(np.abs(ss_res["T"] - res["T"]).max() < 1e-9),
+                "note": "the same step with the registration's scene points sharded over the ranks and one 29-double all-reduce "
+                        "per pass (SURVEY s8e row 2): the right shape for scenes of millions of points, slower than the "
+                        "replicated registration at camera size"}
         if "replica" in extras:
             rp_elapsed, rp_rows = extras["replica"]
             out["replica"] = {"value_mrays_per_s": world * n_rays * args.steps / rp_elapsed / 1e6, "scaling": "weak",

@@ -213,6 +213,40 @@ int pedp_feature_match(pedp_ctx_t ctx, const double *fs, int64_t Ns, const doubl
 int pedp_segment_plane(pedp_ctx_t ctx, const double *pts, int64_t N, double distance_threshold, int num_iterations,
                        uint64_t seed, double plane[4], int32_t *inliers, int64_t *n_inliers);
 
+/* preprocess_source of a frame in one call (src/pose_estimation.py:186-268; the branch run.py takes: no
+ * param['box'], no param['mesh'], no background cloud), the scene staying on the device between the stages:
+ *     voxel_down_sample(down_sample) :204-205 -> segment_plane :323-329 -> [i == 0: estimate_normals of the
+ *     down-sampled cloud :216] -> select_by_index(inliers, invert=True) :234 -> cluster_dbscan(eps 10, 10) +
+ *     largest cluster :270-299 -> remove_statistical_outlier(75, 0.01) :308-312 -> [i == 0: estimate_normals
+ *     of the result :250-251, oriented like the ones it carries]
+ * The kernels and rules of the single operations above; results are bit for bit those of calling them one
+ * after the other.  pts: N x 3 float64, host memory or (pts_on_device != 0) device memory that the caller has
+ * ordered before the call.  out_pts / out_normals (normals only when first_frame): capacity x 3 float64 host
+ * arrays; capacity = N always fits.  stage_counts (nullable): points after the voxel grid, the plane removal,
+ * the cluster selection, the outlier filter.  status: PEDP_PREPROCESS_OK, _NO_CLUSTER (nothing left after the
+ * plane, or DBSCAN found noise only -- the reference prints "No valid clusters found." and fails on None) or
+ * _DEGENERATE (fewer than three points); n_out is 0 for the latter two. */
+typedef struct pedp_preprocess_params {
+    double voxel_size;          /* params['down_sample'] */
+    double plane_distance;      /* params['plane_removal']['distance_threshold'] */
+    int32_t plane_iterations;   /* params['plane_removal']['num_iterations'] */
+    int32_t first_frame;        /* i == 0 */
+    uint64_t seed;              /* segment_plane's sampler (see pedp_segment_plane) */
+    double normal_radius;       /* estimate_normals: 2 */
+    int32_t normal_max_nn;      /*                   5 */
+    int32_t cluster_min_points; /* filter_largest_cluster: 10 */
+    double cluster_eps;         /*                         10 */
+    int32_t outlier_neighbors;  /* remove_statistical_outliers: 75 */
+    int32_t reserved;
+    double outlier_std_ratio;   /*                              0.01 */
+} pedp_preprocess_params;
+#define PEDP_PREPROCESS_OK 0
+#define PEDP_PREPROCESS_NO_CLUSTER 1
+#define PEDP_PREPROCESS_DEGENERATE 2
+int pedp_preprocess_source(pedp_ctx_t ctx, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
+                           double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
+                           int *status);
+
 /* ---------------------------------------------------------------- ICP
  * Replaces src/pose_estimation.py:519-521 and :654-660:
  *     o3d.pipelines.registration.registration_icp(source, target, max_corr_dist, init,
@@ -305,9 +339,13 @@ int pedp_ransac_hypotheses(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t tar
  *     correspondences and poses are identical to the culled run, only the work differs.
  *   timed_pass >= 0: record HIP events around the sweep kernel of that correspondence pass (read
  *     with pedp_nn_last_sweep_ms); -2: around the sweep kernel of every fourth pass from pass 1 on
- *     (up to eight), pedp_nn_last_sweep_ms then reports their mean; -1 = none.
- * "Sweep kernel": nn_sweep_kernel on the segmented path, icp_pass_kernel (the whole per-chunk
- * pass, sweep included) on the fused path of radius-limited registrations. */
+ *     (up to eight), pedp_nn_last_sweep_ms then reports their mean; -3 (fused path): ONE pair of
+ *     events around all the passes' launches of a registration, pedp_nn_last_sweep_ms reports the
+ *     span divided by the number of launches -- the mean launch-to-launch time of the pass kernel,
+ *     boundaries included; -1 = none.
+ * "Sweep kernel": nn_sweep_kernel on the segmented path, icp_pass_kernel (the whole pass: per-chunk
+ * work, sweep included, and its close by the last workgroup) on the fused path of radius-limited
+ * registrations. */
 int pedp_icp_configure(pedp_ctx_t ctx, int exhaustive, int timed_pass);
 
 /* Work statistics of the last pedp_icp on this context: correspondence passes run, (scene,

@@ -300,3 +300,41 @@ def test_device_resident_scene_through_the_voxel_grid(ctx, oracle):
     b, _, _ = preprocess_source(PointCloud(pts), None, params, i=0)
     assert np.array_equal(a.points, b.points) and np.array_equal(a.normals, b.normals)
     assert np.array_equal(holder.points, pts) and holder.colors.shape == pts.shape                   # read: now it is made
+
+
+def test_preprocess_source_in_one_call_equals_the_steps(ctx, oracle):
+    """pedp_preprocess_source (the scene on the device between the stages) against preprocess_source through the
+    single operations: the same points and normals in every bit, for the first frame and a tracking frame, from a host
+    array and from a device tensor; a frame that leaves no cluster takes the step path (the reference's behaviour)."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import cloud_ops, icp_refine, synth
+    from pedp_hip.compat import PointCloud, preprocess_source
+
+    f = synth.Frame("parity")
+    depth = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
+    scene = f.scene(depth)
+    for i in (0, 1):
+        param = {"preprocess_source": {"down_sample": 4, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 200}},
+                 "box": False, "mesh": False}
+        icp_refine._FORCE_STEPS = True
+        try:
+            steps, _, _ = preprocess_source(PointCloud(scene), None, {k: (dict(v) if isinstance(v, dict) else v) for k, v in param.items()}, i=i)
+        finally:
+            icp_refine._FORCE_STEPS = False
+        one, _, fp = preprocess_source(PointCloud(scene), None, param, i=i)
+        assert np.array_equal(one.points, steps.points) and len(one.points) > 200
+        assert one.has_normals() == steps.has_normals() == (i == 0)
+        if i == 0:
+            assert np.array_equal(one.normals, steps.normals) and fp is None
+        dev, _, _ = preprocess_source(PointCloud(torch.from_numpy(scene).cuda()), None, dict(param), i=i)
+        assert np.array_equal(dev.points, steps.points) and (i != 0 or np.array_equal(dev.normals, steps.normals))
+    # the counters of the stages, and the statuses
+    voxel = 4 if True else 0
+    p, n, counts, status = cloud_ops.preprocess_source_fused(scene, voxel, 2.0, 200, first_frame=True, ctx=ctx)
+    down, _ = oracle.voxel_down_sample(scene, voxel)
+    assert status == 0 and counts[0] == len(down) and counts[1] > counts[2] >= counts[3] == len(p) and n.shape == p.shape
+    flat = np.c_[np.random.default_rng(0).uniform(0, 100, (4000, 2)), np.zeros(4000)]      # nothing but the plane
+    p, n, counts, status = cloud_ops.preprocess_source_fused(flat, 2.0, 1.0, 50, first_frame=False, ctx=ctx)
+    assert status == 1 and len(p) == 0 and n is None and counts[1] == 0
+    p, n, counts, status = cloud_ops.preprocess_source_fused(flat[:2], 2.0, 1.0, 50, first_frame=False, ctx=ctx)
+    assert status == 2 and len(p) == 0

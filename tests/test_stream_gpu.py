@@ -18,67 +18,28 @@ pytestmark = pytest.mark.gpu
 
 
 def test_config5_frame_chain_at_camera_resolution(oracle, tmp_path):
-    torch = pytest.importorskip("torch")
+    pytest.importorskip("torch")
     from pedp_hip import compat, synth, viewer_wire
-    from pedp_hip.compat import PinholeCameraIntrinsic, PointCloud, TriangleMesh
-    from pedp_hip.ray_projection import FrameProjector
+    from pedp_hip.compat import PointCloud
+    from pedp_hip.frame_chain import bench_frame_setup
 
     f = synth.Frame("bench_100k")                                         # 640 x 576, 100k triangles
     t_hit = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)["t_hit"]
-    rng = np.random.default_rng(0)
-    z_mm = np.where(np.isfinite(t_hit), t_hit * f.dirs[:, 2], 600.0) + rng.normal(0.0, 0.5, t_hit.shape)
-    depth_m = (z_mm / 1000.0).reshape(f.height, f.width).astype(np.float32)   # the filters work in metres
+    chain, depth_m, heat, init_pose = bench_frame_setup(f, t_hit)          # the chain bench.py's frame_chain region times
     K32 = f.K.astype(np.float32)
-    model = PointCloud(f.model_points, normals=f.normals)
-    mesh = TriangleMesh(f.model_points, f.tris)
-    intr = PinholeCameraIntrinsic(f.width, f.height, intrinsic_matrix=f.K)
-    color_to_depth = np.eye(4)
-    color_to_depth[:3, 3] = (2.0, -1.0, 0.5)
+    params, color_to_depth = chain.params, chain.color_to_depth
     depth_to_color = np.linalg.inv(color_to_depth)
-    heat = np.zeros((f.height, f.width))
-    heat[200:380, 220:420] = np.linspace(0.76, 1.0, 200)[None, :]
-    params = {"preprocess_target": {"max_pcd": 100000, "keep_normals": True},
-              "preprocess_source": {"down_sample": 2, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 500}},
-              "box": False, "mesh": False,
-              "refine_registration": {"distance_threshold": 6.0}, "run_icp": {"fitness_threshold": 0.97, "rmse_threshold": 0.8}}
-    proj = FrameProjector(mesh, intr, color_to_depth)
     q = queue.Queue()
     viewer_wire.attach_queues(q)
-    # the scene cloud comes back to the host (the reference's chain works on host clouds): into a PINNED
-    # buffer that lives across frames.  A pageable destination makes the runtime pin and unpin 9 MB per
-    # frame, which holds up the next submissions by 20-30 ms (DESIGN s6).
-    host_pts = torch.empty((f.width * f.height, 3), dtype=torch.float64, pin_memory=True)
 
-    def frame(seed):
-        # ---- depth pre-filters and back-projection, device tensors throughout (estimater.py:255-259)
-        d = torch.from_numpy(depth_m).cuda()
-        d = compat.erode_depth(d, radius=2, device="cuda")
-        d = compat.bilateral_filter_depth(d, radius=2, device="cuda")
-        xyz = compat.depth2xyzmap_batch(d[None], torch.as_tensor(K32, device="cuda")[None], zfar=np.inf)[0]
-        dev_pts = xyz[xyz[..., 2] >= 0.001].double() * 1000.0                  # scene cloud in mm (run.py works in mm)
-        host_pts[: len(dev_pts)].copy_(dev_pts)
-        pts = host_pts[: len(dev_pts)].numpy().copy()
-        source = PointCloud(pts)
-        # ---- run.py:95-99: start pose (depth-camera frame), refinement
-        init = synth.start_pose()
-        init[2, 3] += 5.0
-        np.random.seed(seed)
-        _, icp, z, _ = compat.refine_pose_with_icp(source, model, None, init, params)
-        # ---- run.py:109-119: posed mesh, projection in the colour-camera frame, back into the depth frame
-        model_in_scene = np.linalg.inv(icp.transformation)
-        mesh_copy = compat.transform_object(mesh, model_in_scene)
-        cloud = proj.project(model_in_scene, heat, 0.75)
-        cloud.transform(color_to_depth)
-        msg = compat.update_dash_data([cloud], mesh_copy)                      # run.py:131
-        return d, xyz, pts, init, icp, z, cloud, mesh_copy, msg
-
-    frame(0)                                                                   # warm-up: buffers, graphs
+    chain.process(depth_m, init_pose(), heat, seed=0)                          # warm-up: buffers, graphs
     n = 3
     t0 = time.perf_counter()
     for _ in range(n):
-        out = frame(0)
+        out = chain.process(depth_m, init_pose(), heat, seed=0)
     dt = (time.perf_counter() - t0) / n
-    d, xyz, pts, init, icp, z, cloud, mesh_copy, msg = out
+    d, xyz, pts, init, icp, z, cloud, mesh_copy, msg = (out[k] for k in ("depth", "xyz", "points", "init", "icp", "z", "cloud",
+                                                                           "mesh", "message"))
     print(f"config 5 geometry chain: {1e3 * dt:.1f} ms per 640x576 frame = {1.0 / dt:.1f} frames/s "
           f"({len(pts)} scene points, {len(cloud.points)} projected hits)")
 
