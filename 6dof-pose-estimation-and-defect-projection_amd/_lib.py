@@ -84,6 +84,7 @@ PROTOTYPES = {
     "pedp_raycast_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_raycast_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_raycast_last_variant": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "pedp_debug_rast_rects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_cloud_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "pedp_cloud_create_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "pedp_cloud_destroy": (None, [C.c_void_p]),
@@ -332,6 +333,16 @@ class Cloud:
 
 def raycast_configure(ctx, tri_chunks=0, variant=0):
     check(load().pedp_raycast_configure(ctx._h, int(tri_chunks), int(variant)), "pedp_raycast_configure")
+
+
+def debug_rast_rects(ctx, mesh, rays6):
+    """pedp_debug_rast_rects: (tri [F, 12], ray [N, 3], (GX, GY, grid_status)) of a variant-4 cast of these rays."""
+    r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
+    tri = np.zeros((mesh.F, 12), np.float32)
+    ray = np.zeros((len(r), 3), np.float32)
+    grid = np.zeros(3, np.int32)
+    check(load().pedp_debug_rast_rects(ctx._h, mesh._h, _ptr(r), len(r), _ptr(tri), _ptr(ray), _ptr(grid)), "pedp_debug_rast_rects")
+    return tri, ray, tuple(int(x) for x in grid)
 
 
 def raycast_last_sweep_ms(ctx):

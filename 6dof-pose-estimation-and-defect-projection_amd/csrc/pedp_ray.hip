@@ -53,6 +53,7 @@
 // triangles (coalesced 16-B loads of the AoS records), 4 wave-uniform rays per wave, and the
 // packed key is min-reduced across the 64 lanes: the wavefront-wide min-t reduction.
 #include "pedp_internal.h"
+#include <vector>
 #include <new>
 
 namespace {
@@ -787,13 +788,13 @@ constexpr int RAST_ITEM_CAP = 1 << 18;
 constexpr int RAST_CHAIN_MAX = 64;
 constexpr float RAST_COS_MIN = 0.17f;
 constexpr int RAST_ITEM_WAVES = 2048;
-constexpr float RAST_DILATE_MAX = 64.0f;
+constexpr int RAST_FULL_CAP = 8192;     // triangles without a bounded image that one cast can list
 
 struct RastHdr {  // two per context (used in turn), device memory; ray_finalize_kernel puts the other one back to its start values
     int ok;       // 1: the grid answers this cast; 0: the exhaustive loop in ray_finalize_kernel does
     int n_items;
     int reason;   // why ok was cleared: 1 origins differ, 2 ray outside the half space, 4 chain too long, 8 item table full
-    int pad;
+    int n_full;   // triangles without a bounded image (listed; rast_full_kernel tests them against every ray)
     float O[3], A[3], E1[3], E2[3];
     float u0, v0, su, sv;
     int GX, GY;
@@ -1006,20 +1007,25 @@ __device__ __forceinline__ void rast_test(const float4 nd, unsigned ray, const f
     if (mt_accept(m)) atomicMin(&keys[ray], mt_key(m, f));
 }
 
-__global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__ aos, int64_t F, RastHdr *__restrict__ h,
-                                                      const unsigned *__restrict__ head, const float4 *__restrict__ nodes,
-                                                      RastItem *__restrict__ items, unsigned long long *__restrict__ keys) {
-    if (h->ok == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t fl = f < F ? f : F - 1;  // tail lanes re-run the last triangle and drop it below
-    const float *rec = aos + fl * PEDP_TRI_STRIDE;
-    const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
-    float O[3], A[3], E1[3], E2[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { O[k] = h->O[k]; A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
-    const int GX = h->GX, GY = h->GY;
-    const float u0 = h->u0, v0 = h->v0, su = h->su, sv = h->sv;
+// The cells of the rays that can meet triangle q (origin O, frame A/E1/E2, grid u0/v0/su/sv, GX x GY): the
+// bounding rectangle of its mapped corners, widened by a margin that is PROVEN to hold every ray the oracle's
+// fp32 test accepts (DESIGN s4.1 "Margin": derivation; tests/test_ray_gpu.py::test_grid_margin_* measure it).
+//   An accepted ray has, in exact arithmetic on the stored operands, barycentric coordinates no farther outside
+//   the triangle than the roundings of un, vn, det allow: with u = 2^-24, s = O - v0, L the longest edge, m = e2 x e1
+//   its exact hit point lies within  6.5 u (3 |s| + L) L^2 / (|m| cos theta_d) + 2.1 u L  of the triangle; mapped
+//   to the plane at unit distance along A (a point at depth w, off axis by |p|, moves by (1 + |p|) / w per unit)
+//   and with cos theta_d |P - O| = |s . m| / |m| that is at most
+//       u c_a [6.5 (3 |s| + L) L^2 + 2.1 L |m|] / |s . m|,     c_a = (1 + |p|) sqrt(1 + |p|^2),
+//   |p| taken at its largest over the rectangle.  TWICE that is used, plus 64 u (1 + |p|^2) for the roundings of
+//   the two mappings (ray and corners) and an eighth of a cell for the cell arithmetic.  The margin is never cut
+//   off (round 2 capped it at 64 cells).  A triangle seen so nearly edge-on that s . m is rounding (the origin
+//   within ~1e-6 rad of its plane) has no bounded image, like one that reaches the plane through O: such triangles
+//   are LISTED and tested against every ray by rast_full_kernel.  m == 0 exactly: det is 0 for every ray, nothing
+//   can be accepted.
+struct RastRect { float fx0, fx1, fy0, fy1, mx, my; int full; };  // unwidened rectangle in cell units, the margins, "every cell"
+__device__ __forceinline__ bool rast_rect(const TriRec &q, const float *O, const float *A, const float *E1, const float *E2,
+                                          float u0, float v0, float su, float sv, int GX, int GY, int &x0, int &x1, int &y0,
+                                          int &y1, RastRect &rr) {
     // corners relative to O (v1, v2 re-derived from the record's edges: one more rounding, far below the margins)
     float X[3][3];
     X[0][0] = q.v0x - O[0]; X[0][1] = q.v0y - O[1]; X[0][2] = q.v0z - O[2];
@@ -1036,8 +1042,10 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
         scale = fmaxf(scale, fabsf(X[k][0]) + fabsf(X[k][1]) + fabsf(X[k][2]));
     }
     const float eps = 1e-5f * scale;
-    bool live = f < F && !(wmax < -eps);  // wholly behind the plane through O: t . (d.A) = w > 0 is impossible
-    int x0 = 0, x1 = GX - 1, y0 = 0, y1 = GY - 1;
+    bool live = !(wmax < -eps);  // wholly behind the plane through O: t . (d.A) = w > 0 is impossible
+    if (q.mx == 0.0f && q.my == 0.0f && q.mz == 0.0f) live = false;  // det = d . m == 0 for every ray
+    x0 = 0; x1 = GX - 1; y0 = 0; y1 = GY - 1;
+    rr.fx0 = 0.f; rr.fx1 = (float)GX; rr.fy0 = 0.f; rr.fy1 = (float)GY; rr.mx = rr.my = 0.f; rr.full = 1;
     if ((wmin > eps) && (scale < 3e38f)) {  // otherwise it reaches the plane (or has a NaN / infinite corner): no bounded image
         float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f;
 #pragma unroll
@@ -1047,22 +1055,79 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
             umin = fminf(umin, a); umax = fmaxf(umax, a);
             vmin = fminf(vmin, b); vmax = fmaxf(vmax, b);
         }
-        // Margin.  The oracle's fp32 test accepts a ray whose exact point lies outside the exact triangle by
-        // at most the rounding of un, vn, det against |det| -- in mapped coordinates a dilation of
-        // about g / (sin phi cos theta), g ~ 2^-22, phi the corner angle, theta the viewing angle; with
-        // s = v0 - O that is g |e1| |e2| |s| / |s . m|.  Sixteen times that, plus an eighth of a cell
-        // (capped at RAST_DILATE_MAX cells: beyond that the origin lies within ~1e-4 rad of the triangle's
-        // plane, every ray that reaches the triangle does so at |det| of rounding size).
         const float l1 = sqrtf(q.e1x * q.e1x + q.e1y * q.e1y + q.e1z * q.e1z), l2 = sqrtf(q.e2x * q.e2x + q.e2y * q.e2y + q.e2z * q.e2z);
+        const float gx = q.e2x - q.e1x, gy = q.e2y - q.e1y, gz = q.e2z - q.e1z;
+        const float L = fmaxf(fmaxf(l1, l2), sqrtf(gx * gx + gy * gy + gz * gz));
         const float ls = sqrtf(X[0][0] * X[0][0] + X[0][1] * X[0][1] + X[0][2] * X[0][2]);
+        const float lm = sqrtf(q.mx * q.mx + q.my * q.my + q.mz * q.mz);
         const float sm = fabsf(X[0][0] * q.mx + X[0][1] * q.my + X[0][2] * q.mz);
-        const float dil = fminf(3.8e-6f * l1 * l2 * ls / fmaxf(sm, 1e-30f), 1e6f);
-        const float mx_ = 0.125f + fminf(dil * su, RAST_DILATE_MAX), my_ = 0.125f + fminf(dil * sv, RAST_DILATE_MAX);
-        const float fx0 = (umin - u0) * su - mx_, fx1 = (umax - u0) * su + mx_;
-        const float fy0 = (vmin - v0) * sv - my_, fy1 = (vmax - v0) * sv + my_;
-        if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 < (float)GX) || !(fy0 < (float)GY)) live = false;  // beside the rays' rectangle
-        x0 = rast_clampi(fx0, GX - 1); x1 = rast_clampi(fx1, GX - 1);
-        y0 = rast_clampi(fy0, GY - 1); y1 = rast_clampi(fy1, GY - 1);
+        const float pa = fmaxf(fabsf(umin), fabsf(umax)), pb = fmaxf(fabsf(vmin), fabsf(vmax));
+        const float pm2 = (pa * pa + pb * pb) * 1.01f + 1e-6f, pm = sqrtf(pm2);
+        const float ca = (1.0f + pm) * sqrtf(1.0f + pm2);
+        const float U = 5.9604645e-8f;
+        const float dil = 2.0f * U * ca * (6.5f * (3.0f * ls + L) * L * L + 2.1f * L * lm) / fmaxf(sm, 1e-37f) + 64.0f * U * (1.0f + pm2);
+        // (s . m itself carries up to 4 u |s| |m| of rounding: below sixteen times u |s| |m| it says nothing -- the
+        // triangle has no bounded image; above, it is within a third of the exact value, which the factor two absorbs)
+        if (sm > 16.0f * U * ls * lm && dil * su < 1e9f && dil * sv < 1e9f) {  // (false for NaN / inf too)
+            const float mx_ = 0.125f + dil * su, my_ = 0.125f + dil * sv;
+            rr.fx0 = (umin - u0) * su; rr.fx1 = (umax - u0) * su; rr.fy0 = (vmin - v0) * sv; rr.fy1 = (vmax - v0) * sv;
+            rr.mx = mx_; rr.my = my_; rr.full = 0;
+            const float fx0 = rr.fx0 - mx_, fx1 = rr.fx1 + mx_, fy0 = rr.fy0 - my_, fy1 = rr.fy1 + my_;
+            if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 < (float)GX) || !(fy0 < (float)GY)) live = false;  // beside the rays' rectangle
+            x0 = rast_clampi(fx0, GX - 1); x1 = rast_clampi(fx1, GX - 1);
+            y0 = rast_clampi(fy0, GY - 1); y1 = rast_clampi(fy1, GY - 1);
+        }
+    }
+    return live;
+}
+
+// diagnostics (pedp_debug_rast_rects): the rectangle of every triangle and the continuous cell coordinates of every ray
+__global__ void rast_debug_tri_kernel(const float *__restrict__ aos, int64_t F, const RastHdr *__restrict__ h, float *__restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float *rec = aos + f * PEDP_TRI_STRIDE;
+    const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
+    float O[3], A[3], E1[3], E2[3];
+    for (int k = 0; k < 3; ++k) { O[k] = h->O[k]; A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
+    int x0, x1, y0, y1;
+    RastRect rr;
+    const bool live = rast_rect(q, O, A, E1, E2, h->u0, h->v0, h->su, h->sv, h->GX, h->GY, x0, x1, y0, y1, rr);
+    float *o = out + 12 * f;
+    o[0] = live ? 1.f : 0.f; o[1] = (float)rr.full; o[2] = rr.fx0; o[3] = rr.fx1; o[4] = rr.fy0; o[5] = rr.fy1; o[6] = rr.mx; o[7] = rr.my;
+    o[8] = (float)x0; o[9] = (float)x1; o[10] = (float)y0; o[11] = (float)y1;
+}
+__global__ void rast_debug_ray_kernel(const float *__restrict__ rays6, int64_t N, const RastHdr *__restrict__ h, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float A[3], E1[3], E2[3], u = 0.f, v = 0.f;
+    for (int k = 0; k < 3; ++k) { A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
+    const int kind = rast_map(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], A, E1, E2, u, v);
+    out[3 * i] = (float)kind; out[3 * i + 1] = (u - h->u0) * h->su; out[3 * i + 2] = (v - h->v0) * h->sv;
+}
+
+__global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__ aos, int64_t F, RastHdr *__restrict__ h,
+                                                      const unsigned *__restrict__ head, const float4 *__restrict__ nodes,
+                                                      RastItem *__restrict__ items, unsigned long long *__restrict__ keys,
+                                                      unsigned *__restrict__ full_list) {
+    if (h->ok == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t fl = f < F ? f : F - 1;  // tail lanes re-run the last triangle and drop it below
+    const float *rec = aos + fl * PEDP_TRI_STRIDE;
+    const TriRec q = {rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], rec[11]};
+    float O[3], A[3], E1[3], E2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { O[k] = h->O[k]; A[k] = h->A[k]; E1[k] = h->E1[k]; E2[k] = h->E2[k]; }
+    const int GX = h->GX, GY = h->GY;
+    const float u0 = h->u0, v0 = h->v0, su = h->su, sv = h->sv;
+    int x0, x1, y0, y1;
+    RastRect rr;
+    bool live = rast_rect(q, O, A, E1, E2, u0, v0, su, sv, GX, GY, x0, x1, y0, y1, rr) && f < F;
+    if (live && rr.full) {  // no bounded image: every ray, by the kernel made for that (a handful of silhouette triangles)
+        const int at = atomicAdd(&h->n_full, 1);
+        if (at < RAST_FULL_CAP) full_list[at] = (unsigned)f;
+        else rast_fail(h, 8);
+        live = false;
     }
     const int w = x1 - x0 + 1, hh = y1 - y0 + 1;
     const long long ncell = live ? (long long)w * hh : 0;
@@ -1135,6 +1200,30 @@ __global__ __launch_bounds__(256) void rast_tri_kernel(const float *__restrict__
             if (++steps > RAST_CHAIN_MAX) { rast_fail(h, 4); break; }
         }
     }
+}
+
+// The listed triangles (no bounded image) against EVERY ray: a thread per ray, the records through scalar loads.
+__global__ __launch_bounds__(256) void rast_full_kernel(const float *__restrict__ aos, const float *__restrict__ rays6, int64_t N,
+                                                       const RastHdr *__restrict__ h, const unsigned *__restrict__ full_list,
+                                                       unsigned long long *__restrict__ keys) {
+    if (h->ok == 0) return;
+    const int n = h->n_full < RAST_FULL_CAP ? h->n_full : RAST_FULL_CAP;
+    if (n == 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Ray r;
+    r.ox = rays6[6 * i]; r.oy = rays6[6 * i + 1]; r.oz = rays6[6 * i + 2];
+    r.dx = rays6[6 * i + 3]; r.dy = rays6[6 * i + 4]; r.dz = rays6[6 * i + 5];
+    unsigned long long best = KEY_MISS;
+    for (int k = 0; k < n; ++k) {
+        const unsigned f = full_list[k];  // wave-uniform
+        const MT m = mt_eval(r, aos + (size_t)f * PEDP_TRI_STRIDE);
+        if (mt_accept(m)) {
+            const unsigned long long key = mt_key(m, f);
+            best = key < best ? key : best;
+        }
+    }
+    if (best != KEY_MISS) atomicMin(&keys[i], best);
 }
 
 __global__ __launch_bounds__(256) void rast_item_kernel(const float *__restrict__ aos, RastHdr *__restrict__ h,
@@ -1244,7 +1333,7 @@ __global__ __launch_bounds__(256) void ray_finalize_kernel(const float *__restri
         rast_status[1] = (int)(N & 0x7FFFFFFF);
         rast_status[0] = rast->ok ? 0 : rast->reason;
         __threadfence_system();
-        rast_next->ok = 1; rast_next->n_items = 0; rast_next->reason = 0;
+        rast_next->ok = 1; rast_next->n_items = 0; rast_next->reason = 0; rast_next->n_full = 0;
     }
     if (i >= N) return;
     if (rast && rast->ok == 0) {
@@ -1480,8 +1569,10 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         variant = 2;
         if (N >= 16384) {
             // the grid of variant 4 unless an earlier cast of this many rays reported that it could not
-            // answer them (rays behind the frame's plane, crowded cells, a full item table)
-            if (c->rast_status && (((volatile int *)c->rast_status)[0] & (2 | 4 | 8))) c->rast_avoid_n = ((volatile int *)c->rast_status)[1];
+            // answer them (origins that differ, rays behind the frame's plane, crowded cells, a full item
+            // table): such rays would pay the grid's four kernels AND the exhaustive completion in every
+            // call, where variant 3's chunked general-origin sweep is several times faster
+            if (c->rast_status && (((volatile int *)c->rast_status)[0] & (1 | 2 | 4 | 8))) c->rast_avoid_n = ((volatile int *)c->rast_status)[1];
             variant = (c->rast_avoid_n == (int)(N & 0x7FFFFFFF)) ? 3 : 4;
         }
     }
@@ -1498,7 +1589,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         PEDP_HIP_CHECK(hipHostGetDevicePointer((void **)&d_status, c->rast_status, 0));
         const size_t sz_head = align256(sizeof(unsigned) * (size_t)N), sz_nodes = align256(sizeof(float4) * (size_t)N);
         const size_t sz_part = align256(sizeof(uint4) * RAST_BBLOCKS);
-        st = c->ray_rast.reserve(512 + sz_part + sz_head + sz_nodes + sizeof(RastItem) * (size_t)RAST_ITEM_CAP);
+        st = c->ray_rast.reserve(512 + sz_part + sz_head + sz_nodes + sizeof(RastItem) * (size_t)RAST_ITEM_CAP + sizeof(unsigned) * RAST_FULL_CAP);
         if (st) return st;
         char *base = (char *)c->ray_rast.ptr;
         // two headers, used in turn: the last kernel of a cast puts the OTHER one back to its start values
@@ -1510,6 +1601,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         unsigned *head = (unsigned *)(base + 512 + sz_part);
         float4 *nodes = (float4 *)(base + 512 + sz_part + sz_head);
         RastItem *items = (RastItem *)(base + 512 + sz_part + sz_head + sz_nodes);
+        unsigned *full_list = (unsigned *)(items + RAST_ITEM_CAP);
         if (c->rast_hdr_ready != (void *)base) {  // new buffer, or a cast that did not reach its last kernel
             RastHdr h0;
             memset(&h0, 0, sizeof(h0));
@@ -1524,9 +1616,11 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
                            nodes, (const uint4 *)part);
         if (mesh->F > 0)
             hipLaunchKernelGGL(rast_tri_kernel, dim3((unsigned)((mesh->F + 255) / 256)), dim3(256), 0, c->stream, mesh->tri,
-                               mesh->F, rast, head, nodes, items, keys);
+                               mesh->F, rast, head, nodes, items, keys, full_list);
         hipLaunchKernelGGL(rast_item_kernel, dim3(RAST_ITEM_WAVES / 4), dim3(256), 0, c->stream, mesh->tri, rast, head, nodes,
                            items, keys);
+        hipLaunchKernelGGL(rast_full_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, d_rays, N,
+                           (const RastHdr *)rast, (const unsigned *)full_list, keys);
         PEDP_HIP_CHECK(hipGetLastError());
         PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
         c->ray_timed = true;
@@ -1663,6 +1757,39 @@ int pedp_raycast_last_variant(pedp_ctx_t c, int *variant, int *grid_status) {
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     *variant = c->ray_last_variant;
     *grid_status = (c->ray_last_variant == 4 && c->rast_status) ? ((volatile int *)c->rast_status)[0] : 0;
+    return PEDP_OK;
+}
+
+/* Diagnostics of the triangle-driven ray stage (tests/test_ray_gpu.py::test_grid_margin_*): run a variant-4 cast
+ * of the N host rays and return, for every triangle, [live, every-cell, fx0, fx1, fy0, fy1 (the bounding rectangle of
+ * its mapped corners in cell units, before widening), mx, my (the margins), x0, x1, y0, y1 (the cells visited)] and,
+ * for every ray, [kind (1: mapped), cell coordinate x, y (continuous)]; grid[0..1] = GX, GY, grid[2] = status. */
+int pedp_debug_rast_rects(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, float *tri_out, float *ray_out, int *grid) {
+    PEDP_REQUIRE(c && mesh && rays6 && tri_out && ray_out && grid && N > 0, "pedp_debug_rast_rects: bad argument");
+    const int keep = c->ray_variant;
+    c->ray_variant = 4;
+    std::vector<float> t((size_t)N);
+    std::vector<uint32_t> id((size_t)N);
+    const int rc = pedp_raycast(c, mesh, rays6, N, PEDP_HOST, t.data(), id.data(), nullptr);
+    c->ray_variant = keep;
+    if (rc) return rc;
+    // the header the cast used (the finalize kernel reset the OTHER one) and the rays it uploaded are still in place
+    const RastHdr *h = (const RastHdr *)((char *)c->ray_rast.ptr + 256 * ((c->rast_seq + 1) & 1));
+    float *d_tri = nullptr, *d_ray = nullptr;
+    PEDP_HIP_CHECK(hipMalloc((void **)&d_tri, sizeof(float) * 12 * (size_t)(mesh->F > 0 ? mesh->F : 1)));
+    PEDP_HIP_CHECK(hipMalloc((void **)&d_ray, sizeof(float) * 3 * (size_t)N));
+    if (mesh->F > 0)
+        hipLaunchKernelGGL(rast_debug_tri_kernel, dim3((unsigned)((mesh->F + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, mesh->F, h, d_tri);
+    hipLaunchKernelGGL(rast_debug_ray_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const float *)c->ray_in.ptr, N, h, d_ray);
+    RastHdr hh;
+    hipError_t e = hipMemcpyAsync(tri_out, d_tri, sizeof(float) * 12 * (size_t)mesh->F, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ray_out, d_ray, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&hh, h, sizeof(hh), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_tri);
+    (void)hipFree(d_ray);
+    PEDP_HIP_CHECK(e);
+    grid[0] = hh.GX; grid[1] = hh.GY; grid[2] = c->rast_status ? c->rast_status[0] : -1;
     return PEDP_OK;
 }
 

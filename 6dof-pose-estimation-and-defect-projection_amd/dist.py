@@ -112,16 +112,23 @@ class HipBackend:
                 _lib.comm_create(self.ctx, _lib.comm_unique_id(), 1, 0)
                 self.native = True
             return self.native
+        # Two steps, because ncclCommInitRank is itself a collective: a rank that failed BEFORE it (librccl does not
+        # load, a symbol is missing) would leave the others waiting inside it.  (1) every rank probes locally -- making
+        # a unique id needs the library and nothing else -- and the ranks agree on the outcome through one all-reduce;
+        # (2) only if every probe succeeded do all of them enter the communicator's creation.
         box, ok = [None], 1
+        try:
+            probe = _lib.comm_unique_id()
+        except _lib.PedpError:
+            probe, ok = b"", 0
         if rank == 0:
-            try:
-                box[0] = _lib.comm_unique_id()
-            except _lib.PedpError:
-                box[0] = b""
+            box[0] = probe
+        flag = self.torch.tensor([ok], dtype=self.torch.int32, device=f"cuda:{self.device}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            return False
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         try:
-            if not box[0]:
-                raise _lib.PedpError("rank 0 could not make an RCCL unique id")
             _lib.comm_create(self.ctx, box[0], world, rank)
         except _lib.PedpError:
             ok = 0

@@ -16,7 +16,7 @@ import logging
 import numpy as np
 
 from . import _lib
-from .geometry import LineSet, PointCloud, clone
+from .geometry import KDTreeSearchParamHybrid, LineSet, PointCloud, clone
 
 
 def heatmap_to_points(heatmap, threshold=0.5):
@@ -253,18 +253,29 @@ def calc_coordinates(depth_image, points, intrinsic):
 
 def align_to_surface(defect_points, target_pcd, offset=0.1, ctx=None):
     """Snap every defect point [x, y, z, ...] to its nearest model point and lift it by `offset`
-    along that point's normal (:413-460).  Returns (offset_points, aligned_points).  The
-    reference estimates normals when the model has none; that belongs to the preprocessing row
-    that is not built, so a model without normals is an error here."""
-    from .geometry import normals_of, points_of
+    along that point's normal (:413-460).  Returns (offset_points, aligned_points).  Like the
+    reference (:428-433) a model without normals gets them estimated first, in place, with
+    KDTreeSearchParamHybrid(radius=0.1, max_nn=30) (pedp_estimate_normals)."""
+    from .geometry import as_holder, normals_of, points_of
 
     if len(defect_points) == 0:
         return np.array([]), np.array([])
     pts = np.asarray(defect_points, dtype=np.float64).reshape(len(defect_points), -1)
     model, normals = points_of(target_pcd), normals_of(target_pcd)
     if normals is None:
-        raise RuntimeError("align_to_surface: the target cloud carries no normals; normal estimation "
-                           "(defect_projection.py:428-433) is not part of this build")
+        if isinstance(target_pcd, PointCloud):
+            target_pcd.estimate_normals(search_param=KDTreeSearchParamHybrid(radius=0.1, max_nn=30))   # on the GPU, in place
+            normals = normals_of(target_pcd)
+        else:   # an Open3D cloud: normals on the GPU from its points, written back like the reference's in-place call
+            holder = as_holder(target_pcd)
+            holder.estimate_normals(search_param=KDTreeSearchParamHybrid(radius=0.1, max_nn=30))
+            normals = np.asarray(holder.normals)
+            try:
+                import open3d as o3d
+
+                target_pcd.normals = o3d.utility.Vector3dVector(normals)
+            except ImportError:
+                pass
     ctx = ctx or _lib.default_context()
     idx, _ = _lib.nn(ctx, _lib.Cloud(ctx, pts[:, :3]), _lib.Cloud(ctx, model))
     aligned = model[idx]

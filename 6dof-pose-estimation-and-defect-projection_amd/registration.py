@@ -185,14 +185,15 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
 
     Every source point is paired with the target point whose feature is nearest.  An iteration draws
     ransac_n = 3 pairs, fits Umeyama without scaling and applies the checkers; a draw that passes is
-    VALIDATED like one ICP correspondence pass (fitness = share of the transformed source within
-    max_correspondence_distance of its nearest target point, inlier rmse); the best validated draw
-    wins (fitness, then rmse) and tightens the iteration budget:
-    k = log(1 - confidence) / log(1 - ratio^3), ratio = share of the PAIRS that are inliers under it.
-    Open3D walks the iterations under OpenMP with random_device-seeded engines; here they are taken
-    in order (the single-thread semantics), the draws are a counter-based function of (seed,
-    iteration), generated RANSAC_CHUNK at a time on the GPU, and the accepted ones are validated
-    RANSAC_BATCH at a time (results used in order, those behind a tightened budget dropped)."""
+    scored ON THE PAIRS, as 0.18's RegistrationRANSACBasedOnCorrespondence does
+    (EvaluateRANSACBasedOnCorrespondence): fitness = share of the pairs closer than
+    max_correspondence_distance under the draw, inlier rmse over those pairs; the best draw wins
+    (fitness, then rmse) and tightens the iteration budget, k = log(1 - confidence) / log(1 - fitness^3).
+    (Round 2 validated a draw with a nearest-neighbour pass over the whole source -- what Open3D did
+    before 0.13)  Open3D walks the iterations under OpenMP with random_device-seeded
+    engines; here they are taken in order (the single-thread semantics), the draws are a counter-based
+    function of (seed, iteration), generated RANSAC_CHUNK at a time on the GPU, and the accepted ones
+    are scored RANSAC_BATCH at a time (results used in order, those behind a tightened budget dropped)."""
     from . import cloud_ops
 
     est = estimation_method if estimation_method is not None else TransformationEstimationPointToPoint()
@@ -227,8 +228,9 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
         _ransac_seed[0] += 1
     else:
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-    evaluate = ICPConvergenceCriteria(max_iteration=0)
     budget, itr, validated = crit.max_iteration, 0, 0
+    paired = tgt_pts[corr]
+    r2 = max_correspondence_distance ** 2
     while itr < budget:
         count = min(RANSAC_CHUNK, budget - itr)
         ok, T = _lib.ransac_hypotheses(ctx, d_src, d_tgt, corr, seed, itr, count, edge, dist, angle)
@@ -238,15 +240,22 @@ def registration_ransac_based_on_feature_matching(source, target, source_feature
             batch = batch[itr + batch < budget]
             if len(batch) == 0:
                 break
-            results = registration_icp_batch(d_src, d_tgt, [max_correspondence_distance] * len(batch), T[batch], est, evaluate)
-            for k, res in zip(batch, results):
+            # EvaluateRANSACBasedOnCorrespondence for the whole batch: the PAIRS under each accepted draw
+            moved = np.einsum("bij,nj->bni", T[batch][:, :3, :3], src_pts) + T[batch][:, None, :3, 3]
+            d2 = ((moved - paired[None]) ** 2).sum(2)
+            good = d2 < r2
+            for row, k in enumerate(batch):
                 if itr + k >= budget:
                     break
                 validated += 1
-                if res.fitness > best.fitness or (res.fitness == best.fitness and res.inlier_rmse < best.inlier_rmse):
-                    best = res
-                    moved = src_pts @ T[k][:3, :3].T + T[k][:3, 3]
-                    ratio = float(np.mean(((moved - tgt_pts[corr]) ** 2).sum(1) < max_correspondence_distance ** 2))
+                n_good = int(good[row].sum())
+                fitness = n_good / len(corr)
+                rmse = float(np.sqrt(d2[row][good[row]].sum() / n_good)) if n_good else 0.0
+                if fitness > best.fitness or (fitness == best.fitness and rmse < best.inlier_rmse):   # IsBetterRANSACThan
+                    best = RegistrationResult(T[k].copy())
+                    best.fitness, best.inlier_rmse = fitness, rmse
+                    best.correspondence_set = np.column_stack([np.flatnonzero(good[row]), corr[good[row]]]).astype(np.int32)
+                    ratio = fitness                       # corres_inlier_ratio = |inlier pairs| / |pairs|
                     if 0.0 < ratio < 1.0 and crit.confidence < 1.0:
                         k_est = np.log(1.0 - crit.confidence) / np.log(1.0 - ratio ** ransac_n)
                         if k_est < budget:

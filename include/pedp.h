@@ -91,6 +91,12 @@ int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
  * answered the cast (grid_status 0) or the exhaustive sweep had to (bit 0 origins differ, 1 a ray
  * outside the half space, 2 a crowded cell, 3 item table full).  Synchronises the stream. */
 int pedp_raycast_last_variant(pedp_ctx_t ctx, int *variant, int *grid_status);
+/* Diagnostics of the triangle-driven ray stage, for the tests that MEASURE its margin: runs a variant-4 cast of the N
+ * host rays; tri_out = F x 12 floats per triangle [live, every-cell, fx0, fx1, fy0, fy1: the bounding rectangle of its
+ * mapped corners in cell units before widening, mx, my: the margins, x0, x1, y0, y1: the cells visited]; ray_out = N x 3
+ * [kind (1 = mapped), continuous cell coordinate x, y]; grid = [GX, GY, grid_status]. */
+int pedp_debug_rast_rects(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N, float *tri_out, float *ray_out,
+                          int *grid);
 
 /* Milliseconds the last pedp_raycast spent in its sweep stage -- for variant 4 the bounds, chain, triangle
  * and tile kernels, for variant 3 the direction binning, cull masks, segment table and the sweep itself (HIP events on the context's stream,

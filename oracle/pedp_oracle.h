@@ -47,6 +47,8 @@ int pedp_oracle_raycast(const float *tri9, int64_t F, const float *rays6, int64_
 /* Same result through a bounding-volume hierarchy (CPU baseline of the same
  * algorithmic class as Embree; build is part of the call like in the reference,
  * defect_projection.py:253-254).  build_seconds / cast_seconds may be NULL. */
+/* All accepted (ray, triangle) pairs (small cases: N x F tests). */
+int64_t pedp_oracle_accepted_pairs(const float *tri9, int64_t F, const float *rays6, int64_t N, int32_t *pairs, int64_t capacity);
 int pedp_oracle_raycast_bvh(const float *tri9, int64_t F, const float *rays6, int64_t N,
                             float *t_hit, uint32_t *prim_id, float *uv, int nthreads,
                             double *build_seconds, double *cast_seconds);

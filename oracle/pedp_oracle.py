@@ -79,6 +79,21 @@ def raycast(verts, tris, rays6, nthreads=0, bvh=False, timings=None):
     return {"t_hit": t, "primitive_ids": ids, "primitive_uvs": uv}
 
 
+def accepted_pairs(verts, tris, rays6):
+    """Every (ray, triangle) pair the oracle's test accepts: int32 [n, 2] in (ray, triangle) order."""
+    tri9 = tri_setup(verts, tris)
+    r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
+    fn = lib().pedp_oracle_accepted_pairs
+    fn.restype = C.c_int64
+    cap = max(4 * len(r), 1024)
+    while True:
+        out = np.empty((cap, 2), np.int32)
+        n = fn(_p(tri9), C.c_int64(len(tri9)), _p(r), C.c_int64(len(r)), _p(out), C.c_int64(cap))
+        if n <= cap:
+            return out[:n]
+        cap = int(n)
+
+
 def mt_test(o, d, tri9):
     o = np.ascontiguousarray(o, np.float32)
     d = np.ascontiguousarray(d, np.float32)

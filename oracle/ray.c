@@ -129,6 +129,22 @@ int pedp_oracle_raycast(const float *tri9, int64_t F, const float *rays6, int64_
     return 0;
 }
 
+/* Every (ray, triangle) pair the test accepts, not only the closest hit per ray: pairs[2 k] = ray, pairs[2 k + 1] =
+ * triangle, in (ray, triangle) order; returns the count (pairs beyond `capacity` are counted, not stored).  The
+ * margin of the GPU's triangle-driven ray stage is measured against this set (tests/test_ray_gpu.py). */
+int64_t pedp_oracle_accepted_pairs(const float *tri9, int64_t F, const float *rays6, int64_t N, int32_t *pairs, int64_t capacity) {
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t f = 0; f < F; ++f) {
+            float t, u, v;
+            if (pedp_oracle_mt_test(rays6 + 6 * i, rays6 + 6 * i + 3, tri9 + PEDP_ORACLE_TRI * f, &t, &u, &v)) {
+                if (n < capacity) { pairs[2 * n] = (int32_t)i; pairs[2 * n + 1] = (int32_t)f; }
+                ++n;
+            }
+        }
+    return n;
+}
+
 /* ------------------------------------------------------------------ BVH baseline
  * Median-split BVH over triangle bounds, leaves of <= 4 triangles, ordered
  * stack traversal.  Leaves run the SAME pedp_oracle_mt_test and the same tie rule,

@@ -26,14 +26,19 @@ def test_bench_100k_rays_bit_exact_all_variants(ctx, oracle, frame100k):
     ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
     assert np.isfinite(ref["t_hit"]).sum() == 35863            # hit count of this frame (oracle)
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
-    for variant in (3, 1):                                       # culled, exhaustive
+    for variant in (4, 3, 1):                                    # triangle-driven grid (the default), cone-culled, exhaustive
         _lib.raycast_configure(ctx, 0, variant)
         try:
-            got = mesh.cast_rays(f.rays6)
+            got = mesh.cast_rays(f.rays6)                        # natural ray order, with uv
+            ran = _lib.raycast_last_variant(ctx)
         finally:
             _lib.raycast_configure(ctx, 0, 0)
+        assert ran[0] == variant and (variant != 4 or ran[1] == 0)   # the GRID answered, not the exhaustive kernel behind it
         _same(got, ref)
         assert np.array_equal(got["primitive_uvs"].view(np.uint32), ref["primitive_uvs"].view(np.uint32))
+    auto = mesh.cast_rays(f.rays6)
+    assert _lib.raycast_last_variant(ctx) == (4, 0)              # ... and it is what a plain call of this frame takes
+    _same(auto, ref)
     # permutation invariance: shuffling the rays shuffles the answers, nothing else
     perm = np.random.default_rng(0).permutation(f.n_rays)
     shuffled = mesh.cast_rays(f.rays6[perm], want_uv=False)
@@ -89,7 +94,9 @@ def test_bench_1m_config_rays(ctx, oracle):
     ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
     got = mesh.cast_rays(f.rays6)
+    assert _lib.raycast_last_variant(ctx) == (4, 0)              # the triangle-driven grid answered all 921,600 rays itself
     _same(got, ref)
+    assert np.array_equal(got["primitive_uvs"].view(np.uint32), ref["primitive_uvs"].view(np.uint32))
     assert np.isfinite(ref["t_hit"]).sum() > 50_000
 
 

@@ -153,8 +153,18 @@ def test_align_to_surface_matches_oracle_nn(ctx, oracle):
     assert np.array_equal(off, f.model_points[idx] + f.normals[idx] * 0.25)
     e_off, e_al = compat.align_to_surface(np.zeros((0, 4)), model)
     assert e_off.size == 0 and e_al.size == 0
-    with pytest.raises(RuntimeError, match="normals"):
-        compat.align_to_surface(defects, compat.PointCloud(f.model_points))
+    # a model without normals gets them estimated first, in place, with radius 0.1 / max_nn 30 (:428-433) -- on this
+    # model (points ~1 mm apart) every neighbourhood holds the point alone, so Open3D's rule gives (0, 0, 1)
+    bare = compat.PointCloud(f.model_points)
+    off2, al2 = compat.align_to_surface(defects, bare, offset=0.25)
+    ref_n = oracle.estimate_normals(f.model_points, 0.1, 30)
+    assert bare.has_normals() and np.array_equal(bare.normals, ref_n)
+    assert np.array_equal(al2, aligned) and np.array_equal(off2, f.model_points[idx] + ref_n[idx] * 0.25)
+    # ... and with a radius that reaches the neighbours the estimated normals are real ones
+    dense = compat.PointCloud(f.model_points * 0.02)                        # the model in a unit where 0.1 spans neighbours
+    compat.align_to_surface(defects * 0.02, dense, offset=0.01)
+    ref_d = oracle.estimate_normals(f.model_points * 0.02, 0.1, 30)
+    assert np.abs(dense.normals - ref_d).max() < 1e-9 and (np.abs(dense.normals[:, 2]) < 0.999).mean() > 0.5   # real normals, not the (0, 0, 1) default
 
 
 def test_project_heatmap_device_memory(ctx, oracle):

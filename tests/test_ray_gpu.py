@@ -386,3 +386,125 @@ def test_grid_sweep_fuzz_against_exhaustive(ctx, seed):
     got = _grid_cast(ctx, mesh, rays, 0)
     assert np.isfinite(ref["t_hit"]).mean() > 0.05
     _same(got, ref)
+
+
+# ---- the margin of the triangle-driven ray stage, MEASURED against everything the oracle's test accepts
+def _margin_slack(ctx, oracle, verts, tris, rays):
+    """For every (ray, triangle) pair the oracle accepts: the ray's continuous cell coordinate lies inside the
+    triangle's un-widened rectangle grown by HALF the margin the kernel applies (slack >= 2), and inside the
+    cells the kernel visits.  Returns (largest used share of the margin, pairs checked, pairs with a bounded image)."""
+    from pedp_hip import _lib
+
+    mesh = _lib.Mesh(ctx, verts, tris)
+    tri, ray, (GX, GY, status) = _lib.debug_rast_rects(ctx, mesh, rays)
+    assert status == 0, f"the grid did not answer (status {status})"
+    pairs = oracle.accepted_pairs(verts, tris, rays)
+    i, f = pairs[:, 0], pairs[:, 1]
+    t = tri[f]
+    assert (t[:, 0] == 1).all(), "an accepted pair's triangle was dropped"
+    assert (ray[i, 0] == 1).all()
+    x, y = ray[i, 1].astype(np.float64), ray[i, 2].astype(np.float64)
+    # the cells visited hold the ray's cell (bounded image or not)
+    cx, cy = np.clip(np.floor(x), 0, GX - 1), np.clip(np.floor(y), 0, GY - 1)
+    assert ((t[:, 8] <= cx) & (cx <= t[:, 9]) & (t[:, 10] <= cy) & (cy <= t[:, 11])).all()
+    b = t[:, 1] == 0                                   # bounded image: rectangle + margin
+    ex = np.maximum(np.maximum(t[b, 2] - x[b], x[b] - t[b, 3]), 0.0)
+    ey = np.maximum(np.maximum(t[b, 4] - y[b], y[b] - t[b, 5]), 0.0)
+    used = np.maximum(ex / t[b, 6], ey / t[b, 7]) if b.any() else np.zeros(0)
+    worst = float(used.max()) if len(used) else 0.0
+    assert worst <= 0.5, f"an accepted ray uses {worst:.3f} of the margin: less than a factor two is left"
+    return worst, len(pairs), int(b.sum())
+
+
+def _pinhole(rng, w, h, fov_scale, origin=None, tilt=None):
+    fx = fov_scale * w
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    d = np.stack([(u.ravel() - w / 2 + 0.37) / fx, (v.ravel() - h / 2 - 0.21) / fx, np.ones(w * h)], axis=1)
+    if tilt is not None:
+        d = d @ tilt.T
+    o = np.zeros(3) if origin is None else origin
+    return np.hstack([np.tile(o, (w * h, 1)), d]).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grid_margin_on_triangle_soups(ctx, oracle, seed):
+    """The fuzz soups of the sweep test (sizes over four decades, slivers, triangles across the camera plane) at a
+    size the oracle can test pair by pair: every accepted pair is inside its rectangle with a factor >= 2 to spare."""
+    rng = np.random.default_rng(4000 + seed)
+    n_tri = 700
+    centre = rng.normal(0, 1, 3) * [150.0, 150.0, 0.0] + [0.0, 0.0, rng.uniform(300, 900)]
+    c = centre + rng.normal(0, 1, (n_tri, 3)) * rng.uniform(30, 300)
+    size = 10.0 ** rng.uniform(-1.5, 2.5, n_tri)
+    a = c + rng.normal(0, 1, (n_tri, 3)) * size[:, None]
+    b = c + rng.normal(0, 1, (n_tri, 3)) * size[:, None]
+    sl = rng.random(n_tri) < 0.2                                     # slivers, the sharp corner anywhere
+    b[sl] = c[sl] + (a[sl] - c[sl]) * rng.uniform(-0.2, 1.2, (int(sl.sum()), 1)) + rng.normal(0, 1e-4, (int(sl.sum()), 3))
+    verts = np.stack([c, a, b], axis=1).reshape(-1, 3)
+    verts[:12] = rng.normal(0, 1, (12, 3)) * [300.0, 300.0, 150.0]   # through / behind the camera plane
+    tris = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+    tilt = np.linalg.qr(rng.normal(size=(3, 3)))[0] if seed % 3 == 2 else None
+    origin = rng.normal(0, 30, 3) if seed % 2 else None
+    if tilt is not None:
+        verts = verts @ tilt.T
+    rays = _pinhole(rng, 168, 110, rng.uniform(0.35, 1.6), origin, tilt)     # up to ~55 degrees off axis
+    worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts.astype(np.float32), tris, rays)
+    print(f"soup {seed}: {n_pairs} accepted pairs, {n_bounded} with a bounded image, largest used share of the margin {worst:.3f}")
+    assert n_pairs > 300 and n_bounded > 0.5 * n_pairs
+
+
+def test_grid_margin_on_adversarial_triangles(ctx, oracle):
+    """What the margin's formula is about: triangles seen almost edge-on (the origin a hair off their plane), needles
+    whose sharp corner is NOT the record's first vertex, slivers of the size of the view, big triangles whose first
+    vertex is far away while the rays meet them close by, a wide-angle camera.  Every accepted pair inside with >= 2x."""
+    rng = np.random.default_rng(77)
+    tri_list = []
+
+    def add(p0, p1, p2):
+        tri_list.append(np.array([p0, p1, p2], np.float64))
+
+    for k in range(150):                                            # edge-on: planes through a point a hair off the origin
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        off = 10.0 ** rng.uniform(-7, -2) * rng.choice([-1, 1])
+        base = np.array([rng.uniform(-200, 200), rng.uniform(-150, 150), rng.uniform(300, 700)])
+        e = np.cross(n, rng.normal(size=3)); e /= np.linalg.norm(e)
+        g = np.cross(n, e)
+        q0 = base - n * (base @ n) + n * off * np.linalg.norm(base)         # the plane passes the origin at `off` radians
+        s = rng.uniform(5, 200)
+        add(q0, q0 + e * s, q0 + g * s * rng.uniform(0.2, 1.0))
+    for k in range(150):                                            # needles: long first edge, tiny second, sharp corner at v1 / v2
+        p0 = np.array([rng.uniform(-250, 250), rng.uniform(-180, 180), rng.uniform(250, 800)])
+        d1 = rng.normal(size=3); d1 /= np.linalg.norm(d1)
+        d2 = np.cross(d1, rng.normal(size=3)); d2 /= np.linalg.norm(d2)
+        L, w = rng.uniform(50, 600), 10.0 ** rng.uniform(-4, -0.5)
+        add(p0, p0 + d1 * L, p0 + d2 * w) if k % 2 else add(p0, p0 + d2 * w, p0 + d1 * L)
+    for k in range(60):                                             # view-sized slivers across the frame
+        z = rng.uniform(300, 600)
+        y = rng.uniform(-200, 200)
+        add([-600, y, z], [600, y + rng.uniform(-30, 30), z + rng.uniform(-50, 50)], [0, y + 10.0 ** rng.uniform(-4, -1), z])
+    for k in range(60):                                             # floors: first vertex far away, hit close by
+        h = rng.uniform(20, 150)
+        far = np.array([rng.uniform(-3e4, 3e4), h, rng.uniform(2e4, 9e4)])
+        add(far, [-800, h + rng.uniform(-5, 5), 60], [900, h + rng.uniform(-5, 5), 80])
+    verts = np.concatenate(tri_list).astype(np.float32)
+    tris = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+    for fov, origin in ((0.9, None), (0.3, None), (0.45, rng.normal(0, 20, 3))):   # 0.3: +-59 degrees across
+        rays = _pinhole(rng, 168, 110, fov, origin)
+        worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts, tris, rays)
+        print(f"adversarial, fov scale {fov}: {n_pairs} accepted pairs, {n_bounded} bounded, largest used share of the margin {worst:.3f}")
+        assert n_pairs > 300
+
+
+def test_grid_margin_degenerate_records_cost_nothing(ctx, oracle):
+    """Zero-area triangles (m == 0 exactly: det is 0 for every ray) are dropped, not tested against every cell."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    v = np.concatenate([f.verts_posed, np.repeat(f.verts_posed[:1], 3, 0)])
+    n = len(f.verts_posed)
+    dead = np.array([[n, n + 1, n + 2]] * 50 + [[5, 5, 9]] * 50, np.uint32)      # coincident corners, repeated index
+    tris = np.concatenate([f.tris, dead])
+    mesh = _lib.Mesh(ctx, v, tris)
+    tri, ray, (GX, GY, status) = _lib.debug_rast_rects(ctx, mesh, f.rays6)
+    assert status == 0 and (tri[len(f.tris):, 0] == 0).all()
+    got = _grid_cast(ctx, mesh, f.rays6, 0)
+    _same(got, oracle.raycast(v, tris, f.rays6, bvh=True))
