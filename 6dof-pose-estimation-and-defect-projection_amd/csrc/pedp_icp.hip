@@ -139,6 +139,7 @@ struct IcpState {
     // tickets and sign-offs are counted on from launch to launch (nothing to reset at the end of a pass): what the
     // counters read when this launch began
     unsigned ticket_base, idle_base;
+    double T_init[16];         // the start transformation: slot 0 of the update history (arrives with the state, no copy of its own)
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -1977,7 +1978,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                         const double lim = cr * rscale + reach + 1e-9 * (fabs(tx) + fabs(ty) + fabs(tz) + 1.0);
                         visit |= !(cr < 0.0) && !(ex * ex + ey * ey + ez * ez > lim * lim);  // (also when anything is NaN)
                     }
-                    withdraw = !visit && was_live;
+                    withdraw = !visit && (was_live || pass == 0);   // pass 0: every chunk's correspondences start at "none"
                 }
                 todo = __builtin_amdgcn_ballot_w64(visit);
                 unsigned long long wd = __builtin_amdgcn_ballot_w64(withdraw);
@@ -2016,7 +2017,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 pi = a.perm[k];
                 if (rebuild) {
                     x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
-                    for (int q = 0; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                    xform(st->T_init, x, y, z);
+                    for (int q = 1; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
                     // a chunk that was live in the pass before has that pass's neighbours (every point of a live
                     // chunk gets one, or NaN): the search radii need not start from r again
                     if ((a.live[a.n_lw + (chunk >> 6)] >> (chunk & 63)) & 1ull)
@@ -2550,9 +2552,9 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
         o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad * 2);  // ever reads what a faster wave of the same pass has rewritten
         o_hist = take(sizeof(double) * 16 * (size_t)iter_capacity(max_iter));
         o_cpart = take(sizeof(double) * PSTRIDE * (size_t)w.blocks_cap);
+        o_ticket = take(17 * 128);  // the ticket and the sixteen sign-off counters, a line each; the live masks right behind (one memset)
         o_live = take(sizeof(unsigned long long) * 2 * (size_t)w.n_lw);  // live mask + the mask before the last rebuild
         o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
-        o_ticket = take(17 * 128);  // the ticket and the sixteen sign-off counters, a line each
     }
     off = align_up(off, 4096);
     w.pose_stride = off;  // a batch lays `poses` such blocks one behind the other
@@ -2851,7 +2853,7 @@ int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const 
 // icp_enqueue; the same block receives the final state)
 void icp_fill_state(IcpState *dst, const TargetPrep &tp, const double init[16], const pedp_icp_params *prm, int64_t Ns) {
     IcpState h{};
-    for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; }
+    for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; h.T_init[k] = init[k]; }
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
     h.rebuild = 1;  // fused pass: pass 0 builds the live chunk set from the whole scene
     const double r = prm->max_correspondence_distance, margin = fused_margin(r);
@@ -2894,11 +2896,10 @@ int icp_enqueue(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const Ta
     const bool fused = w.fused && !degenerate;
     double bc[3] = {0, 0, 0};
     if (fused) {
-        // history slot 0 = the start transformation; the live mask starts empty
-        PEDP_HIP_CHECK(hipMemcpyAsync(w.hist, hp->T, sizeof(double) * 16, hipMemcpyHostToDevice, x->stream));
-        PEDP_HIP_CHECK(hipMemsetAsync(w.live, 0, sizeof(unsigned long long) * 2 * (size_t)w.n_lw, x->stream));
-        PEDP_HIP_CHECK(hipMemsetAsync(w.idx, 0xFF, sizeof(int32_t) * (size_t)Ns, x->stream));  // chunks a rebuild pass never touches have no correspondences
-        PEDP_HIP_CHECK(hipMemsetAsync(w.ticket, 0, 17 * 128, x->stream));
+        // tickets, sign-off counters and both live masks start at zero: one memset (they lie one behind the other); the
+        // start transformation -- slot 0 of the history -- arrives inside the state; pass 0 itself writes "no
+        // correspondence" for every chunk it does not visit
+        PEDP_HIP_CHECK(hipMemsetAsync(w.ticket, 0, (size_t)((char *)w.live - (char *)w.ticket) + sizeof(unsigned long long) * 2 * (size_t)w.n_lw, x->stream));
         for (int k = 0; k < 3; ++k) bc[k] = 0.5 * (tp.lo[k] + tp.hi[k]);
     }
     if (job.timed_pass != -1) { x->nn_pairs = 0; x->nn_span_launches = 1; }
@@ -3127,14 +3128,11 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
                 up[k].done = 1;  // an empty seat of the group: every kernel returns at once
             }
         }
-        // start states, history slot 0 (each pose's start transformation), empty live masks
+        // start states (each carries its start transformation: slot 0 of the history); tickets and live masks at zero
         PEDP_HIP_CHECK(hipMemcpy2DAsync(w.st, w.pose_stride, up, sizeof(IcpState), sizeof(IcpState), (size_t)G,
                                         hipMemcpyHostToDevice, c->stream));
-        PEDP_HIP_CHECK(hipMemcpy2DAsync(w.hist, w.pose_stride, up[0].T, sizeof(IcpState), sizeof(double) * 16, (size_t)G,
-                                        hipMemcpyHostToDevice, c->stream));
-        PEDP_HIP_CHECK(hipMemset2DAsync(w.live, w.pose_stride, 0, sizeof(unsigned long long) * 2 * (size_t)w.n_lw, (size_t)G, c->stream));
-        PEDP_HIP_CHECK(hipMemset2DAsync(w.idx, w.pose_stride, 0xFF, sizeof(int32_t) * (size_t)job.Ns, (size_t)G, c->stream));
-        PEDP_HIP_CHECK(hipMemset2DAsync(w.ticket, w.pose_stride, 0, 17 * 128, (size_t)G, c->stream));
+        PEDP_HIP_CHECK(hipMemset2DAsync(w.ticket, w.pose_stride, 0, (size_t)((char *)w.live - (char *)w.ticket) + sizeof(unsigned long long) * 2 * (size_t)w.n_lw,
+                                        (size_t)G, c->stream));
         bool finished = false;
         for (int guard = 0; guard < (1 << 20) && !finished; ++guard) {
             PEDP_HIP_CHECK(hipGraphLaunch(c->icp_bgraph[slot], c->stream));

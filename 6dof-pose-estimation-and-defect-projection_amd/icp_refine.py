@@ -222,7 +222,7 @@ def preprocess_source(pcd, background, param, i=0):
 
 _FORCE_STEPS = False   # tests: preprocess_source through the single operations
 
-Z_LOOKAHEAD = 3   # probes tried ahead per batch: 2^3 - 1 = 7 start poses share the launches of one
+Z_LOOKAHEAD = 3   # probes tried ahead per batch: 2^3 - 1 = 7 start poses share the launches of one (4: 15 poses per batch measured slower)
 
 
 def _z_move(offset, step, heading, better, max_adjustment):

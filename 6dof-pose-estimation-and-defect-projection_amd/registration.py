@@ -16,7 +16,7 @@ Open3D's (a target without normals under point-to-plane).
 import numpy as np
 
 from . import _lib
-from .geometry import RegistrationResult, normals_of, points_of
+from .geometry import PointCloud, RegistrationResult, normals_of, points_of
 
 
 class TransformationEstimationPointToPlane:
@@ -57,13 +57,36 @@ def get_rotation_matrix_from_xyz(rotation):
     ])
 
 
+def _fingerprint(pts, nrm):
+    """Cheap identity of a holder's arrays: the arrays themselves (id, address, shape) and 32 sampled rows, so that a
+    holder whose points were replaced (transform assigns new arrays) or rewritten in place is uploaded again."""
+    step = max(len(pts) // 32, 1)
+    key = (id(pts), pts.ctypes.data, pts.shape, pts[::step].tobytes())
+    if nrm is not None:
+        key += (id(nrm), nrm.ctypes.data, nrm[::step].tobytes())
+    return key
+
+
 def upload(cloud, ctx=None):
     """Device copy of a PointCloud-like object; pass the returned handle to registration_icp
-    when the same cloud is registered many times (improve_result does ~50 calls per frame)."""
+    when the same cloud is registered many times (improve_result does ~50 calls per frame).
+    A PointCloud holder keeps its device copy: the model cloud of a camera loop -- the same holder in every frame's
+    z search and restarts -- is uploaded, ordered and packed once, not twice per frame."""
     if isinstance(cloud, _lib.Cloud):
         return cloud
     ctx = ctx or _lib.default_context()
-    return _lib.Cloud(ctx, points_of(cloud), normals_of(cloud))
+    pts, nrm = points_of(cloud), normals_of(cloud)
+    if isinstance(cloud, PointCloud) and len(pts):
+        p64 = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        n64 = None if nrm is None else np.ascontiguousarray(nrm, np.float64).reshape(-1, 3)
+        key = (id(ctx),) + _fingerprint(p64, n64)
+        kept = getattr(cloud, "_device_copy", None)
+        if kept is not None and kept[0] == key:
+            return kept[1]
+        handle = _lib.Cloud(ctx, p64, n64)
+        cloud._device_copy = (key, handle)
+        return handle
+    return _lib.Cloud(ctx, pts, nrm)
 
 
 def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None,

@@ -384,6 +384,15 @@ def test_committed_bench_line_follows_the_contract():
         assert 0 < r["frac"] <= 1.0, f"{key}: a fraction above 1 credits flops the kernel does not execute"
         # the kernel as it runs in the region it is quoted for
         assert r["kernel_ms"] * r["launches_per_step"] <= r["region_ms_per_step"] * 1.001, key
+    if order(newest)[0] >= 3:   # round 3: the new frame on the clock, which ray stage answered, its own roofline entry
+        assert d["ray_variant"] == 4 and d["ray_grid_status"] == 0
+        r = d["roofline_ray_stage"]
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
+        assert r["kernel_ms"] * r["launches_per_step"] <= r["region_ms_per_step"] * 1.001
+        ff, fc = d["fresh_frame"], d["frame_chain"]
+        assert ff["ms_per_frame"] > 0 and ff["ray_variant"] == 4 and ff["ray_grid_status"] == 0 and ff["pose_error_vs_gt"] < 0.05
+        assert fc["ms_per_frame"] > 0 and fc["frames"] >= 3 and fc["pose_error_vs_gt"] < 0.05 and fc["projected_hits"] > 10000
+        assert set(fc["stage_ms"]) >= {"depth filters + back-projection", "refine_pose_with_icp", "posed mesh + projection"}
     assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["region_ms_per_step"] == d["ms_per_step"]
     assert d["roofline_ray_sweep"]["north_star_hbm_target_met"] in (True, False)
     assert d["exhaustive"]["ms_per_step"] == d["roofline_ray_sweep"]["region_ms_per_step"]

@@ -7,7 +7,7 @@ as measured (width uncalibrated) and flagged.  WRITE_SIZE is taken as is."""
 import collections, csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def load(name):
@@ -38,7 +38,14 @@ KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector 
     ("ray_sweep_rpl_kernel<true>", "ray_sweep_rpl_kernel", False),
     ("ray_sweep_seg_kernel", "ray_sweep_seg_kernel", False),
     ("ray_cull_mask_kernel", "ray_cull_mask_kernel", True),
+    ("rast_bounds_kernel", "rast_bounds_kernel", True),
+    ("rast_insert_kernel", "rast_insert_kernel", True),
+    ("rast_tri_kernel", "rast_tri_kernel", True),
+    ("rast_item_kernel", "rast_item_kernel", True),
+    ("rast_full_kernel", "rast_full_kernel", True),
+    ("ray_finalize_kernel", "ray_finalize_kernel", True),
     ("erode_kernel<2>", "erode_kernel", True),
+    ("bilateral_kernel<2>", "bilateral_kernel", True),
     ("xyzmap_kernel", "xyzmap_kernel", True),
 )
 out = {}
@@ -62,5 +69,20 @@ for key, name, stream in KERNELS:
         rec["mfma_util"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         rec["mfma_flop"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
     out[name] = rec
+# the triangle-driven ray stage as a whole: its kernels of one cast summed (ray_finalize_kernel is shared with the other
+# variants: its mean over all casts is taken)
+parts = [out[k] for k in ("rast_bounds_kernel", "rast_insert_kernel", "rast_tri_kernel", "rast_item_kernel", "rast_full_kernel",
+                          "ray_finalize_kernel") if k in out]
+if parts:
+    agg = {"hbm_bytes_per_cast": sum(p["hbm_bytes_per_launch"] for p in parts),
+           "fetch_bytes_corrected": sum(p["fetch_bytes_corrected"] for p in parts), "write_bytes": sum(p["write_bytes"] for p in parts)}
+    for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+        if all(c in p for p in parts):
+            agg[c] = sum(p[c] for p in parts)
+    if agg.get("SQ_WAVE_CYCLES"):
+        agg["wait_share_of_wave_cycles"] = agg["SQ_WAIT_ANY"] / agg["SQ_WAVE_CYCLES"]
+    agg["per_kernel_wait_share"] = {k: out[k]["SQ_WAIT_ANY"] / out[k]["SQ_WAVE_CYCLES"] for k in out
+                                    if k.startswith("rast_") and out[k].get("SQ_WAVE_CYCLES")}
+    out["ray_stage_rast"] = agg
 json.dump(out, open(os.path.join(P, f"{RND}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
