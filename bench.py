@@ -413,8 +413,11 @@ def run(args):
         pairs_pass = pairs_swept / n_pass
         sweep_tflops = FLOP_PER_PAIR * pairs_pass / (sweep_ms * 1e-3) / 1e12
         par = {"single": "one GPU; ray stage and ICP of a step overlap on two HIP streams",
-               "shard": f"one frame sharded over {world} GPUs: contiguous ray blocks + all-gather of hit records, scene "
-                        f"shards + one 29-double all-reduce per pass ({'library-issued RCCL' if native else 'torch.distributed'})",
+               "shard": f"one frame sharded over {world} GPUs: contiguous ray blocks + all-gather of hit records "
+                        f"({'library-issued RCCL' if native else 'torch.distributed'}); the frame's one registration "
+                        + ("replicated on every rank (a camera-size scene: passes too short to pay for an all-reduce each; the "
+                           "scene-sharded variant is timed under icp_scene_sharded, the pose batch under icp_batched)"
+                           if replicate_icp else "with scene shards + one 29-double all-reduce per pass"),
                "replica": f"{world} GPUs, each its own whole frame, no collective"}[mode]
         frames_per_step = world if mode == "replica" else 1
         out = {
