@@ -99,7 +99,8 @@ __global__ void grid_cell_kernel(const double *__restrict__ pts, int64_t N, Grid
     val[i] = (int)i;
 }
 
-// sorted by cell: where each cell's run starts and ends, and the points gathered in that order
+// sorted by cell: where each cell's run starts and ends (empty cells keep the 0 / 0 they were cleared to), and the
+// points gathered in that order
 __global__ void grid_ranges_kernel(const unsigned *__restrict__ cell_sorted, const int *__restrict__ idx_sorted,
                                    const double *__restrict__ pts, int64_t N, int *__restrict__ cell_start,
                                    int *__restrict__ cell_end, double *__restrict__ sp) {
@@ -110,6 +111,20 @@ __global__ void grid_ranges_kernel(const unsigned *__restrict__ cell_sorted, con
     if (j == N - 1 || cell_sorted[j + 1] != c) cell_end[c] = (int)j + 1;
     const int64_t i = idx_sorted[j];
     sp[3 * j] = pts[3 * i]; sp[3 * j + 1] = pts[3 * i + 1]; sp[3 * j + 2] = pts[3 * i + 2];
+}
+
+// The cells x0 .. x1 of one x row have consecutive ids, so their points are ONE run of the cell-sorted order: from the
+// first non-empty cell's start to the last one's end (rs = re = 0: the row is empty).  The loads are independent.
+__device__ __forceinline__ void row_run(const int *__restrict__ cell_start, const int *__restrict__ cell_end, int base, int x0, int x1,
+                                        int &rs, int &re) {
+    rs = re = 0;
+    for (int x = x0; x <= x1; ++x) {
+        const int s = cell_start[base + x], e = cell_end[base + x];
+        if (e > s) {
+            if (re == 0) rs = s;
+            re = e;
+        }
+    }
 }
 
 // calls f(q) for every sorted position q whose point lies in one of the 27 cells around p
@@ -127,24 +142,48 @@ __device__ __forceinline__ void for_neighbours(const Grid &g, const double *p, c
 }
 
 // ------------------------------------------------------------------ DBSCAN
-// The two passes over a point's neighbourhood run a WAVE per point: the 64 lanes take the points of the 27
-// cells 64 at a time (a thread walking them alone is one long chain of dependent loads: 6.9 k points took
-// 117 us for the counts and 950 us for the unions).
-template <class F>
-__device__ __forceinline__ void for_neighbours_wave(const Grid &g, const double *p, const int *__restrict__ cell_start,
-                                                    const int *__restrict__ cell_end, int lane, F f) {
-    const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
-              cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dim[2] - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dim[1] - 1); ++y)
-            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dim[0] - 1); ++x) {
-                const int c = x + g.dim[0] * (y + g.dim[1] * z);
-                const int e = cell_end[c];
-                for (int q0 = cell_start[c]; q0 < e; q0 += 64) f(q0 + lane, q0 + lane < e);  // wave-uniform trip count
-            }
+// The grid cell is eps / sqrt(3) less a hair: two points of one cell are closer than eps, so the core points of a
+// cell form a clique -- they are one component without looking -- and a cell pair needs ONE edge between two of
+// their core points to be united.  Points within eps lie at most DB_R = 2 cells apart per axis: the neighbourhood
+// is 25 x rows of 5 cells, each row one run of the cell-sorted points (row_run), so lanes 0..24 of a
+// wave fetch the 25 runs at once and the wave takes the non-empty ones 64 points at a time.  (With cells of eps
+// every core point united itself with every core neighbour: 350 k finds and compare-and-swaps for 9 k points,
+// 340 us; cells as cliques leave about a tenth of that.)
+// A cloud whose extent over eps is beyond the grid's cell budget gets cells of eps or more (make_grid doubles them until
+// they fit): no cliques there, 9 rows of 3 cells, and every core point unites itself with every core neighbour
+// (CLIQUE = false below).
+struct DbCell { int x, y, z; };
+__device__ __forceinline__ DbCell db_cell(const Grid &g, const double *p) {
+    return {grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
+            grid_axis(p[2], g.lo[2], g.cell, g.dim[2])};
+}
+// the run of row `r` (0 .. (2R+1)^2 - 1) around cell c: sorted positions rs .. re
+template <int DB_R>
+__device__ __forceinline__ void db_row(const Grid &g, const DbCell &c, int r, const int *__restrict__ cell_start,
+                                       const int *__restrict__ cell_end, int &rs, int &re) {
+    constexpr int DB_SIDE = 2 * DB_R + 1;
+    const int y = c.y + r % DB_SIDE - DB_R, z = c.z + r / DB_SIDE - DB_R;
+    rs = re = 0;
+    if (r < DB_SIDE * DB_SIDE && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+        row_run(cell_start, cell_end, g.dim[0] * (y + g.dim[1] * z), max(c.x - DB_R, 0), min(c.x + DB_R, g.dim[0] - 1), rs, re);
+    }
+}
+template <int DB_R, class F>
+__device__ __forceinline__ void for_rows_wave(const Grid &g, const double *p, const int *__restrict__ cell_start,
+                                              const int *__restrict__ cell_end, int lane, F f) {
+    int rs, re;
+    db_row<DB_R>(g, db_cell(g, p), lane, cell_start, cell_end, rs, re);
+    unsigned long long busy = __builtin_amdgcn_ballot_w64(re > rs);
+    while (busy) {  // wave-uniform
+        const int b = __builtin_ctzll(busy);
+        busy &= busy - 1;
+        const int e = __builtin_amdgcn_readlane(re, b);
+        for (int q0 = __builtin_amdgcn_readlane(rs, b); q0 < e; q0 += 64) f(q0 + lane, q0 + lane < e);  // wave-uniform trip count
+    }
 }
 
 constexpr int DB_WPB = 4;  // point waves per workgroup
+template <bool CLIQUE>
 __global__ __launch_bounds__(DB_WPB * 64) void dbscan_core_kernel(Grid g, const double *__restrict__ sp, int64_t N,
                                                                  const int *__restrict__ cell_start,
                                                                  const int *__restrict__ cell_end, double e2, int min_points,
@@ -156,7 +195,7 @@ __global__ __launch_bounds__(DB_WPB * 64) void dbscan_core_kernel(Grid g, const 
     if (j >= N) return;  // wave-uniform
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
     int cnt = 0;
-    for_neighbours_wave(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
+    for_rows_wave<CLIQUE ? 2 : 1>(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
         const bool in = valid && dist2(p, sp + 3 * (size_t)q) < e2;
         cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
     });
@@ -167,11 +206,32 @@ __global__ __launch_bounds__(DB_WPB * 64) void dbscan_core_kernel(Grid g, const 
     }
 }
 
+// a thread per cell: rep[c] = the smallest index among the cell's core points (none: INT_MAX), and every core point
+// of the cell hangs under it -- the clique, united without an atomic
+__global__ void dbscan_cell_kernel(int64_t n_cells, const int *__restrict__ cell_start, const int *__restrict__ cell_end,
+                                   const int *__restrict__ idx_sorted,
+                                   const int *__restrict__ core, int *__restrict__ rep, int *__restrict__ parent) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const int a = cell_start[c], e = cell_end[c];
+    int r = 0x7FFFFFFF;
+    for (int q = a; q < e; ++q) {
+        const int i = idx_sorted[q];
+        if (core[i]) r = min(r, i);
+    }
+    rep[c] = r;
+    if (r == 0x7FFFFFFF) return;
+    for (int q = a; q < e; ++q) {
+        const int i = idx_sorted[q];
+        if (core[i]) parent[i] = r;
+    }
+}
+
 // Find with path halving.  parent[x] <= x always points at a member of x's component, and only roots are
 // ever hooked (atomicCAS on parent[root] == root in the union loop), so overwriting a NON-root's parent with
 // its grandparent -- a plain store, whoever wins a race stores an ancestor -- keeps every invariant and the
 // component's smallest index as its root; without it the index-ordered hooking grows chains hundreds of
-// links long (6.9 k points: union kernel 950 us).
+// links long.
 __device__ __forceinline__ int uf_find(int *parent, int a) {
     int r = a;
     while (true) {
@@ -183,30 +243,102 @@ __device__ __forceinline__ int uf_find(int *parent, int a) {
     }
 }
 
+// Uniting the cells.  With cliques a wave per CELL (the wave of the cell's first point; the others leave): the cell's
+// core points wait in LDS, the wave walks the neighbourhood once, and a core neighbour q in a cell ABOVE this one
+// (the pair is seen from the lower cell) within eps of any of them lists q's cell -- the first of every run of equal
+// cells in a pass of 64.  The union-find is touched once per cell at the end (its loads and compare-and-swaps are
+// device-coherent, a microsecond each): the listed cells' components are resolved to their roots, and every
+// distinct root above the smallest of them (and of the cell's own) is hooked under that one, so the lanes'
+// compare-and-swaps go to different words.  Without cliques a wave per core point i lists its core neighbours of
+// smaller index (the pair is seen from the larger) and unites itself with them the same way.
+constexpr int DB_LIST = 128;  // listed cells per wave before the union-find is visited
+template <bool CLIQUE>
 __global__ __launch_bounds__(DB_WPB * 64) void dbscan_union_kernel(Grid g, const double *__restrict__ sp, int64_t N,
                                                                   const int *__restrict__ cell_start,
-                                                                  const int *__restrict__ cell_end, double e2,
-                                                                  const int *__restrict__ idx_sorted, const int *__restrict__ core,
+                                                                  const int *__restrict__ cell_end, const unsigned *__restrict__ cell_s,
+                                                                  double e2, const int *__restrict__ idx_sorted,
+                                                                  const int *__restrict__ core, const int *__restrict__ rep,
                                                                   int *__restrict__ parent) {
+    __shared__ int list_all[DB_WPB][DB_LIST];
+    __shared__ double mine_all[DB_WPB][64][3];
     const int lane = threadIdx.x & 63;
+    int *list = list_all[threadIdx.x >> 6];
+    double (*mine)[3] = mine_all[threadIdx.x >> 6];
     const int64_t j = (int64_t)blockIdx.x * DB_WPB + (threadIdx.x >> 6);
     if (j >= N) return;  // wave-uniform
-    const int i = idx_sorted[j];
-    if (!core[i]) return;  // wave-uniform
+    const unsigned ci = cell_s[j];
+    int i = idx_sorted[j];
+    if (CLIQUE) {
+        if (cell_start[ci] != (int)j) return;  // wave-uniform: not the cell's first point
+        i = rep[ci];
+        if (i == 0x7FFFFFFF) return;  // no core point in the cell
+    } else if (!core[i]) return;  // wave-uniform
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
-    for_neighbours_wave(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
-        if (!valid) return;
-        const int iq = idx_sorted[q];
-        if (iq >= i || !core[iq] || !(dist2(p, sp + 3 * (size_t)q) < e2)) return;
-        int a = i, b = iq;  // union: the larger root is hooked under the smaller one
-        while (true) {
-            a = uf_find(parent, a);
-            b = uf_find(parent, b);
-            if (a == b) break;
-            if (a < b) { const int t = a; a = b; b = t; }
-            if (atomicCAS(&parent[a], a, b) == a) break;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int listed = 0;
+    auto unite = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the list has landed
+        for (int l0 = 0; l0 < listed; l0 += 64) {
+            const bool act = l0 + lane < listed;
+            const int r = act ? uf_find(parent, CLIQUE ? rep[list[l0 + lane]] : list[l0 + lane]) : 0x7FFFFFFF, ri = uf_find(parent, i);
+            int low = min(r, ri);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) low = min(low, __shfl_xor(low, off, 64));
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {  // the listed roots, then i's own (lane 0)
+                int a = round == 0 ? (act ? r : low) : (lane == 0 ? ri : low), b = low;
+                while (a != b) {  // union: the larger root is hooked under the smaller one
+                    if (a < b) { const int t = a; a = b; b = t; }
+                    if (atomicCAS(&parent[a], a, b) == a) break;
+                    a = uf_find(parent, a);
+                    b = uf_find(parent, b);
+                }
+            }
         }
-    });
+        listed = 0;
+    };
+    const int own_end = CLIQUE ? cell_end[ci] : (int)j + 1;
+    for (int a0 = (int)j; a0 < own_end; a0 += 64) {  // the cell's points, 64 at a time (CLIQUE; else the one point)
+        int n_mine = 1;
+        if (CLIQUE) {
+            const bool is_core = a0 + lane < own_end && core[idx_sorted[a0 + lane]];
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(is_core);
+            n_mine = __builtin_popcountll(cm);
+            if (!n_mine) continue;  // wave-uniform
+            if (is_core) {
+                const int slot = __builtin_popcountll(cm & below);
+                mine[slot][0] = sp[3 * (size_t)(a0 + lane)]; mine[slot][1] = sp[3 * (size_t)(a0 + lane) + 1];
+                mine[slot][2] = sp[3 * (size_t)(a0 + lane) + 2];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        for_rows_wave<CLIQUE ? 2 : 1>(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
+            unsigned cq = 0;
+            int other = 0;
+            bool act = false;
+            if (valid) {
+                cq = cell_s[q];
+                other = idx_sorted[q];
+                act = (CLIQUE ? cq > ci : other < i) && core[other];
+            }
+            if (CLIQUE) {
+                if (act) {
+                    const double pq[3] = {sp[3 * (size_t)q], sp[3 * (size_t)q + 1], sp[3 * (size_t)q + 2]};
+                    bool near = false;
+                    for (int a = 0; a < n_mine; ++a) near |= dist2(mine[a], pq) < e2;
+                    act = near;
+                }
+                const unsigned key = act ? cq : 0xFFFFFFFFu, before = __shfl_up(key, 1, 64);
+                act = act && (lane == 0 || before != key);  // one lane per run of equal cells (position order = cell order)
+            } else act = act && dist2(p, sp + 3 * (size_t)q) < e2;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+            if (!mask) return;  // wave-uniform
+            if (listed + 64 > DB_LIST) unite();
+            if (act) list[listed + __builtin_popcountll(mask & below)] = CLIQUE ? (int)cq : other;
+            listed += __builtin_popcountll(mask);
+        });
+    }
+    unite();
 }
 
 // roots of core components in index order -> flags for the rank scan
@@ -220,21 +352,33 @@ __global__ void dbscan_root_kernel(int64_t N, const int *__restrict__ core, int 
     is_rep[i] = (r == (int)i) ? 1u : 0u;
 }
 
-__global__ void dbscan_label_kernel(Grid g, const double *__restrict__ sp, int64_t N, const int *__restrict__ cell_start,
-                                    const int *__restrict__ cell_end, double e2, const int *__restrict__ idx_sorted,
-                                    const int *__restrict__ root, const unsigned *__restrict__ rank /* exclusive scan of is_rep */,
-                                    int32_t *__restrict__ labels) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
+// labels: a component's rank among the roots in index order; a point that is not core takes the smallest rank among
+// the core points within eps (none: -1, noise).  A wave per point; the core points' waves leave at once.
+template <bool CLIQUE>
+__global__ __launch_bounds__(DB_WPB * 64) void dbscan_label_kernel(Grid g, const double *__restrict__ sp, int64_t N,
+                                                                  const int *__restrict__ cell_start,
+                                                                  const int *__restrict__ cell_end, double e2,
+                                                                  const int *__restrict__ idx_sorted, const int *__restrict__ root,
+                                                                  const unsigned *__restrict__ rank /* exclusive scan of is_rep */,
+                                                                  int32_t *__restrict__ labels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * DB_WPB + (threadIdx.x >> 6);
+    if (j >= N) return;  // wave-uniform
     const int i = idx_sorted[j];
-    if (root[i] >= 0) { labels[i] = (int32_t)rank[root[i]]; return; }
+    if (root[i] >= 0) {  // wave-uniform
+        if (lane == 0) labels[i] = (int32_t)rank[root[i]];
+        return;
+    }
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
     int best = 0x7FFFFFFF;
-    for_neighbours(g, p, cell_start, cell_end, [&](int q) {
+    for_rows_wave<CLIQUE ? 2 : 1>(g, p, cell_start, cell_end, lane, [&](int q, bool valid) {
+        if (!valid) return;
         const int rq = root[idx_sorted[q]];
         if (rq >= 0 && dist2(p, sp + 3 * (size_t)q) < e2) best = min(best, (int)rank[rq]);
     });
-    labels[i] = best == 0x7FFFFFFF ? -1 : best;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+    if (lane == 0) labels[i] = best == 0x7FFFFFFF ? -1 : best;
 }
 
 // ------------------------------------------------------------------ k nearest neighbours (mean distance)
@@ -297,14 +441,67 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
     avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
-// One WAVE per query on the grid (clouds above KNN_SMALL_MAX points).  The wave walks the same
-// shells as the thread-per-query kernel above, but its 64 lanes fetch a cell's points together and
-// park the squared distances in LDS; it stops after the shell within whose reach at least k of
-// them lie (the same rule: the k-th best is then settled), and extracts the k smallest one by one
-// with a wave-wide argmin, in ascending order -- the order the mean is summed in.  Same multiset,
-// same summation order, same bits as the other two kernels and the oracle.  A query whose shells
-// hold more candidates than the LDS share raises `overflow`; the host then runs the
-// thread-per-query kernel for the cloud.
+// The k smallest of the n_c squared distances in cand[] (a wave's LDS share), summed as square roots in
+// ascending order -- the order the oracle's sorted top-k list is summed in.  `hi` is a value with
+// chi = #{cand <= hi} >= m.  Three steps, none of them a serial extraction (75 wave-wide argmins cost
+// more than everything else the query does):
+//   1. halve [lo, hi] on the value until about m + 24 candidates lie below hi (counts by ballot),
+//   2. compact those survivors to the front of cand[] (in place: writes trail the reads),
+//   3. rank each survivor by counting the survivors below it ((d, position) order, so ties get distinct
+//      ranks), write sqrt(d) of ranks < m to srt[rank], and sum srt[0..m) in order.
+// Same multiset, same summation order, same bits as the extraction it replaces.
+constexpr int KNN_KMAX = 304;  // k <= 300 (pedp_knn_mean_distance)
+__device__ __forceinline__ double knn_select_sum(double *cand, int n_c, int m, double hi, int chi, double *srt, int lane) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    double lo = -1.0;  // #{cand <= lo} < m
+    for (int it = 0; it < 64 && chi > m + 24; ++it) {
+        const double mid = 0.5 * ((lo > 0.0 ? lo : 0.0) + hi);
+        if (!(mid > lo && mid < hi)) break;
+        int cnt = 0;
+        for (int q0 = 0; q0 < n_c; q0 += 64) {
+            const int q = q0 + lane;
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(q < n_c && cand[q] <= mid));
+        }
+        if (cnt >= m) { hi = mid; chi = cnt; } else lo = mid;
+    }
+    int S = 0;
+    for (int q0 = 0; q0 < n_c; q0 += 64) {
+        const int q = q0 + lane;
+        const double d = q < n_c ? cand[q] : 0.0;
+        const bool keep = q < n_c && d <= hi;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) cand[S + __builtin_popcountll(mask & below)] = d;  // S + ... <= q: behind every unread element
+        S += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    for (int i = lane; i < S; i += 64) {
+        const double d = cand[i];
+        int r0 = 0, r1 = 0;
+        int j = 0;
+        for (; j + 1 < S; j += 2) {
+            const double o0 = cand[j], o1 = cand[j + 1];
+            r0 += (o0 < d || (o0 == d && j < i)) ? 1 : 0;
+            r1 += (o1 < d || (o1 == d && j + 1 < i)) ? 1 : 0;
+        }
+        if (j < S) { const double o0 = cand[j]; r0 += (o0 < d || (o0 == d && j < i)) ? 1 : 0; }
+        const int rank = r0 + r1;
+        if (rank < m) srt[rank] = sqrt(d);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) s += srt[r];  // every lane forms the same sum
+    return s;
+}
+
+// One WAVE per query on the grid (clouds above KNN_SMALL_MAX points).  The candidates are the points of the cube of
+// cells within rho of the query's cell: (2 rho + 1)^2 x rows, each one run of the cell-sorted points
+// (row_run), so the lanes fetch the runs' bounds at once, and the candidates are then numbered through
+// the runs and fetched 256 at a time -- four independent loads in flight per lane.  (Visiting the cells one after the
+// other cost a memory latency per cell, most of them empty in a scanned sheet.)  The squared distances are parked
+// in LDS; the cube is large enough when at least k of them lie within its reach rho * cell (every point outside
+// the cube is farther: the k-th best is then settled -- the rule of the thread-per-query kernel's shells), else
+// the next larger cube is gathered.  knn_select_sum does the rest.  A query whose cube holds more candidates than
+// the LDS share raises `overflow`; the host then runs the thread-per-query kernel for the cloud.
 constexpr int KNN_WCAP = 2048;  // candidates per query wave (16 KB)
 constexpr int KNN_WPB = 4;      // query waves per workgroup
 __global__ __launch_bounds__(KNN_WPB * 64) void knn_mean_wave_kernel(Grid g, const double *__restrict__ sp, int64_t N,
@@ -313,116 +510,106 @@ __global__ __launch_bounds__(KNN_WPB * 64) void knn_mean_wave_kernel(Grid g, con
                                                                     const int *__restrict__ idx_sorted, int k,
                                                                     double *__restrict__ avg, int *__restrict__ overflow) {
     __shared__ double cand_all[KNN_WPB][KNN_WCAP];
+    __shared__ double srt_all[KNN_WPB][KNN_KMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * KNN_WPB + wave;
     if (j >= N) return;  // wave-uniform
     double *cand = cand_all[wave];
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
     const int m = (int)(N < k ? N : k);
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
     const int cx = grid_axis(p[0], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(p[1], g.lo[1], g.cell, g.dim[1]),
               cz = grid_axis(p[2], g.lo[2], g.cell, g.dim[2]);
     const int far = max(max(max(cx, g.dim[0] - 1 - cx), max(cy, g.dim[1] - 1 - cy)), max(cz, g.dim[2] - 1 - cz));
-    int n_c = 0;
-    for (int rho = 0; rho <= far; ++rho) {
-        for (int z = max(cz - rho, 0); z <= min(cz + rho, g.dim[2] - 1); ++z)
-            for (int y = max(cy - rho, 0); y <= min(cy + rho, g.dim[1] - 1); ++y) {
-                const bool face = (abs(z - cz) == rho) || (abs(y - cy) == rho);
-                for (int x = max(cx - rho, 0); x <= min(cx + rho, g.dim[0] - 1); ++x) {
-                    if (!face && abs(x - cx) != rho) continue;  // interior of the cube: visited by an earlier shell
-                    const int c = x + g.dim[0] * (y + g.dim[1] * z);
-                    const int e = cell_end[c];
-                    for (int q0 = cell_start[c]; q0 < e; q0 += 64) {  // wave-uniform bounds
-                        const int q = q0 + lane;
-                        if (q < e && n_c + lane < KNN_WCAP) cand[n_c + lane] = dist2(p, sp + 3 * (size_t)q);
-                        n_c += e - q0 < 64 ? e - q0 : 64;
+    int n_c = 0, within = 0;
+    double reach2 = 0.0;
+    for (int rho = 1;; ++rho) {
+        n_c = 0;
+        const int side = 2 * rho + 1, rows = side * side;
+        const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.dim[0] - 1);
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            const int r = r0 + lane, y = cy + r % side - rho, z = cz + r / side - rho;
+            int rs = 0, re = 0;
+            if (r < rows && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2])
+                row_run(cell_start, cell_end, g.dim[0] * (y + g.dim[1] * z), x0, x1, rs, re);
+            const int cnt = re - rs;
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const int first = incl - cnt, tot = __builtin_amdgcn_readlane(incl, 63);
+            const unsigned long long busy = __builtin_amdgcn_ballot_w64(cnt > 0);
+            if (n_c + tot <= KNN_WCAP) {  // wave-uniform; beyond it the query overflows below
+                for (int c0 = 0; c0 < tot; c0 += 256) {
+                    int src[4] = {0, 0, 0, 0};
+                    for (unsigned long long bb = busy; bb; bb &= bb - 1) {  // the run each of the four candidates lies in
+                        const int b = __builtin_ctzll(bb);
+                        const int pb = __builtin_amdgcn_readlane(first, b), sb = __builtin_amdgcn_readlane(rs, b);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = c0 + 64 * u + lane;
+                            if (idx >= pb) src[u] = sb + (idx - pb);
+                        }
                     }
+                    double d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[u] = dist2(p, sp + 3 * (size_t)(c0 + 64 * u + lane < tot ? src[u] : 0));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c0 + 64 * u + lane < tot) cand[n_c + c0 + 64 * u + lane] = d[u];
                 }
             }
+            n_c += tot;
+        }
         if (n_c > KNN_WCAP) {  // wave-uniform
             if (lane == 0) atomicOr(overflow, 1);
             return;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
-        const double reach = (double)rho * g.cell * (1.0 - 1e-9), reach2 = reach * reach;
-        int within = 0;
-        for (int q = lane; q < n_c; q += 64) within += cand[q] <= reach2 ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) within += __shfl_xor(within, off, 64);
-        if (within >= m) break;
-    }
-    double lmin = inf;
-    int lidx = -1;
-    for (int q = lane; q < n_c; q += 64) {
-        const double d = cand[q];
-        if (d < lmin) { lmin = d; lidx = q; }
-    }
-    double s = 0.0;
-    for (int r = 0; r < m; ++r) {
-        double v = lmin;
-        int owner = lane;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off, 64);
-            const int oo = __shfl_xor(owner, off, 64);
-            if (ov < v || (ov == v && oo < owner)) { v = ov; owner = oo; }
+        const double reach = (double)rho * g.cell * (1.0 - 1e-9);
+        reach2 = reach * reach;
+        within = 0;
+        for (int q0 = 0; q0 < n_c; q0 += 64) {
+            const int q = q0 + lane;
+            within += __builtin_popcountll(__builtin_amdgcn_ballot_w64(q < n_c && cand[q] <= reach2));
         }
-        s += sqrt(v);  // every lane forms the same sum
-        if (lane == owner) {  // drop the extracted value and find the share's next minimum
-            cand[lidx] = inf;
-            lmin = inf;
-            lidx = -1;
-            for (int q = lane; q < n_c; q += 64) {
-                const double d = cand[q];
-                if (d < lmin) { lmin = d; lidx = q; }
-            }
-        }
+        if (within >= m || rho >= far) break;  // rho >= far: the cube is the whole grid
+    }
+    double s;
+    if (within >= m) s = knn_select_sum(cand, n_c, m, reach2, within, srt_all[wave], lane);
+    else {  // the whole cloud without k points in reach: all n_c = N >= m candidates compete
+        double mx = 0.0;
+        for (int q = lane; q < n_c; q += 64) mx = fmax(mx, cand[q]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        s = knn_select_sum(cand, n_c, m, mx, n_c, srt_all[wave], lane);
     }
     if (lane == 0) avg[idx_sorted[j]] = m > 0 ? s / (double)m : -1.0;
 }
 
 // Small clouds (the largest cluster that reaches the outlier filter is a few thousand points): one
-// WAVE per query.  The wave writes the squared distances to all N points into LDS, every lane
-// keeps the minimum of its strided share, and the k smallest are extracted one by one with a
-// wave-wide argmin -- in ascending order, which is the order the mean is summed in.  The lane that
-// owned an extracted value rescans its share.  Same multiset and same summation order as the grid
-// kernel and the oracle.
+// WAVE per query.  The wave writes the squared distances to all N points into LDS and hands them to
+// knn_select_sum with the largest of them as the first bound.  Same multiset and same summation
+// order as the grid kernel and the oracle.
 constexpr int KNN_SMALL_MAX = 4096;  // 32 KB of distances per query wave; beyond ~4k points the grid walk is faster
 __global__ __launch_bounds__(64) void knn_mean_small_kernel(const double *__restrict__ pts, int N, int k,
                                                             double *__restrict__ avg) {
     extern __shared__ double dist[];  // N squared distances of this query
+    __shared__ double srt[KNN_KMAX];
     const int lane = threadIdx.x, i = blockIdx.x;
     const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    double lmin = inf;
-    int lidx = -1;
+    double mx = 0.0;
     for (int q = lane; q < N; q += 64) {
         const double d = dist2(p, pts + 3 * (size_t)q);
         dist[q] = d;
-        if (d < lmin) { lmin = d; lidx = q; }
+        mx = fmax(mx, d);
     }
-    const int m = N < k ? N : k;
-    double s = 0.0;
-    for (int r = 0; r < m; ++r) {
-        double v = lmin;
-        int owner = lane;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off, 64);
-            const int oo = __shfl_xor(owner, off, 64);
-            if (ov < v || (ov == v && oo < owner)) { v = ov; owner = oo; }
-        }
-        s += sqrt(v);  // every lane forms the same sum
-        if (lane == owner) {  // drop the extracted value and find the share's next minimum
-            dist[lidx] = inf;
-            lmin = inf;
-            lidx = -1;
-            for (int q = lane; q < N; q += 64) {
-                const double d = dist[q];
-                if (d < lmin) { lmin = d; lidx = q; }
-            }
-        }
-    }
+    for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    const int m = N < k ? N : k;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const double s = knn_select_sum(dist, N, m, mx, N, srt, lane);
     if (lane == 0) avg[i] = m > 0 ? s / (double)m : -1.0;
 }
 
@@ -882,28 +1069,46 @@ __host__ __device__ inline double plane_dist(const double pl[4], const double *p
     return fabs(((pl[0] * p[0] + pl[1] * p[1]) + pl[2] * p[2]) + pl[3]);
 }
 
-__global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ pts, long long N, double threshold,
-                                                           unsigned long long seed, int *__restrict__ counts) {
-    __shared__ int red[4];
-    __shared__ double pl_s[4];
-    __shared__ int ok_s;
-    const int t = blockIdx.x;
-    if (threadIdx.x == 0) {
-        long long s[3];
-        double pl[4];
-        sample3(seed, t, N, s);
-        ok_s = triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], pl);
-        for (int k = 0; k < 4; ++k) pl_s[k] = ok_s ? pl[k] : 0.0;
+// Two kernels.  The first forms every iteration's plane (a thread per iteration; a plane that does not exist --
+// collinear sample -- gets a NaN offset, which no distance test passes, and the count -1).  The second counts
+// inliers tile by tile: a workgroup holds 256 points in registers and runs RS_PLANES planes from LDS over them,
+// so the cloud is read once per RS_PLANES iterations (a workgroup per iteration streaming the whole cloud
+// moved 228 MB through L2 for 9.5 k points x 1000 iterations: 166 us).  Integer adds: any order, same counts.
+constexpr int RS_PLANES = 64;
+__global__ void ransac_plane_kernel(const double *__restrict__ pts, long long N, unsigned long long seed, int n_iter,
+                                    double *__restrict__ planes, int *__restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_iter) return;
+    long long s[3];
+    double pl[4];
+    sample3(seed, t, N, s);
+    const bool ok = triangle_plane(pts + 3 * s[0], pts + 3 * s[1], pts + 3 * s[2], pl);
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    for (int k = 0; k < 4; ++k) planes[4 * (size_t)t + k] = ok ? pl[k] : (k == 3 ? nan : 0.0);
+    counts[t] = ok ? 0 : -1;
+}
+__global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ pts, long long N, double threshold, int n_iter,
+                                                           const double *__restrict__ planes, int *__restrict__ counts) {
+    __shared__ double pl_s[RS_PLANES][4];
+    __shared__ int cnt_s[RS_PLANES];
+    const int t0 = blockIdx.y * RS_PLANES, nt = min(RS_PLANES, n_iter - t0);
+    if (threadIdx.x < RS_PLANES) {
+        cnt_s[threadIdx.x] = 0;
+        if ((int)threadIdx.x < nt)
+            for (int k = 0; k < 4; ++k) pl_s[threadIdx.x][k] = planes[4 * (size_t)(t0 + threadIdx.x) + k];
     }
     __syncthreads();
-    if (!ok_s) { if (threadIdx.x == 0) counts[t] = -1; return; }
-    const double pl[4] = {pl_s[0], pl_s[1], pl_s[2], pl_s[3]};
-    int cnt = 0;
-    for (long long i = threadIdx.x; i < N; i += 256) cnt += plane_dist(pl, pts + 3 * i) < threshold;
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool have = i < N;
+    double p[3] = {0.0, 0.0, 0.0};
+    if (have) { p[0] = pts[3 * i]; p[1] = pts[3 * i + 1]; p[2] = pts[3 * i + 2]; }
+    for (int t = 0; t < nt; ++t) {
+        const double pl[4] = {pl_s[t][0], pl_s[t][1], pl_s[t][2], pl_s[t][3]};
+        const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(have && plane_dist(pl, p) < threshold));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_s[t], c);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) counts[t] = red[0] + red[1] + red[2] + red[3];
+    if ((int)threadIdx.x < nt && cnt_s[threadIdx.x]) atomicAdd(&counts[t0 + threadIdx.x], cnt_s[threadIdx.x]);
 }
 
 // host: GetPlaneFromPoints, oracle/cloudops.c pedp_oracle_plane_from_points
@@ -1116,6 +1321,7 @@ struct GridIndex {
     Grid g;
     double *sp;
     int *val_s, *cell_start, *cell_end;
+    unsigned *cell_s;                    // cell of every sorted position
     void *tmp;  // the sort's scratch, free once the index stands
     size_t tmp_bytes;
 };
@@ -1133,17 +1339,16 @@ int grid_index_build(pedp_ctx_t c, Carver &cv, const double *d_pts, int64_t N, c
     unsigned *cell = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
     int *val = cv.take<int>(N);
     ix.val_s = cv.take<int>(N);
-    ix.cell_start = cv.take<int>(n_cells);
-    ix.cell_end = cv.take<int>(n_cells);
+    ix.cell_start = cv.take<int>(2 * (size_t)n_cells);  // starts and ends side by side: one clear
+    ix.cell_end = ix.cell_start + n_cells;
+    ix.cell_s = cell_s;
     ix.tmp = cv.take<char>(tmp_sort < 256 ? 256 : tmp_sort);
     ix.tmp_bytes = tmp_sort;
-    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    const unsigned grid = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
+    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_start, 0, sizeof(int) * 2 * (size_t)n_cells, c->stream));
+    hipLaunchKernelGGL(grid_cell_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(ix.tmp, tmp_sort, cell, cell_s, val, ix.val_s, (unsigned)N, 0, 32, c->stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3(grid), dim3(256), 0, c->stream, cell_s, ix.val_s, d_pts, N, ix.cell_start, ix.cell_end,
-                       ix.sp);
+    hipLaunchKernelGGL(grid_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, cell_s, ix.val_s, d_pts, N,
+                       ix.cell_start, ix.cell_end, ix.sp);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1152,15 +1357,20 @@ int dbscan_core(pedp_ctx_t c, const double *d_pts, int64_t N, double eps, int mi
                 int32_t **out_labels) {
     Grid g;
     int64_t n_cells = 0;
-    // cell >= eps with margin: neighbours within eps are never two cells apart
-    int rc = make_grid(lo, hi, eps * (1.0 + 1e-9), g, n_cells, "pedp_cluster_dbscan");
+    // cell = eps / sqrt(3) less a hair: a cell's diameter is below eps and neighbours within eps are never three cells apart
+    int rc = make_grid(lo, hi, eps * 0.57735026918962576 * (1.0 - 1e-9), g, n_cells, "pedp_cluster_dbscan");
     if (rc) return rc;
+    const bool clique = g.cell * 1.7320508075688772 < eps;
+    if (!clique) {  // beyond the cell budget: cells of eps (or its next doubling that fits), neighbours one cell apart
+        rc = make_grid(lo, hi, eps * (1.0 + 1e-9), g, n_cells, "pedp_cluster_dbscan");
+        if (rc) return rc;
+    }
     const unsigned n = (unsigned)N;
     size_t tmp_sort = 0, tmp_scan = 0;
     const size_t ix_bytes = grid_index_bytes(c, N, n_cells, &tmp_sort);
     PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
                                          rocprim::plus<unsigned>(), c->stream));
-    const size_t need = ix_bytes + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 4 + a256(tmp_scan) + 4096;
+    const size_t need = ix_bytes + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 4 + a256(sizeof(int) * n_cells) + a256(tmp_scan) + 4096;
     int st = c->ops.reserve(need);
     if (st) return st;
     Carver cv{(char *)c->ops.ptr};
@@ -1168,20 +1378,33 @@ int dbscan_core(pedp_ctx_t c, const double *d_pts, int64_t N, double eps, int mi
     rc = grid_index_build(c, cv, d_pts, N, g, n_cells, tmp_sort, ix);
     if (rc) return rc;
     unsigned *is_rep = cv.take<unsigned>(N), *rank = cv.take<unsigned>(N);
-    int *core = cv.take<int>(N), *parent = cv.take<int>(N), *root = cv.take<int>(N);
+    int *core = cv.take<int>(N), *parent = cv.take<int>(N), *root = cv.take<int>(N), *rep = cv.take<int>(n_cells);
     int32_t *d_labels = cv.take<int32_t>(N);
     void *d_tmp = cv.take<char>(tmp_scan);
     const unsigned grid = (unsigned)((N + 255) / 256);
     const double e2 = eps * eps;
     const unsigned grid_w = (unsigned)((N + DB_WPB - 1) / DB_WPB);
-    hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
-                       min_points, ix.val_s, core, parent);
-    hipLaunchKernelGGL(dbscan_union_kernel, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
-                       ix.val_s, core, parent);
+    if (clique) {
+        hipLaunchKernelGGL(dbscan_core_kernel<true>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
+                           min_points, ix.val_s, core, parent);
+        hipLaunchKernelGGL(dbscan_cell_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, c->stream, n_cells, ix.cell_start,
+                           ix.cell_end, ix.val_s, core, rep, parent);
+        hipLaunchKernelGGL(dbscan_union_kernel<true>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end,
+                           ix.cell_s, e2, ix.val_s, core, rep, parent);
+    } else {
+        hipLaunchKernelGGL(dbscan_core_kernel<false>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2,
+                           min_points, ix.val_s, core, parent);
+        hipLaunchKernelGGL(dbscan_union_kernel<false>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end,
+                           ix.cell_s, e2, ix.val_s, core, rep, parent);
+    }
     hipLaunchKernelGGL(dbscan_root_kernel, dim3(grid), dim3(256), 0, c->stream, N, core, parent, root, is_rep);
     PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, is_rep, rank, 0u, n, rocprim::plus<unsigned>(), c->stream));
-    hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2, ix.val_s,
-                       root, rank, d_labels);
+    if (clique)
+        hipLaunchKernelGGL(dbscan_label_kernel<true>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2, ix.val_s,
+                           root, rank, d_labels);
+    else
+        hipLaunchKernelGGL(dbscan_label_kernel<false>, dim3(grid_w), dim3(DB_WPB * 64), 0, c->stream, g, ix.sp, N, ix.cell_start, ix.cell_end, e2, ix.val_s,
+                           root, rank, d_labels);
     PEDP_HIP_CHECK(hipGetLastError());
     *out_labels = d_labels;
     return PEDP_OK;
@@ -1266,11 +1489,14 @@ int normals_core(pedp_ctx_t c, const double *d_pts, int64_t N, double radius, in
 // plane RANSAC: inlier counts of every iteration -> the best iteration (most inliers, earliest on ties) and its plane
 int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distance_threshold, int num_iterations, uint64_t seed,
                     int *best_t, double best[4]) {
-    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + 512);
+    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + a256(sizeof(double) * 4 * (size_t)num_iterations) + 512);
     if (st) return st;
     int *d_cnt = (int *)c->ops.ptr;
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)num_iterations), dim3(256), 0, c->stream, d_pts, (long long)N,
-                       distance_threshold, (unsigned long long)seed, d_cnt);
+    double *d_planes = (double *)((char *)c->ops.ptr + a256(sizeof(int) * (size_t)num_iterations));
+    hipLaunchKernelGGL(ransac_plane_kernel, dim3((unsigned)((num_iterations + 63) / 64)), dim3(64), 0, c->stream, d_pts, (long long)N,
+                       (unsigned long long)seed, num_iterations, d_planes, d_cnt);
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((num_iterations + RS_PLANES - 1) / RS_PLANES)),
+                       dim3(256), 0, c->stream, d_pts, (long long)N, distance_threshold, num_iterations, (const double *)d_planes, d_cnt);
     PEDP_HIP_CHECK(hipGetLastError());
     std::vector<int> counts((size_t)num_iterations);
     PEDP_HIP_CHECK(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int) * (size_t)num_iterations, hipMemcpyDeviceToHost, c->stream));
@@ -1498,7 +1724,7 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
     double *d_pts = cv.take<double>(3 * (size_t)N), *sp = cv.take<double>(3 * (size_t)N), *d_nrm = cv.take<double>(3 * (size_t)N);
     unsigned *cell_id = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
     int *val = cv.take<int>(N), *val_s = cv.take<int>(N), *nbr_n = cv.take<int>(N);
-    int *cell_start = cv.take<int>(n_cells), *cell_end = cv.take<int>(n_cells);
+    int *cell_start = cv.take<int>(2 * (size_t)n_cells), *cell_end = cell_start + n_cells;
     void *d_tmp = cv.take<char>(tmp_sort);
     int *nbr_j = cv.take<int>((size_t)N * max_nn);
     double *nbr_d = cv.take<double>((size_t)N * max_nn);
@@ -1506,8 +1732,7 @@ int pedp_fpfh(pedp_ctx_t c, const double *pts, const double *normals, int64_t N,
     if (d_in) d_pts = d_in;  // already up (bounds_of)
     else { int up_ = pedp_upload(c, d_pts, pts, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
     { int up_ = pedp_upload(c, d_nrm, normals, sizeof(double) * 3 * (size_t)N); if (up_) return up_; }
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * (size_t)n_cells, c->stream));
-    PEDP_HIP_CHECK(hipMemsetAsync(cell_end, 0, sizeof(int) * (size_t)n_cells, c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(cell_start, 0, sizeof(int) * 2 * (size_t)n_cells, c->stream));
     const unsigned grid = (unsigned)((N + 255) / 256), grid64 = (unsigned)((N + NRM_THREADS - 1) / NRM_THREADS);
     hipLaunchKernelGGL(grid_cell_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell_id, val);
     PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, cell_id, cell_s, val, val_s, n, 0, 32, c->stream));
