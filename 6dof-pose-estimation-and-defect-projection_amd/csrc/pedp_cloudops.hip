@@ -31,6 +31,10 @@
 
 namespace {
 
+// rocPRIM sorts up to a million items by merging (about twenty launches whatever the key's width); with the limit at
+// zero it always takes the radix passes, whose number follows the bits asked for
+using RadixPasses = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Carver {
@@ -49,14 +53,16 @@ __device__ __forceinline__ double dist2(const double *a, const double *b) {
 }
 
 // ------------------------------------------------------------------ voxel grid
-__global__ void voxel_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz, double voxel,
-                                 unsigned long long *__restrict__ key, int *__restrict__ val) {
+// key = (cx, cy, cz) packed most significant first into just the bits the box needs (sy, sz: the widths of cy and cz):
+// the radix sort's passes follow the key's width
+__global__ void voxel_key_kernel(const double *__restrict__ pts, int64_t N, double lox, double loy, double loz, double voxel, int sy,
+                                 int sz, unsigned long long *__restrict__ key, int *__restrict__ val) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const unsigned long long cx = (unsigned long long)(long long)floor((pts[3 * i] - lox) / voxel);
     const unsigned long long cy = (unsigned long long)(long long)floor((pts[3 * i + 1] - loy) / voxel);
     const unsigned long long cz = (unsigned long long)(long long)floor((pts[3 * i + 2] - loz) / voxel);
-    key[i] = ((cx & 0x1FFFFFull) << 42) | ((cy & 0x1FFFFFull) << 21) | (cz & 0x1FFFFFull);
+    key[i] = ((cx & 0x1FFFFFull) << (sy + sz)) | ((cy & ((1ull << sy) - 1ull)) << sz) | (cz & ((1ull << sz) - 1ull));
     val[i] = (int)i;
 }
 
@@ -113,18 +119,39 @@ __global__ void grid_ranges_kernel(const unsigned *__restrict__ cell_sorted, con
     sp[3 * j] = pts[3 * i]; sp[3 * j + 1] = pts[3 * i + 1]; sp[3 * j + 2] = pts[3 * i + 2];
 }
 
-// The cells x0 .. x1 of one x row have consecutive ids, so their points are ONE run of the cell-sorted order: from the
-// first non-empty cell's start to the last one's end (rs = re = 0: the row is empty).  The loads are independent.
+// The index by counting: a point's cell and its slot among the cell's points (an atomic count: the slots' order is
+// whatever the hardware made it -- every reader of the index is indifferent to the order inside a cell: counts,
+// minima, sets, and lists with explicit (distance, index) order), an exclusive scan of the counts, the points placed.
+// Six launches; a sort of nine thousand pairs is a dozen.  begin[] has n_cells + 1 entries and is monotone, so cell
+// c's run is begin[c] .. begin[c + 1] and the cells c .. c' of one x row are the one run begin[c] .. begin[c' + 1].
+__global__ void grid_count_kernel(const double *__restrict__ pts, int64_t N, Grid g, unsigned *__restrict__ cell, int *__restrict__ slot,
+                                  unsigned *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int cx = grid_axis(pts[3 * i], g.lo[0], g.cell, g.dim[0]), cy = grid_axis(pts[3 * i + 1], g.lo[1], g.cell, g.dim[1]),
+              cz = grid_axis(pts[3 * i + 2], g.lo[2], g.cell, g.dim[2]);
+    const unsigned c = (unsigned)(cx + g.dim[0] * (cy + g.dim[1] * cz));
+    cell[i] = c;
+    slot[i] = (int)atomicAdd(&count[c], 1u);
+}
+__global__ void grid_place_kernel(const double *__restrict__ pts, int64_t N, const unsigned *__restrict__ cell,
+                                  const int *__restrict__ slot, const int *__restrict__ begin, double *__restrict__ sp,
+                                  int *__restrict__ idx_sorted, unsigned *__restrict__ cell_s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned c = cell[i];
+    const int64_t j = (int64_t)begin[c] + slot[i];
+    sp[3 * j] = pts[3 * i]; sp[3 * j + 1] = pts[3 * i + 1]; sp[3 * j + 2] = pts[3 * i + 2];
+    idx_sorted[j] = (int)i;
+    cell_s[j] = c;
+}
+
+// The cells x0 .. x1 of one x row have consecutive ids, so their points are ONE run of the cell-sorted order
+// (rs = re: the row is empty).
 __device__ __forceinline__ void row_run(const int *__restrict__ cell_start, const int *__restrict__ cell_end, int base, int x0, int x1,
                                         int &rs, int &re) {
-    rs = re = 0;
-    for (int x = x0; x <= x1; ++x) {
-        const int s = cell_start[base + x], e = cell_end[base + x];
-        if (e > s) {
-            if (re == 0) rs = s;
-            re = e;
-        }
-    }
+    rs = cell_start[base + x0];
+    re = cell_end[base + x1];
 }
 
 // calls f(q) for every sorted position q whose point lies in one of the 27 cells around p
@@ -1111,6 +1138,39 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     if ((int)threadIdx.x < nt && cnt_s[threadIdx.x]) atomicAdd(&counts[t0 + threadIdx.x], cnt_s[threadIdx.x]);
 }
 
+// the best iteration -- most inliers, the earliest on ties -- and its three sampled points, in one small block for the
+// host: out[0] = iteration (-1: no plane at all), out[1..9] = the points
+__global__ __launch_bounds__(256) void ransac_best_kernel(const int *__restrict__ counts, int n_iter, const double *__restrict__ pts,
+                                                          long long N, unsigned long long seed, double *__restrict__ out) {
+    __shared__ int cnt_s[256], it_s[256];
+    int bc = -1, bt = -1;
+    for (int t = threadIdx.x; t < n_iter; t += 256)
+        if (counts[t] > bc) { bc = counts[t]; bt = t; }  // ascending t: the earliest of the thread's share
+    cnt_s[threadIdx.x] = bc;
+    it_s[threadIdx.x] = bt;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const int oc = cnt_s[threadIdx.x + w], ot = it_s[threadIdx.x + w];
+            if (oc > cnt_s[threadIdx.x] || (oc == cnt_s[threadIdx.x] && ot >= 0 && (it_s[threadIdx.x] < 0 || ot < it_s[threadIdx.x]))) {
+                cnt_s[threadIdx.x] = oc;
+                it_s[threadIdx.x] = ot;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int best = it_s[0];
+        out[0] = (double)best;
+        if (best >= 0) {
+            long long s[3];
+            sample3(seed, best, N, s);
+            for (int q = 0; q < 3; ++q)
+                for (int k = 0; k < 3; ++k) out[1 + 3 * q + k] = pts[3 * s[q] + k];
+        }
+    }
+}
+
 // host: GetPlaneFromPoints, oracle/cloudops.c pedp_oracle_plane_from_points
 void plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
     pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
@@ -1273,15 +1333,26 @@ int voxel_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N
     if (rc) return rc;
     rc = bounds_device(c, d_pts, N, d_part, lo, hi);
     if (rc) return rc;
+    int bits[3];
     for (int k = 0; k < 3; ++k) {
         PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
         lo[k] = lo[k] - voxel_size * 0.5;
         PEDP_REQUIRE((hi[k] - lo[k]) / voxel_size < 2097151.0, "pedp_voxel_down_sample: voxel_size is too small");
+        // the largest cell index of the axis, one to spare for the division's rounding
+        const unsigned long long top = (unsigned long long)std::floor((hi[k] - lo[k]) / voxel_size) + 1ull;
+        bits[k] = 1;
+        while (bits[k] < 21 && (top >> bits[k])) ++bits[k];
     }
+    const int key_bits = bits[0] + bits[1] + bits[2];
     const unsigned n = (unsigned)N;
     size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                           (int *)nullptr, (int *)nullptr, n, 0, 63, c->stream));
+    const bool passes = N >= 131072;  // below, the merge sort's launches are the shorter ones (a radix pass takes 20 us whatever the size)
+    if (passes)
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs<RadixPasses>(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                            (int *)nullptr, (int *)nullptr, n, 0, key_bits, c->stream));
+    else
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr,
+                                               (int *)nullptr, n, 0, key_bits, c->stream));
     PEDP_ROCPRIM(rocprim::run_length_encode(nullptr, tmp_rle, (unsigned long long *)nullptr, n, (unsigned long long *)nullptr,
                                             (unsigned *)nullptr, (unsigned *)nullptr, c->stream));
     PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_scan, (unsigned *)nullptr, (unsigned *)nullptr, 0u, n,
@@ -1300,8 +1371,10 @@ int voxel_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N
     unsigned *counts = cv.take<unsigned>(N), *offsets = cv.take<unsigned>(N), *n_runs = cv.take<unsigned>(1);
     void *d_tmp = cv.take<char>(tmp);
     const unsigned grid = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, key, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, 63, c->stream));
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, lo[0], lo[1], lo[2], voxel_size, bits[1], bits[2],
+                       key, val);
+    if (passes) PEDP_ROCPRIM(rocprim::radix_sort_pairs<RadixPasses>(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, key_bits, c->stream));
+    else PEDP_ROCPRIM(rocprim::radix_sort_pairs(d_tmp, tmp_sort, key, key_s, val, val_s, n, 0, key_bits, c->stream));
     PEDP_ROCPRIM(rocprim::run_length_encode(d_tmp, tmp_rle, key_s, n, uniq, counts, n_runs, c->stream));
     PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_scan, counts, offsets, 0u, n, rocprim::plus<unsigned>(), c->stream));
     hipLaunchKernelGGL(voxel_average_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, d_nrm, val_s, counts, offsets, n_runs,
@@ -1320,35 +1393,37 @@ int voxel_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N
 struct GridIndex {
     Grid g;
     double *sp;
-    int *val_s, *cell_start, *cell_end;
+    int *val_s, *cell_start, *cell_end;  // cell_end = cell_start + 1: one monotone array of n_cells + 1 run starts
     unsigned *cell_s;                    // cell of every sorted position
-    void *tmp;  // the sort's scratch, free once the index stands
+    void *tmp;  // the scan's scratch, free once the index stands
     size_t tmp_bytes;
 };
 // carves the index out of cv (the caller has reserved room: grid_index_bytes) and builds it
-size_t grid_index_bytes(pedp_ctx_t c, int64_t N, int64_t n_cells, size_t *tmp_sort) {
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, *tmp_sort, (unsigned *)nullptr, (unsigned *)nullptr, (int *)nullptr, (int *)nullptr,
-                                           (unsigned)N, 0, 32, c->stream));
-    return a256(sizeof(double) * 3 * N) + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 2 + a256(sizeof(int) * n_cells) * 2 +
-           a256(*tmp_sort < 256 ? 256 : *tmp_sort);
+size_t grid_index_bytes(pedp_ctx_t c, int64_t N, int64_t n_cells, size_t *tmp_scan) {
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, *tmp_scan, (unsigned *)nullptr, (int *)nullptr, 0u, (size_t)n_cells + 1,
+                                         rocprim::plus<unsigned>(), c->stream));
+    return a256(sizeof(double) * 3 * N) + a256(sizeof(unsigned) * N) * 2 + a256(sizeof(int) * N) * 2 + a256(sizeof(int) * (n_cells + 1)) * 2 +
+           a256(*tmp_scan < 256 ? 256 : *tmp_scan);
 }
-int grid_index_build(pedp_ctx_t c, Carver &cv, const double *d_pts, int64_t N, const Grid &g, int64_t n_cells, size_t tmp_sort,
+int grid_index_build(pedp_ctx_t c, Carver &cv, const double *d_pts, int64_t N, const Grid &g, int64_t n_cells, size_t tmp_scan,
                      GridIndex &ix) {
     ix.g = g;
     ix.sp = cv.take<double>(3 * (size_t)N);
-    unsigned *cell = cv.take<unsigned>(N), *cell_s = cv.take<unsigned>(N);
-    int *val = cv.take<int>(N);
+    unsigned *cell = cv.take<unsigned>(N);
+    ix.cell_s = cv.take<unsigned>(N);
+    int *slot = cv.take<int>(N);
     ix.val_s = cv.take<int>(N);
-    ix.cell_start = cv.take<int>(2 * (size_t)n_cells);  // starts and ends side by side: one clear
-    ix.cell_end = ix.cell_start + n_cells;
-    ix.cell_s = cell_s;
-    ix.tmp = cv.take<char>(tmp_sort < 256 ? 256 : tmp_sort);
-    ix.tmp_bytes = tmp_sort;
-    PEDP_HIP_CHECK(hipMemsetAsync(ix.cell_start, 0, sizeof(int) * 2 * (size_t)n_cells, c->stream));
-    hipLaunchKernelGGL(grid_cell_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_pts, N, g, cell, val);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(ix.tmp, tmp_sort, cell, cell_s, val, ix.val_s, (unsigned)N, 0, 32, c->stream));
-    hipLaunchKernelGGL(grid_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, cell_s, ix.val_s, d_pts, N,
-                       ix.cell_start, ix.cell_end, ix.sp);
+    unsigned *count = cv.take<unsigned>(n_cells + 1);
+    ix.cell_start = cv.take<int>(n_cells + 1);
+    ix.cell_end = ix.cell_start + 1;
+    ix.tmp = cv.take<char>(tmp_scan < 256 ? 256 : tmp_scan);
+    ix.tmp_bytes = tmp_scan;
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    PEDP_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(unsigned) * ((size_t)n_cells + 1), c->stream));
+    hipLaunchKernelGGL(grid_count_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, g, cell, slot, count);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(ix.tmp, tmp_scan, count, ix.cell_start, 0u, (size_t)n_cells + 1, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(grid_place_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, (const unsigned *)cell, (const int *)slot,
+                       (const int *)ix.cell_start, ix.sp, ix.val_s, ix.cell_s);
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
@@ -1489,7 +1564,7 @@ int normals_core(pedp_ctx_t c, const double *d_pts, int64_t N, double radius, in
 // plane RANSAC: inlier counts of every iteration -> the best iteration (most inliers, earliest on ties) and its plane
 int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distance_threshold, int num_iterations, uint64_t seed,
                     int *best_t, double best[4]) {
-    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + a256(sizeof(double) * 4 * (size_t)num_iterations) + 512);
+    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + a256(sizeof(double) * (4 * (size_t)num_iterations + 16)) + 512);
     if (st) return st;
     int *d_cnt = (int *)c->ops.ptr;
     double *d_planes = (double *)((char *)c->ops.ptr + a256(sizeof(int) * (size_t)num_iterations));
@@ -1498,20 +1573,16 @@ int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distanc
     hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((num_iterations + RS_PLANES - 1) / RS_PLANES)),
                        dim3(256), 0, c->stream, d_pts, (long long)N, distance_threshold, num_iterations, (const double *)d_planes, d_cnt);
     PEDP_HIP_CHECK(hipGetLastError());
-    std::vector<int> counts((size_t)num_iterations);
-    PEDP_HIP_CHECK(hipMemcpyAsync(counts.data(), d_cnt, sizeof(int) * (size_t)num_iterations, hipMemcpyDeviceToHost, c->stream));
+    double *d_best = d_planes + 4 * (size_t)num_iterations, *h_best = (double *)((char *)c->pinned + 8192);
+    hipLaunchKernelGGL(ransac_best_kernel, dim3(1), dim3(256), 0, c->stream, (const int *)d_cnt, num_iterations, d_pts, (long long)N,
+                       (unsigned long long)seed, d_best);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_best, d_best, sizeof(double) * 10, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int bt = -1, best_cnt = -1;
-    for (int t = 0; t < num_iterations; ++t)
-        if (counts[t] > best_cnt) { best_cnt = counts[t]; bt = t; }  // most inliers, earliest iteration on ties
+    const int bt = (int)h_best[0];
     *best_t = bt;
     if (bt < 0) return PEDP_OK;
-    long long s[3];
-    sample3(seed, bt, N, s);
-    double p3[9];  // the three sampled points (72 bytes back)
-    for (int q = 0; q < 3; ++q)
-        PEDP_HIP_CHECK(hipMemcpyAsync(p3 + 3 * q, d_pts + 3 * s[q], sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const double *p3 = h_best + 1;  // the three sampled points
     triangle_plane(p3, p3 + 3, p3 + 6, best);
     return PEDP_OK;
 }
@@ -1525,9 +1596,44 @@ __global__ void plane_keep_kernel(const double *__restrict__ pts, int64_t N, dou
     const bool in = plane_dist(pl, pts + 3 * i) < thr;
     flag[i] = (in == (inliers != 0)) ? 1u : 0u;
 }
-__global__ void label_keep_kernel(const int32_t *__restrict__ labels, int64_t N, int32_t label, unsigned *__restrict__ flag) {
+// the largest cluster (np.unique + argmax: the lowest label among the largest) without a trip to the host: members per
+// label, the label with most members, the flags of its points (no cluster at all: *label = -1, nothing is kept)
+__global__ void label_count_kernel(const int32_t *__restrict__ labels, int64_t N, int *__restrict__ members) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) flag[i] = labels[i] == label ? 1u : 0u;
+    const int l = i < N ? labels[i] : -1;
+    // one add per distinct label of the wave (most points carry the same label: a point's own add each queues
+    // thousands of atomics on one word)
+    unsigned long long left = __builtin_amdgcn_ballot_w64(l >= 0);
+    while (left) {  // wave-uniform
+        const int l0 = __builtin_amdgcn_readlane(l, __builtin_ctzll(left));
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(l == l0);
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(left)) atomicAdd(&members[l0], __builtin_popcountll(same));
+        left &= ~same;
+    }
+}
+__global__ __launch_bounds__(256) void label_largest_kernel(const int *__restrict__ members, int64_t N, int *__restrict__ label) {
+    __shared__ int cnt_s[256], lab_s[256];
+    int bc = 0, bl = -1;
+    for (int64_t l = threadIdx.x; l < N; l += 256)
+        if (members[l] > bc) { bc = members[l]; bl = (int)l; }  // ascending l: the lowest of the thread's share
+    cnt_s[threadIdx.x] = bc;
+    lab_s[threadIdx.x] = bl;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const int oc = cnt_s[threadIdx.x + w], ol = lab_s[threadIdx.x + w];
+            if (oc > cnt_s[threadIdx.x] || (oc == cnt_s[threadIdx.x] && ol >= 0 && ol < lab_s[threadIdx.x])) {
+                cnt_s[threadIdx.x] = oc;
+                lab_s[threadIdx.x] = ol;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *label = lab_s[0];
+}
+__global__ void label_keep_kernel(const int32_t *__restrict__ labels, int64_t N, const int *__restrict__ label, unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = (*label >= 0 && labels[i] == *label) ? 1u : 0u;
 }
 __global__ void range_keep_kernel(const double *__restrict__ avg, int64_t N, double limit, unsigned *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1859,7 +1965,7 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     if (m1 < 3) { *status = PEDP_PREPROCESS_DEGENERATE; return PEDP_OK; }
     // the clouds between the stages: three (points, normals) pairs and a flag array, sized by the down-sampled cloud
     const size_t one = a256(sizeof(double) * 3 * (size_t)m1);
-    rc = c->chain.reserve(6 * one + a256(sizeof(unsigned) * (size_t)m1) + 256);
+    rc = c->chain.reserve(6 * one + a256(sizeof(unsigned) * (size_t)m1) + a256(sizeof(int) * ((size_t)m1 + 1)) + 256);
     if (rc) return rc;
     rc = small_block(c, &d_part);
     if (rc) return rc;
@@ -1867,6 +1973,7 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     double *A_pts = (double *)cb, *A_nrm = (double *)(cb + one), *B_pts = (double *)(cb + 2 * one), *B_nrm = (double *)(cb + 3 * one),
            *C_pts = (double *)(cb + 4 * one), *C_nrm = (double *)(cb + 5 * one);
     unsigned *flag = (unsigned *)(cb + 6 * one);
+    int *d_members = (int *)(cb + 6 * one + a256(sizeof(unsigned) * (size_t)m1));  // members per label, then the largest cluster's label
     PEDP_HIP_CHECK(hipMemcpyAsync(A_pts, v_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
     // ---- table plane: the best of the sampled planes (the refit plane of segment_plane has no reader on this branch)
     int best_t = -1;
@@ -1902,23 +2009,17 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     int32_t *d_labels = nullptr;
     rc = dbscan_core(c, B_pts, m2, prm->cluster_eps, prm->cluster_min_points, lo, hi, &d_labels);
     if (rc) return rc;
-    std::vector<int32_t> labels((size_t)m2);
-    { int dn_ = pedp_download(c, labels.data(), d_labels, sizeof(int32_t) * (size_t)m2); if (dn_) return dn_; }
-    int32_t top = -1;
-    for (int64_t i = 0; i < m2; ++i) top = labels[i] > top ? labels[i] : top;
-    if (top < 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
-    std::vector<int64_t> members((size_t)top + 1, 0);
-    for (int64_t i = 0; i < m2; ++i)
-        if (labels[i] >= 0) ++members[labels[i]];
-    int32_t largest = 0;
-    for (int32_t l = 1; l <= top; ++l)
-        if (members[l] > members[largest]) largest = l;
+    PEDP_HIP_CHECK(hipMemsetAsync(d_members, 0, sizeof(int) * (size_t)(m2 + 1), c->stream));
+    hipLaunchKernelGGL(label_count_kernel, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_labels, m2,
+                       d_members);
+    hipLaunchKernelGGL(label_largest_kernel, dim3(1), dim3(256), 0, c->stream, (const int *)d_members, m2, d_members + m2);
     hipLaunchKernelGGL(label_keep_kernel, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_labels, m2,
-                       largest, flag);
+                       (const int *)(d_members + m2), flag);
     int64_t m3 = 0;
     rc = select_core(c, B_pts, nrm ? B_nrm : nullptr, m2, flag, C_pts, C_nrm, &m3);
     if (rc) return rc;
     if (stage_counts) stage_counts[2] = m3;
+    if (m3 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }  // every label was noise
     // ---- statistical outlier filter: mean distance to the k nearest on the device, Open3D's global step on the host
     // in index order (cloud_ops.statistical_outlier_indices: sequential sums), the cut again on the device
     if (m3 > KNN_SMALL_MAX) {
