@@ -13,10 +13,24 @@
 // window column in registers for its four outputs.  Compulsory traffic is 8 B per pixel (4 in,
 // 4 out): the erode kernel is HBM-bound, the bilateral kernel is bound by its 25 exp per pixel.
 #include "pedp_internal.h"
+#include <algorithm>
 
 namespace {
 
-constexpr int TILE_W = 64, TILE_H = 16, STRIP = 4;
+// Camera frames (a few hundred workgroups in all) take 64 x 16 tiles, a thread owning 4 rows; the tiles are handed out
+// so that every XCD works through one contiguous run of them (workgroup i runs on XCD i % 8).  Large images take the
+// band walkers further down.
+constexpr int WIDE_PIXELS = 1 << 20;  // images from here on take the band walkers
+
+// tile origin of this workgroup: tiles in row-major order, dealt to the XCDs in eight contiguous runs
+__device__ __forceinline__ bool tile_origin(int tiles_x, int tiles_total, int tile_w, int tile_h, int &x0, int &y0) {
+    const int per = (tiles_total + 7) >> 3, logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= tiles_total) return false;
+    const int ty = logical / tiles_x;
+    x0 = (logical - ty * tiles_x) * tile_w;
+    y0 = ty * tile_h;
+    return true;
+}
 
 struct StencilArgs {
     int H, W, radius;
@@ -40,11 +54,35 @@ __device__ __forceinline__ float erode_finish(float d_ori, float bad, float tota
 // window size is the closed-form count of in-image pixels.  Centres that are NaN or infinite --
 // where |v - d| is NaN -- count by class instead: a NaN centre makes exactly the invalid readings
 // bad, an infinite centre everything that is not NaN.
-template <int R>
-__global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ depth, float *__restrict__ out, StencilArgs p) {
-    constexpr int TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
+// bad += the number of the five differences beyond thr.  The compares are issued together into five mask registers and
+// counted afterwards: a compare's mask may not be read by the next two instructions on gfx950, and with one mask
+// register per compare the compiler's schedule was compare, two idle slots, count (a third of the issue slots idle).
+// Ten instructions for five tests; two tests share one add-with-carry.
+__device__ __forceinline__ void count5_beyond(int &bad, float d0, float d1, float d2, float d3, float d4, float thr) {
+    unsigned long long m0, m1, m2, m3;
+    int x0, x2;
+    asm("v_cmp_gt_f32_e64 %[m0], |%[d0]|, %[t]\n\t"
+        "v_cmp_gt_f32_e64 %[m1], |%[d1]|, %[t]\n\t"
+        "v_cmp_gt_f32_e64 %[m2], |%[d2]|, %[t]\n\t"
+        "v_cmp_gt_f32_e64 %[m3], |%[d3]|, %[t]\n\t"
+        "v_cmp_gt_f32_e64 vcc, |%[d4]|, %[t]\n\t"
+        "v_cndmask_b32_e64 %[x0], 0, 1, %[m0]\n\t"
+        "v_addc_co_u32_e64 %[bad], %[m1], %[bad], %[x0], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[x2], 0, 1, %[m2]\n\t"
+        "v_addc_co_u32_e64 %[bad], %[m3], %[bad], %[x2], %[m3]\n\t"
+        "v_addc_co_u32_e32 %[bad], vcc, 0, %[bad], vcc"
+        : [bad] "+v"(bad), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [x0] "=&v"(x0), [x2] "=&v"(x2)
+        : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [d4] "v"(d4), [t] "s"(thr)
+        : "vcc");
+}
+
+template <int R, int TILE_W, int STRIP>
+__global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ depth, float *__restrict__ out, StencilArgs p, int tiles_x,
+                                                    int tiles_total) {
+    constexpr int TILE_H = (256 / TILE_W) * STRIP, TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
     __shared__ float tile[TH][TW];
-    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    int x0, y0;
+    if (!tile_origin(tiles_x, tiles_total, TILE_W, TILE_H, x0, y0)) return;  // workgroup-uniform
     const float inf = __builtin_inff(), nan = __builtin_nanf("");
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW, gy = y0 + ty - R, gx = x0 + tx - R;
@@ -56,7 +94,7 @@ __global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ de
         tile[ty][tx] = v;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
     const int x = x0 + lx, ys = y0 + ly * STRIP;
     if (x >= p.W) return;
     float d_ori[STRIP];
@@ -76,12 +114,20 @@ __global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ de
         for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];  // NaN outside the image
 #pragma unroll
         for (int j = 0; j < STRIP; ++j) {
+            if constexpr (R == 2)
+                count5_beyond(bad[j], col[j] - d_ori[j], col[j + 1] - d_ori[j], col[j + 2] - d_ori[j], col[j + 3] - d_ori[j],
+                              col[j + 4] - d_ori[j], p.a);
+            else {
 #pragma unroll
-            for (int dv = -R; dv <= R; ++dv) bad[j] += (fabsf(col[j + dv + R] - d_ori[j]) > p.a) ? 1 : 0;
+                for (int dv = -R; dv <= R; ++dv) bad[j] += (fabsf(col[j + dv + R] - d_ori[j]) > p.a) ? 1 : 0;
+            }
         }
     }
     // NaN / infinite centres (rare; the branch is taken by a wave only if one of its lanes has one)
-    if (cls[0] | cls[1] | cls[2] | cls[3]) {
+    int any_cls = 0;
+#pragma unroll
+    for (int j = 0; j < STRIP; ++j) any_cls |= cls[j];
+    if (any_cls) {
 #pragma unroll
         for (int j = 0; j < STRIP; ++j) {
             if (cls[j] == 0) continue;
@@ -100,6 +146,135 @@ __global__ __launch_bounds__(256) void erode_kernel(const float *__restrict__ de
         if (y >= p.H) continue;
         const int rows = min(y + R, p.H - 1) - max(y - R, 0) + 1;
         out[(size_t)y * p.W + x] = erode_finish(d_ori[j], (float)bad[j], (float)(rows * cols), p.b);
+    }
+}
+
+// Large images: a workgroup WALKS down a band of 64 columns, 16 rows a step.  The rows of the band live in a ring of
+// four 16-row slots in LDS (the step's block, the one above, the one below, and the slot the next block is being
+// written to), so every image row is fetched once per band -- no halo rows -- and the next block's loads are in flight
+// while the current block is counted: one barrier per step, nothing waits for memory but the prologue.  The bands are
+// dealt to the XCDs in eight contiguous runs (workgroup i runs on XCD i % 8), neighbouring bands walk in step, and the
+// two halo columns either side come out of the XCD's L2.  Per step and thread: five loads for the ring, four centre
+// readings for the next step (the ring holds the staged values -- invalid readings as +inf -- and an invalid centre
+// needs the reading itself), the 4 x 25 tests of its 1 x 4 strip, four stores.
+constexpr int WALK_W = 64, WALK_BH = 16, WALK_SLOTS = 4, WALK_STRIP = 4;
+struct WalkArgs { int bands, segs, seg_rows; };
+
+__device__ __forceinline__ bool walk_origin(const WalkArgs &w, int H, int &x0, int &ys0, int &ys1) {
+    const int n = w.bands * w.segs, per = (n + 7) >> 3, logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= n) return false;
+    const int band = logical / w.segs, seg = logical - band * w.segs;  // band-major: an XCD's run is whole bands
+    x0 = band * WALK_W;
+    ys0 = seg * w.seg_rows;
+    ys1 = min(ys0 + w.seg_rows, H);
+    return ys0 < H;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void erode_walk_kernel(const float *__restrict__ depth, float *__restrict__ out, StencilArgs p,
+                                                         WalkArgs w) {
+    constexpr int TW = WALK_W + 2 * R, NL = (WALK_BH * TW + 255) / 256, STRIP = WALK_STRIP, RING = WALK_SLOTS * WALK_BH;
+    static_assert(R <= WALK_BH && (RING & (RING - 1)) == 0, "halo within one block, ring a power of two");
+    __shared__ float ring[RING][TW];
+    int x0, ys0, ys1;
+    if (!walk_origin(w, p.H, x0, ys0, ys1)) return;  // workgroup-uniform
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
+    const int n_blocks = (ys1 - ys0 + WALK_BH - 1) / WALK_BH;
+    // element e of a block: row e / TW, column e % TW of the band with its halo columns
+    auto fetch = [&](int b, float (&v)[NL]) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = (int)threadIdx.x + 256 * i, row = e / TW, col = e - row * TW;
+            const int g = ys0 + WALK_BH * b + row, gx = x0 - R + col;
+            const bool need = e < WALK_BH * TW && g >= max(ys0 - R, 0) && g < min(ys1 + R, p.H) && gx >= 0 && gx < p.W;
+            v[i] = need ? depth[(size_t)g * p.W + gx] : nan;  // outside the image (or of no use to this segment): NaN
+        }
+    };
+    auto park = [&](int b, const float (&v)[NL]) {  // block b (-1 ..) lives in slot (b + 1) % 4
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = (int)threadIdx.x + 256 * i, row = e / TW, col = e - row * TW;
+            if (e < WALK_BH * TW) ring[((b + 1) * WALK_BH + row) & (RING - 1)][col] = (v[i] < 0.001f || v[i] >= p.zfar) ? inf : v[i];
+        }
+    };
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx;
+    const bool mine = x < p.W;
+    auto centres = [&](int b, float (&d)[STRIP]) {
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+            const int y = ys0 + WALK_BH * b + ly * STRIP + j;
+            d[j] = (mine && y < ys1) ? depth[(size_t)y * p.W + x] : 0.0f;
+        }
+    };
+    float d_ori[STRIP];
+    {
+        float va[NL], vb[NL], vc[NL];
+        fetch(-1, va); fetch(0, vb); fetch(1, vc);
+        centres(0, d_ori);
+        park(-1, va); park(0, vb); park(1, vc);
+    }
+    __syncthreads();
+    const int cols = min(x + R, p.W - 1) - max(x - R, 0) + 1;
+    // bad / total > ratio is monotone in the count: for the full window the division is done once per thread -- the
+    // smallest count that passes -- and every interior pixel compares integers (a float division is a dozen lane-ops)
+    constexpr int FULL = (2 * R + 1) * (2 * R + 1);
+    int full_from = FULL + 1;
+    for (int n = FULL; n >= 0; --n)
+        if ((float)n / (float)FULL > p.b) full_from = n;
+    for (int b = 0; b < n_blocks; ++b) {
+        float nv[NL], d_next[STRIP];
+        const bool more = b + 2 <= n_blocks;  // block n_blocks holds the halo rows below the segment
+        if (more) fetch(b + 2, nv);
+        if (b + 1 < n_blocks) centres(b + 1, d_next);
+        int bad[STRIP], any_cls = 0;
+        const int base = (b + 1) * WALK_BH + ly * STRIP - R;  // ring row of the strip's first window row
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+            bad[j] = 0;
+            any_cls |= (d_ori[j] != d_ori[j] || fabsf(d_ori[j]) == inf) ? 1 : 0;
+        }
+#pragma unroll
+        for (int du = -R; du <= R; ++du) {
+            float col[STRIP + 2 * R];
+#pragma unroll
+            for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = ring[(base + k) & (RING - 1)][lx + du + R];
+#pragma unroll
+            for (int j = 0; j < STRIP; ++j) {
+                if constexpr (R == 2)
+                    count5_beyond(bad[j], col[j] - d_ori[j], col[j + 1] - d_ori[j], col[j + 2] - d_ori[j], col[j + 3] - d_ori[j],
+                                  col[j + 4] - d_ori[j], p.a);
+                else {
+#pragma unroll
+                    for (int dv = -R; dv <= R; ++dv) bad[j] += (fabsf(col[j + dv + R] - d_ori[j]) > p.a) ? 1 : 0;
+                }
+            }
+        }
+        if (any_cls) {  // NaN / infinite centres count by class (erode_kernel)
+#pragma unroll
+            for (int j = 0; j < STRIP; ++j) {
+                const int cls = (d_ori[j] != d_ori[j]) ? 1 : (fabsf(d_ori[j]) == inf ? 2 : 0);
+                if (cls == 0) continue;
+                int n = 0;
+                for (int du = -R; du <= R; ++du)
+                    for (int dv = -R; dv <= R; ++dv) {
+                        const float v = ring[(base + j + dv + R) & (RING - 1)][lx + du + R];
+                        n += (cls == 1) ? (v == inf) : (v == v);
+                    }
+                bad[j] = n;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) {
+            const int y = ys0 + WALK_BH * b + ly * STRIP + j;
+            if (!mine || y >= ys1) continue;
+            const int rows = min(y + R, p.H - 1) - max(y - R, 0) + 1;
+            out[(size_t)y * p.W + x] = rows * cols == FULL ? (bad[j] >= full_from ? 0.0f : d_ori[j])
+                                                           : erode_finish(d_ori[j], (float)bad[j], (float)(rows * cols), p.b);
+        }
+        if (more) park(b + 2, nv);  // slot (b + 3) % 4: no one reads it in this step
+#pragma unroll
+        for (int j = 0; j < STRIP; ++j) d_ori[j] = d_next[j];
+        __syncthreads();
     }
 }
 
@@ -130,25 +305,22 @@ __device__ __forceinline__ float bilateral_weight(int du, int dv, float centre, 
     return expf(__fsub_rn(a, b));
 }
 
-template <int R>
+template <int R, int TILE_W, int STRIP>
 __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict__ depth, float *__restrict__ out,
-                                                        StencilArgs p) {
-    constexpr int TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
+                                                        StencilArgs p, int tiles_x, int tiles_total) {
+    constexpr int TILE_H = (256 / TILE_W) * STRIP, TW = TILE_W + 2 * R, TH = TILE_H + 2 * R;
     __shared__ float tile[TH][TW];
-    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    int x0, y0;
+    if (!tile_origin(tiles_x, tiles_total, TILE_W, TILE_H, x0, y0)) return;  // workgroup-uniform
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW, gy = y0 + ty - R, gx = x0 + tx - R;
         tile[ty][tx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? depth[(size_t)gy * p.W + gx] : 0.0f;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
     const int x = x0 + lx, ys = y0 + ly * STRIP;
     if (x >= p.W) return;
     const float two_sd2 = __fmul_rn(__fmul_rn(2.0f, p.a), p.a), two_sr2 = __fmul_rn(__fmul_rn(2.0f, p.b), p.b);
-    // The weight is expf(a - b), a = -(du^2 + dv^2) / 2 sigmaD^2 one of a few constants, b = dc^2 / 2 sigmaR^2.
-    // Whenever b is below a quarter of an ulp of a, the float32 subtraction returns a itself and the
-    // weight is the constant expf(a): no division, no exponential -- and the same bits.  With the
-    // reference's sigmaR = 1e5 that is every tap but the centre one (a = 0).
     constexpr int KMAX = 2 * R * R;
     float wa[KMAX + 1], ww[KMAX + 1], wthr[KMAX + 1];
 #pragma unroll
@@ -161,10 +333,10 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     int nv[STRIP];
 #pragma unroll
     for (int j = 0; j < STRIP; ++j) { mean[j] = 0.f; nv[j] = 0; }
+    // a pixel outside the image is staged as 0, an invalid reading: both passes skip it like the reference's bounds
+    // tests do, without testing bounds per tap
 #pragma unroll
     for (int du = -R; du <= R; ++du) {
-        const int u = x + du;
-        if (u < 0 || u >= p.W) continue;
         float col[STRIP + 2 * R];
 #pragma unroll
         for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
@@ -172,8 +344,6 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
         for (int j = 0; j < STRIP; ++j) {
 #pragma unroll
             for (int dv = -R; dv <= R; ++dv) {
-                const int v = ys + j + dv;
-                if (v < 0 || v >= p.H) continue;
                 const float cur = col[j + dv + R];
                 if (depth_valid(cur, p.zfar)) { ++nv[j]; mean[j] = __fadd_rn(mean[j], cur); }
             }
@@ -188,8 +358,6 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int du = -R; du <= R; ++du) {
-        const int u = x + du;
-        if (u < 0 || u >= p.W) continue;
         float col[STRIP + 2 * R];
 #pragma unroll
         for (int k = 0; k < STRIP + 2 * R; ++k) col[k] = tile[ly * STRIP + k][lx + du + R];
@@ -197,10 +365,8 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
         for (int j = 0; j < STRIP; ++j) {
 #pragma unroll
             for (int dv = -R; dv <= R; ++dv) {
-                const int v = ys + j + dv;
-                if (v < 0 || v >= p.H) continue;
                 const float cur = col[j + dv + R];
-                if (nv[j] && depth_valid(cur, p.zfar) && fabsf(__fsub_rn(cur, mean[j])) < 0.01f) {
+                if (depth_valid(cur, p.zfar) && fabsf(__fsub_rn(cur, mean[j])) < 0.01f) {
                     const int kk = du * du + dv * dv;
                     const float dc = __fsub_rn(centre[j], cur);
                     const float w = __fmul_rn(dc, dc) < wthr[kk] ? ww[kk]
@@ -334,10 +500,21 @@ int run_stencil(pedp_ctx_t c, const float *depth, int H, int W, StencilArgs p, i
     float *d_out;
     rc = stage_in(c, depth, n, n, mem, &d_in, &d_out, out);
     if (rc) return rc;
-    const dim3 tiles((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H), rows((W + 63) / 64, (H + 3) / 4);
-#define PEDP_STENCIL(RV)                                                                                      \
-    if (MODE == 0) hipLaunchKernelGGL(erode_kernel<RV>, tiles, dim3(256), 0, c->stream, d_in, d_out, p);      \
-    else hipLaunchKernelGGL(bilateral_kernel<RV>, tiles, dim3(256), 0, c->stream, d_in, d_out, p)
+    const int tiles_x = (W + 63) / 64, tiles_total = tiles_x * ((H + 15) / 16);
+    const dim3 tiles(8u * (unsigned)((tiles_total + 7) / 8)), rows((W + 63) / 64, (H + 3) / 4);
+    // large images: bands of 64 columns cut into segments so that about eight workgroups stand on every CU
+    WalkArgs wk;
+    wk.bands = tiles_x;
+    const int blocks = (H + WALK_BH - 1) / WALK_BH;
+    wk.segs = std::max(1, std::min(blocks, (2048 + wk.bands - 1) / wk.bands));
+    wk.seg_rows = WALK_BH * ((blocks + wk.segs - 1) / wk.segs);
+    wk.segs = (H + wk.seg_rows - 1) / wk.seg_rows;
+    const dim3 walkers(8u * (unsigned)((wk.bands * wk.segs + 7) / 8));
+    const bool walk = MODE == 0 && n >= (size_t)WIDE_PIXELS;
+#define PEDP_STENCIL(RV)                                                                                                                \
+    if (walk) hipLaunchKernelGGL(erode_walk_kernel<RV>, walkers, dim3(256), 0, c->stream, d_in, d_out, p, wk);                            \
+    else if (MODE == 0) hipLaunchKernelGGL((erode_kernel<RV, 64, 4>), tiles, dim3(256), 0, c->stream, d_in, d_out, p, tiles_x, tiles_total); \
+    else hipLaunchKernelGGL((bilateral_kernel<RV, 64, 4>), tiles, dim3(256), 0, c->stream, d_in, d_out, p, tiles_x, tiles_total)
     switch (p.radius) {
         case 1: PEDP_STENCIL(1); break;
         case 2: PEDP_STENCIL(2); break;

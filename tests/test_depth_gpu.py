@@ -51,6 +51,21 @@ def test_stencils_match_oracle(ctx, oracle, shape, radius):
     _close(compat.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005), oracle.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005))
 
 
+@pytest.mark.parametrize("radius", [1, 2, 4])
+def test_stencils_on_a_large_image(ctx, oracle, radius):
+    """Images of a million pixels and more take the wide tiles (256 x 16, dealt to the XCDs in contiguous bands); sizes
+    that are no multiple of the tile, invalid readings, NaN and infinities included."""
+    from pedp_hip import compat, synth
+
+    d = np.tile(synth.depth_image(576, 640, seed=11 + radius), (2, 2))[:1100, :1111].copy()
+    assert d.size >= 1 << 20
+    d[5, 7] = np.inf; d[700, 1110] = -np.inf; d[1099, 0] = np.nan; d[300:303, 255:258] = 0.0
+    _same(compat.erode_depth(d, radius), oracle.erode_depth(d, radius))
+    _same(compat.erode_depth(d, radius, 0.004, 0.3, 0.9), oracle.erode_depth(d, radius, 0.004, 0.3, 0.9))
+    _close(compat.bilateral_filter_depth(d, radius), oracle.bilateral_filter_depth(d, radius))
+    _close(compat.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005), oracle.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005))
+
+
 def test_back_projection_and_chain(ctx, oracle):
     from pedp_hip import compat, synth
 
