@@ -58,12 +58,13 @@ def get_rotation_matrix_from_xyz(rotation):
 
 
 def _fingerprint(pts, nrm):
-    """Cheap identity of a holder's arrays: the arrays themselves (id, address, shape) and 32 sampled rows, so that a
-    holder whose points were replaced (transform assigns new arrays) or rewritten in place is uploaded again."""
+    """Cheap identity of a holder's arrays: their memory (address, shape) and 32 sampled rows, so that a holder whose
+    points were replaced (transform assigns new arrays) or rewritten in place is uploaded again.  Not the array
+    OBJECTS: the holder's accessors hand out a fresh view of the same memory on every call."""
     step = max(len(pts) // 32, 1)
-    key = (id(pts), pts.ctypes.data, pts.shape, pts[::step].tobytes())
+    key = (pts.ctypes.data, pts.shape, pts[::step].tobytes())
     if nrm is not None:
-        key += (id(nrm), nrm.ctypes.data, nrm[::step].tobytes())
+        key += (nrm.ctypes.data, nrm[::step].tobytes())
     return key
 
 
