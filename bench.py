@@ -400,9 +400,13 @@ def run(args):
             except OSError:
                 pass
         trace_us = None     # the same kernel in the committed rocprofv3 kernel trace of this command
-        for name in ("r02_bench_kernel_stats_v5.csv", "r03_bench_kernel_stats.csv"):   # the newest one present wins
+        import glob, re
+        stats = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats_v*.csv"))
+                 if re.search(r"r(\d+)_bench_kernel_stats_v(\d+)\.csv$", p)]
+        stats.sort(key=lambda p: tuple(int(g) for g in re.search(r"r(\d+)_bench_kernel_stats_v(\d+)\.csv$", p).groups()))
+        for name in stats[-1:]:   # the newest round / version committed
             try:
-                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                with open(name) as fh:
                     for row in csv.DictReader(fh):
                         if "icp_pass_kernel<8, false>" in row["Name"]:
                             trace_us = float(row["AverageNs"]) / 1e3
