@@ -14,15 +14,20 @@ One STEP = one frame of the hot path with inputs resident in HBM:
 The two stages are independent (scene cloud vs mesh): each runs on its own context and HIP
 stream and they overlap on the device; a step ends when both have finished.
 
-N > 1, --mode shard (default; SURVEY s8e, north_star): ONE frame is split over the ranks --
+N > 1, --mode replica (default): the path's independent units are FRAMES -- every rank processes its own whole
+frame, no data-path collective (weak scaling; value = frames of all ranks x rays / time).  A camera frame's ray stage
+is 0.05 ms and its registration is a chain of 21 dependent 33-us passes: neither pays for a collective, so
+splitting ONE such frame over GPUs cannot speed it up, and the job scales by frames.  The one-frame split is
+still built, tested (tests/test_compat_gpu.py, two ranks) and timed beside the headline ("frame_sharded"):
+--mode shard (north_star) makes it the headline: ONE frame is split over the ranks --
 rays in contiguous blocks with an all-gather of the 8-byte hit records (RCCL over xGMI, issued by the
-library on its own stream).  The frame's ONE registration is replicated on every rank for scenes below
+library on its own stream); it is the right shape for BASELINE config 4 ("bench_1m": a million triangles, a dense
+full-frame heat map).  The frame's ONE registration is replicated on every rank for scenes below
 a million points (a pass is ~35 us: 21 all-reduces cost more than they save; every rank gets the identical
 pose without a collective); larger scenes are sharded with one 29-double all-reduce per pass, and that
 variant is timed beside it ("icp_scene_sharded").  The ICP lever across GPUs at these sizes is the pose
-batch (BASELINE config 3): "icp_batched" shards 32 start poses over the ranks.  Total work is fixed: strong scaling.
---mode replica: every rank processes its own whole frame, no collective (weak scaling); in shard
-mode the replica rate of the same ranks is measured too and reported under "replica".
+batch (BASELINE config 3): "icp_batched" shards 32 start poses over the ranks.  Total work is fixed: strong scaling;
+in shard mode the replica rate of the same ranks is measured too and reported under "replica".
 
 Timed regions, each bracketed by barrier + synchronize, max over ranks:
     headline     K steps of the default path (triangle-driven ray stage, chunked ICP: one launch per pass)
@@ -72,7 +77,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="bench_100k")
-    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
+    ap.add_argument("--mode", choices=["shard", "replica"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exhaustive / batched / 1M-triangle regions")
     return ap.parse_args()
@@ -216,7 +221,7 @@ def run(args):
 
     # ---- the same frame sharded over the ranks (strong scaling)
     sharded = None
-    if mode == "shard":
+    if world > 1:   # built in both modes: the headline of one, a timed region beside the headline of the other
         sharded = pdist.ShardedFrame(ray_be, frame.verts_posed, frame.tris, frame.rays6, scene, frame.model_points,
                                      frame.normals, icp_backend=icp_be)
 
@@ -306,9 +311,12 @@ def run(args):
         if mode == "shard":
             rp_elapsed, _, rp_rows = timed_region(step_whole, args.steps, 1)
             extras["replica"] = (rp_elapsed, rp_rows)
-            if replicate_icp:   # the scene-sharded registration (one all-reduce per pass) beside the replicated one
-                ss_elapsed, ss_res, ss_rows = timed_region(lambda: step_sharded(True), max(2, min(args.steps, 4)), 1)
-                extras["scene_sharded"] = (max(2, min(args.steps, 4)), ss_elapsed, ss_res, ss_rows)
+        elif mode == "replica":   # ---- ONE frame split over the ranks (rays in blocks + all-gather), beside the headline
+            fs_elapsed, fs_res, fs_rows = timed_region(step_sharded, args.steps, 1)
+            extras["frame_sharded"] = (fs_elapsed, fs_res, fs_rows)
+        if world > 1 and replicate_icp:   # the scene-sharded registration (one all-reduce per pass) beside the replicated one
+            ss_elapsed, ss_res, ss_rows = timed_region(lambda: step_sharded(True), max(2, min(args.steps, 4)), 1)
+            extras["scene_sharded"] = (max(2, min(args.steps, 4)), ss_elapsed, ss_res, ss_rows)
         if world == 1:
             # ---- fresh_frame region: what a NEW camera frame costs -- scene handle from a device array with new
             # noise, new mesh pose, then the same ICP + cast
@@ -551,6 +559,15 @@ def run(args):
                 "note": "the same step with the registration's scene points sharded over the ranks and one 29-double all-reduce "
                         "per pass (SURVEY s8e row 2): the right shape for scenes of millions of points, slower than the "
                         "replicated registration at camera size"}
+        if "frame_sharded" in extras:
+            fs_elapsed, fs_res, fs_rows = extras["frame_sharded"]
+            out["frame_sharded"] = {
+                "value_mrays_per_s": n_rays * args.steps / fs_elapsed / 1e6, "scaling": "strong", "ms_per_step": 1e3 * fs_elapsed / args.steps,
+                "ray_stage_ms": float(fs_rows[:, 1].mean()), "icp_ms": float(fs_rows[:, 0].mean()),
+                "pose_equals_headline": bool(np.abs(fs_res["T"] - res["T"]).max() < 1e-9),
+                "note": f"ONE frame split over the {world} ranks: rays in contiguous blocks + all-gather of the hit records "
+                        f"({'library-issued RCCL' if native else 'torch.distributed'}), the registration replicated (camera-size scene); "
+                        "not the headline: a 0.05-ms ray stage does not pay for a collective"}
         if "replica" in extras:
             rp_elapsed, rp_rows = extras["replica"]
             out["replica"] = {"value_mrays_per_s": world * n_rays * args.steps / rp_elapsed / 1e6, "scaling": "weak",

@@ -100,6 +100,14 @@ def test_statistical_outlier_removal(ctx, oracle, k, ratio):
     rng = np.random.default_rng(3)
     clump = np.concatenate([big[:6000], big[100] + rng.normal(0, 1e-3, (2600, 3))])   # 2,600 points in one grid cell
     assert np.array_equal(cloud_ops.knn_mean_distance(clump, k), oracle.knn_mean_distance(clump, k))
+    # queries whose cube grows to the whole grid without k points within its reach (a handful of stragglers far along
+    # the diagonal from everything else), equal distances (a lattice: the selection's ties), duplicates of the query
+    far = np.concatenate([rng.normal([400.0, 400.0, 400.0], 6.0, (4200, 3)), rng.uniform(0.0, 3.0, (30, 3))])
+    assert np.array_equal(cloud_ops.knn_mean_distance(far, k), oracle.knn_mean_distance(far, k))
+    g = np.arange(17, dtype=np.float64)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)           # 4,913 points, many equal d^2
+    lattice = np.concatenate([lattice, lattice[:200]])                                          # and 200 exact duplicates
+    assert np.array_equal(cloud_ops.knn_mean_distance(lattice, k), oracle.knn_mean_distance(lattice, k))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 12345])

@@ -98,3 +98,23 @@ if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wv
     worst = np.argsort(-cs)[:8]
     for i in worst:
         print(f"   slowest cull+sweep {cs[i]:6.2f}: words {words[i]} batches {batches[i]} tiles {tiles[i]} wide {wide[i]} slots {slots[i]}")
+    # per workgroup: how much of its time is the spread of the sweep between its waves
+    g = wvb.copy()
+    ok = (g[:, :, 4] > 0) & (g[:, :, 2] > 0) & (g[:, :, 0] > g[:, :, 0].max() - 60 * mhz)
+    rows = []
+    for b in range(g.shape[0]):
+        m = ok[b]
+        if m.sum() < 2:
+            continue
+        t = g[b][m]
+        total = (t[:, 4] - t[:, 0]) * tick
+        sweep = (t[:, 2] - t[:, 8]) * tick
+        lists = (t[:, 8] - t[:, 1]) * tick
+        rows.append((total.max(), total.mean(), sweep.max(), sweep.mean(), (total - sweep).max() + sweep.mean(), lists.max(), lists.mean(), m.sum()))
+    if rows:
+        r = np.array(rows)
+        print(f"workgroups with per-wave stamps: {len(r)}; waves each median {np.median(r[:,7]):.0f}")
+        print(f"   slowest wave of a workgroup: median {np.median(r[:,0]):.2f} max {r[:,0].max():.2f} | mean wave: median {np.median(r[:,1]):.2f} max {r[:,1].max():.2f}")
+        print(f"   sweep: slowest wave median {np.median(r[:,2]):.2f} max {r[:,2].max():.2f} | mean median {np.median(r[:,3]):.2f} max {r[:,3].max():.2f}")
+        print(f"   if the sweep were shared evenly inside a workgroup: slowest wave median {np.median(r[:,4]):.2f} max {r[:,4].max():.2f}")
+        print(f"   cover + lists: slowest wave median {np.median(r[:,5]):.2f} max {r[:,5].max():.2f} | mean median {np.median(r[:,6]):.2f}")
