@@ -506,7 +506,7 @@ int run_stencil(pedp_ctx_t c, const float *depth, int H, int W, StencilArgs p, i
     WalkArgs wk;
     wk.bands = tiles_x;
     const int blocks = (H + WALK_BH - 1) / WALK_BH;
-    wk.segs = std::max(1, std::min(blocks, (2048 + wk.bands - 1) / wk.bands));
+    wk.segs = std::max(1, std::min(blocks, (2048 + wk.bands - 1) / wk.bands));  // (1,024 to 8,192 workgroups measured alike)
     wk.seg_rows = WALK_BH * ((blocks + wk.segs - 1) / wk.segs);
     wk.segs = (H + wk.seg_rows - 1) / wk.seg_rows;
     const dim3 walkers(8u * (unsigned)((wk.bands * wk.segs + 7) / 8));

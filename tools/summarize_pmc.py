@@ -44,8 +44,9 @@ KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector 
     ("rast_item_kernel", "rast_item_kernel", True),
     ("rast_full_kernel", "rast_full_kernel", True),
     ("ray_finalize_kernel", "ray_finalize_kernel", True),
-    ("erode_kernel<2>", "erode_kernel", True),
-    ("bilateral_kernel<2>", "bilateral_kernel", True),
+    ("erode_walk_kernel<2>", "erode_walk_kernel", True),
+    ("erode_kernel<2", "erode_kernel", True),
+    ("bilateral_kernel<2", "bilateral_kernel", True),
     ("xyzmap_kernel", "xyzmap_kernel", True),
 )
 out = {}
