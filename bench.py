@@ -26,7 +26,7 @@ full-frame heat map).  The frame's ONE registration is replicated on every rank 
 a million points (a pass is ~35 us: 21 all-reduces cost more than they save; every rank gets the identical
 pose without a collective); larger scenes are sharded with one 29-double all-reduce per pass, and that
 variant is timed beside it ("icp_scene_sharded").  The ICP lever across GPUs at these sizes is the pose
-batch (BASELINE config 3): "icp_batched" shards 32 start poses over the ranks.  Total work is fixed: strong scaling;
+batch (BASELINE config 3): "icp_batched" shards its 256 start poses over the ranks.  Total work is fixed: strong scaling;
 in shard mode the replica rate of the same ranks is measured too and reported under "replica".
 
 Timed regions, each bracketed by barrier + synchronize, max over ranks:
@@ -370,8 +370,8 @@ def run(args):
             chain.process(depth_k[0], init_pose(), heat, seed=0, timed=True)     # stage times, outside the timed region
             extras["frame_chain"] = (fc_steps, fc_elapsed, fc_res, dict(chain.stage_ms))
             viewer_wire.attach_queues(None)
-        # ---- BASELINE config 3 in small: 32 start poses refined concurrently, poses sharded over the ranks
-        inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(32)])
+        # ---- BASELINE config 3: 256 start poses refined concurrently (groups of 32 share launches), poses sharded over the ranks
+        inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(256)])
         lo, hi = pdist.shard_bounds(len(inits), rank, world)
         batch_s = []
         for _ in range(3):
