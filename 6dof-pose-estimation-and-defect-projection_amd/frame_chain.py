@@ -30,8 +30,9 @@ class FrameChain:
         self.proj = FrameProjector(self.mesh, intrinsic, self.color_to_depth)
         self.K32 = torch.as_tensor(np.asarray(K32, np.float32), device="cuda")[None]
         self.heat_threshold = heat_threshold
-        self.host_pts = None      # pinned, lives across frames: a pageable destination makes the runtime pin and unpin
-        self.stage_ms = {}        # 9 MB per frame, which holds up the next submissions by 20-30 ms (DESIGN s6)
+        self.host_pts = [None, None]  # pinned, live across frames: a pageable destination makes the runtime pin and unpin
+        self.frame_no = 0             # 9 MB per frame, which holds up the next submissions by 20-30 ms (DESIGN s6); TWO of
+        self.stage_ms = {}            # them in turn, so a frame's scene cloud stays valid while the next one is written
 
     def process(self, depth_m, init, heat, seed=0, device_scene=False, timed=False):
         """One frame.  depth_m: H x W float32 metres (numpy or CUDA tensor); init: start pose scene -> model (mm);
@@ -55,11 +56,13 @@ class FrameChain:
         if device_scene:
             source, pts = PointCloud(dev_pts), None
         else:
-            if self.host_pts is None or len(self.host_pts) < len(dev_pts):
-                self.host_pts = torch.empty((max(len(dev_pts), d.numel()), 3), dtype=torch.float64, pin_memory=True)
-            self.host_pts[: len(dev_pts)].copy_(dev_pts)
-            pts = self.host_pts[: len(dev_pts)].numpy().copy()
-            source = PointCloud(pts)
+            k = self.frame_no & 1
+            self.frame_no += 1
+            if self.host_pts[k] is None or len(self.host_pts[k]) < len(dev_pts):
+                self.host_pts[k] = torch.empty((max(len(dev_pts), d.numel()), 3), dtype=torch.float64, pin_memory=True)
+            self.host_pts[k][: len(dev_pts)].copy_(dev_pts)
+            pts = self.host_pts[k][: len(dev_pts)].numpy()   # the pinned array itself (no second 9-MB copy): valid until
+            source = PointCloud(pts)                         # the frame after next is processed
         lap("scene cloud")
         np.random.seed(seed)
         _, icp, z, _ = compat.refine_pose_with_icp(source, self.model, None, init, self.params)   # run.py:95-99
