@@ -66,6 +66,17 @@ def test_stencils_on_a_large_image(ctx, oracle, radius):
     _close(compat.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005), oracle.bilateral_filter_depth(d, radius, 0.8, 1.0, 0.005))
 
 
+@pytest.mark.parametrize("shape", [(1, 1 << 20), (1 << 20, 1), (3, 350000), (70000, 15)])
+def test_band_walker_on_extreme_shapes(ctx, oracle, shape):
+    """The large-image erode kernel on images that are one band wide, one block high, or thinner than its halo."""
+    from pedp_hip import compat, synth
+
+    base = synth.depth_image(576, 640, seed=5)
+    d = np.resize(base, shape).astype(np.float32)
+    _same(compat.erode_depth(d, 2), oracle.erode_depth(d, 2))
+    _same(compat.erode_depth(d, 3, 0.004, 0.3, 0.9), oracle.erode_depth(d, 3, 0.004, 0.3, 0.9))
+
+
 def test_back_projection_and_chain(ctx, oracle):
     from pedp_hip import compat, synth
 
