@@ -2088,10 +2088,29 @@ struct Sort64Layout {
     void *tmp;
     size_t tmp_bytes;
 };
+// The keys are Hilbert indices, most significant level first: their top 3 b bits are the index at b bits per axis.
+// Only as many levels are sorted on as tell the points apart -- b = ceil(log2(N) / 3) + 1 bits per axis, a few
+// points per cell; inside a cell the stable sort keeps the point order -- because the radix passes' number follows
+// the bits (a 368 k-point frame: 24 bits, three passes, instead of six for all 48).  Large inputs take rocPRIM's radix
+// passes, small ones its merge sort (fewer, shorter launches below ~10^5 items).
+struct SortPlan { int begin_bit, end_bit; bool passes; };
+SortPlan sort_plan(int64_t N, int bits) {
+    int lg = 0;
+    while (lg < 62 && ((int64_t)1 << lg) < N) ++lg;
+    int per_axis = (lg + 2) / 3 + 1;
+    per_axis = per_axis < 5 ? 5 : per_axis;
+    const int used = 3 * per_axis < bits ? 3 * per_axis : bits;
+    return {bits - used, bits, N >= 131072};
+}
 int sort64_layout(pedp_ctx_t c, int64_t N, int bits, Sort64Layout &L) {
     size_t tmp_sort = 0;
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                           (int *)nullptr, (int *)nullptr, (unsigned)N, 0, bits, c->stream));
+    const SortPlan sp = sort_plan(N, bits);
+    if (sp.passes)
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs<RadixPasses>(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                                            (int *)nullptr, (int *)nullptr, (unsigned)N, sp.begin_bit, sp.end_bit, c->stream));
+    else
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr,
+                                               (int *)nullptr, (unsigned)N, sp.begin_bit, sp.end_bit, c->stream));
     const size_t need = 2 * a256(sizeof(unsigned long long) * N) + a256(sizeof(int) * N) + a256(tmp_sort) + 1024;
     int st = c->sort_ws.reserve(need);
     if (st) return st;
@@ -2117,8 +2136,13 @@ int pedp_sort_keys64_run(pedp_ctx_t c, int64_t N, int bits, int32_t *d_perm) {
     int st = sort64_layout(c, N, bits, L);  // same sizes as _begin: the scratch does not move
     if (st) return st;
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, L.val, N);
-    PEDP_ROCPRIM(rocprim::radix_sort_pairs(L.tmp, L.tmp_bytes, L.keys, L.keys_s, L.val, (int *)d_perm, (unsigned)N, 0, bits,
-                                           c->stream));
+    const SortPlan sp = sort_plan(N, bits);
+    if (sp.passes)
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs<RadixPasses>(L.tmp, L.tmp_bytes, L.keys, L.keys_s, L.val, (int *)d_perm, (unsigned)N,
+                                                            sp.begin_bit, sp.end_bit, c->stream));
+    else
+        PEDP_ROCPRIM(rocprim::radix_sort_pairs(L.tmp, L.tmp_bytes, L.keys, L.keys_s, L.val, (int *)d_perm, (unsigned)N, sp.begin_bit,
+                                               sp.end_bit, c->stream));
     PEDP_HIP_CHECK(hipGetLastError());
     return PEDP_OK;
 }
