@@ -133,6 +133,26 @@ int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
     return PEDP_OK;
 }
 
+// Several results that lie in ONE device block (parts i at src + off[i], bytes[i] long, dst[i] == nullptr: skipped) in one
+// copy through the pinned staging buffer and one wait, instead of a copy and a wait per result.  Blocks beyond the
+// staging buffer's limit go part by part.
+int pedp_download_parts(pedp_ctx_s *c, const void *src, size_t span, int n, const size_t *off, void *const *dst, const size_t *bytes) {
+    if (span == 0) return PEDP_OK;
+    if (span > STAGE_MAX) {
+        for (int i = 0; i < n; ++i)
+            if (dst[i]) { int rc = pedp_download(c, dst[i], (const char *)src + off[i], bytes[i]); if (rc) return rc; }
+        return PEDP_OK;
+    }
+    int rc = stage_reserve(c, 1, span);
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipMemcpyAsync(c->stage[1], src, span, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->stage_busy = false;
+    for (int i = 0; i < n; ++i)
+        if (dst[i]) memcpy(dst[i], (const char *)c->stage[1] + off[i], bytes[i]);
+    return PEDP_OK;
+}
+
 int pedp_scratch::reserve(size_t bytes) {
     if (bytes <= cap) return PEDP_OK;
     release();

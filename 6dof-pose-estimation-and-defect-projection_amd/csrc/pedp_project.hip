@@ -243,12 +243,16 @@ extern "C" int pedp_project_heatmap(pedp_ctx_t c, pedp_mesh_t mesh, const pedp_p
     hipLaunchKernelGGL(hit_scatter_kernel, dim3(n_blocks2), dim3(CP_THREADS), 0, c->stream, t_hit, ids, sel, d_heat, n_sel,
                        boff2, cm, origin[0], origin[1], origin[2], d_pts, d_int, d_pix, d_prim);
     PEDP_HIP_CHECK(hipGetLastError());
-    if (mem == PEDP_HOST) {
-        { int dn_ = pedp_download(c, points, d_pts, sizeof(double) * 3 * (size_t)n_hit); if (dn_) return dn_; }
-        { int dn_ = pedp_download(c, intensities, d_int, sizeof(double) * (size_t)n_hit); if (dn_) return dn_; }
-        if (pixels) { int dn_ = pedp_download(c, pixels, d_pix, sizeof(int32_t) * 2 * (size_t)n_hit); if (dn_) return dn_; }
-        if (prim_id) { int dn_ = pedp_download(c, prim_id, d_prim, sizeof(uint32_t) * (size_t)n_hit); if (dn_) return dn_; }
-        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (mem == PEDP_HOST) {  // the four results lie in one block: one copy, one wait
+        const size_t s_pts = a256(sizeof(double) * 3 * (size_t)n_hit), s_int = a256(sizeof(double) * (size_t)n_hit);
+        const size_t s_pix = a256(sizeof(int32_t) * 2 * (size_t)n_hit);
+        const size_t off[4] = {0, s_pts, s_pts + s_int, s_pts + s_int + s_pix};
+        void *const dst[4] = {points, intensities, pixels, prim_id};
+        const size_t bytes[4] = {sizeof(double) * 3 * (size_t)n_hit, sizeof(double) * (size_t)n_hit, sizeof(int32_t) * 2 * (size_t)n_hit,
+                                 sizeof(uint32_t) * (size_t)n_hit};
+        const size_t span = prim_id ? off[3] + bytes[3] : (pixels ? off[2] + bytes[2] : off[1] + bytes[1]);
+        int dn_ = pedp_download_parts(c, ob.ptr, span, 4, off, dst, bytes);
+        if (dn_) return dn_;
     }
     return PEDP_OK;
 }
