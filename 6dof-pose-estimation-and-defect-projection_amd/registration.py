@@ -68,6 +68,14 @@ def _fingerprint(pts, nrm):
     return key
 
 
+def forget_device_copy(cloud):
+    """Drop a holder's kept device copy.  The key above notices a replaced array and a rewrite that touches the sampled
+    rows (any transform does); a caller that edits single rows of `points` in place between two registrations calls this
+    (or assigns a new array) to have the cloud uploaded again."""
+    if hasattr(cloud, "_device_copy"):
+        cloud._device_copy = None
+
+
 def upload(cloud, ctx=None):
     """Device copy of a PointCloud-like object; pass the returned handle to registration_icp
     when the same cloud is registered many times (improve_result does ~50 calls per frame).

@@ -159,6 +159,28 @@ def test_refine_pose_with_icp_from_raw_frame(oracle):
     assert len(moved.points) == len(f.model_points)
 
 
+def test_a_holder_keeps_its_device_copy_between_calls():
+    """reg.upload: the model cloud of a camera loop is uploaded, ordered and packed once -- the same handle comes back as
+    long as the holder's arrays are the same memory with the same (sampled) contents; a transform, a new array or
+    forget_device_copy make a new one."""
+    from pedp_hip import registration as reg, synth
+    from pedp_hip.compat import PointCloud
+
+    f = synth.Frame("parity")
+    cloud = PointCloud(f.model_points, normals=f.normals)
+    a = reg.upload(cloud)
+    assert reg.upload(cloud) is a and reg.upload(cloud) is a          # fresh views of the same arrays: the same handle
+    np.asarray(cloud.points)[:] += 1.0                                   # rewritten in place
+    b = reg.upload(cloud)
+    assert b is not a and reg.upload(cloud) is b
+    cloud.transform(np.eye(4))                                           # new arrays
+    c = reg.upload(cloud)
+    assert c is not b
+    reg.forget_device_copy(cloud)
+    assert reg.upload(cloud) is not c
+    assert reg.upload(a) is a                                            # a handle passes through
+
+
 def test_dist_hip_backend_single_rank(oracle):
     """pedp_hip.dist with the product backend on one GPU (no process group): same answers as
     the plain calls; exercises HipBackend (torch stream hand-over, device packet view)."""
