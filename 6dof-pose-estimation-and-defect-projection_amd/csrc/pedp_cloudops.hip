@@ -419,11 +419,12 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_mean_kernel(Grid g, const dou
                                                                const int *__restrict__ cell_start,
                                                                const int *__restrict__ cell_end,
                                                                const int *__restrict__ idx_sorted, int k,
-                                                               double *__restrict__ avg /* by original index */) {
+                                                               double *__restrict__ avg /* by original index */,
+                                                               const int *__restrict__ gate /* run only if *gate != 0 */) {
     extern __shared__ double top[];  // element r of thread t at top[r * KNN_THREADS + t]
     const int t = threadIdx.x;
     const int64_t j = (int64_t)blockIdx.x * KNN_THREADS + t;
-    if (j >= N) return;
+    if (j >= N || *gate == 0) return;
     const double p[3] = {sp[3 * j], sp[3 * j + 1], sp[3 * j + 2]};
     const int m = (int)(N < k ? N : k);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -1327,12 +1328,13 @@ int small_block(pedp_ctx_t c, double **d_part) {
 }
 
 int voxel_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N, double voxel_size, double **out_pts,
-               double **out_nrm, int64_t *n_out) {
+               double **out_nrm, int64_t *n_out, double *box_lo = nullptr, double *box_hi = nullptr) {
     double lo[3], hi[3], *d_part = nullptr;
     int rc = small_block(c, &d_part);
     if (rc) return rc;
     rc = bounds_device(c, d_pts, N, d_part, lo, hi);
     if (rc) return rc;
+    for (int k = 0; k < 3 && box_lo && box_hi; ++k) { box_lo[k] = lo[k]; box_hi[k] = hi[k]; }  // the averages lie inside it
     int bits[3];
     for (int k = 0; k < 3; ++k) {
         PEDP_REQUIRE(std::isfinite(lo[k]) && std::isfinite(hi[k]), "pedp_voxel_down_sample: non-finite coordinates");
@@ -1517,22 +1519,17 @@ int knn_core(pedp_ctx_t c, const double *d_pts, int64_t N, int k, const double l
     rc = grid_index_build(c, cv, d_pts, N, g, n_cells, tmp_sort, ix);
     if (rc) return rc;
     double *d_avg = cv.take<double>(N);
-    // a wave per query; a cloud too dense for the LDS share of some query falls back to a thread per query
-    int *d_over = (int *)ix.tmp;  // the sort is done: its scratch is free
-    int *h_over = (int *)((char *)c->pinned + 8192);
+    // a wave per query; a cloud too dense for the LDS share of some query falls back to a thread per query: that kernel
+    // is launched behind the first one and leaves at once unless the overflow flag is up (no trip to the host to ask)
+    int *d_over = (int *)ix.tmp;  // the scan is done: its scratch is free
     PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(knn_mean_wave_kernel, dim3((unsigned)((N + KNN_WPB - 1) / KNN_WPB)), dim3(KNN_WPB * 64), 0, c->stream, g, ix.sp, N,
                        ix.cell_start, ix.cell_end, ix.val_s, k, d_avg, d_over);
+    const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
+    PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream, g, ix.sp,
+                       N, ix.cell_start, ix.cell_end, ix.val_s, k, d_avg, (const int *)d_over);
     PEDP_HIP_CHECK(hipGetLastError());
-    PEDP_HIP_CHECK(hipMemcpyAsync(h_over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*h_over) {
-        const size_t lds = sizeof(double) * (size_t)k * KNN_THREADS;
-        PEDP_HIP_CHECK(hipFuncSetAttribute((const void *)knn_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)((N + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, c->stream, g,
-                           ix.sp, N, ix.cell_start, ix.cell_end, ix.val_s, k, d_avg);
-        PEDP_HIP_CHECK(hipGetLastError());
-    }
     *out_avg = d_avg;
     return PEDP_OK;
 }
@@ -1959,7 +1956,8 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     // ---- voxel grid
     double *v_pts = nullptr, *v_nrm = nullptr, *d_part = nullptr;
     int64_t m1 = 0;
-    rc = voxel_core(c, d_in, nullptr, N, prm->voxel_size, &v_pts, &v_nrm, &m1);
+    double box_lo[3], box_hi[3];  // of the input cloud: every later stage's points lie inside, so it can shape their grids
+    rc = voxel_core(c, d_in, nullptr, N, prm->voxel_size, &v_pts, &v_nrm, &m1, box_lo, box_hi);
     if (rc) return rc;
     if (stage_counts) stage_counts[0] = m1;
     if (m1 < 3) { *status = PEDP_PREPROCESS_DEGENERATE; return PEDP_OK; }
@@ -1983,10 +1981,8 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     double lo[3], hi[3];
     // ---- normals of the down-sampled cloud (they orient the final ones)
     if (nrm) {
-        rc = bounds_device(c, A_pts, m1, d_part, lo, hi);
-        if (rc) return rc;
         double *n_out_d = nullptr;
-        rc = normals_core(c, A_pts, m1, prm->normal_radius, prm->normal_max_nn, nullptr, lo, hi, &n_out_d);
+        rc = normals_core(c, A_pts, m1, prm->normal_radius, prm->normal_max_nn, nullptr, box_lo, box_hi, &n_out_d);
         if (rc) return rc;
         PEDP_HIP_CHECK(hipMemcpyAsync(A_nrm, n_out_d, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
     }
@@ -2004,10 +2000,8 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     if (stage_counts) stage_counts[1] = m2;
     if (m2 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
     // ---- DBSCAN, largest cluster (np.unique + argmax: the lowest label among the largest)
-    rc = bounds_device(c, B_pts, m2, d_part, lo, hi);
-    if (rc) return rc;
-    int32_t *d_labels = nullptr;
-    rc = dbscan_core(c, B_pts, m2, prm->cluster_eps, prm->cluster_min_points, lo, hi, &d_labels);
+    int32_t *d_labels = nullptr;  // (the grid over the input's box: no trip to the host for this cloud's own)
+    rc = dbscan_core(c, B_pts, m2, prm->cluster_eps, prm->cluster_min_points, box_lo, box_hi, &d_labels);
     if (rc) return rc;
     PEDP_HIP_CHECK(hipMemsetAsync(d_members, 0, sizeof(int) * (size_t)(m2 + 1), c->stream));
     hipLaunchKernelGGL(label_count_kernel, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_labels, m2,
