@@ -1139,10 +1139,13 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     if ((int)threadIdx.x < nt && cnt_s[threadIdx.x]) atomicAdd(&counts[t0 + threadIdx.x], cnt_s[threadIdx.x]);
 }
 
-// the best iteration -- most inliers, the earliest on ties -- and its three sampled points, in one small block for the
-// host: out[0] = iteration (-1: no plane at all), out[1..9] = the points
+// the best iteration -- most inliers, the earliest on ties -- with its three sampled points and its plane (the one the
+// counts were taken with), in one small block: out[0] = iteration (-1: no plane at all), out[1..9] = the points,
+// out[10..13] = the plane.  The host-array entry reads the points back and forms the plane itself; the device-resident
+// chain hands the block to plane_keep_kernel and never asks.
 __global__ __launch_bounds__(256) void ransac_best_kernel(const int *__restrict__ counts, int n_iter, const double *__restrict__ pts,
-                                                          long long N, unsigned long long seed, double *__restrict__ out) {
+                                                          long long N, unsigned long long seed, const double *__restrict__ planes,
+                                                          double *__restrict__ out) {
     __shared__ int cnt_s[256], it_s[256];
     int bc = -1, bt = -1;
     for (int t = threadIdx.x; t < n_iter; t += 256)
@@ -1168,6 +1171,7 @@ __global__ __launch_bounds__(256) void ransac_best_kernel(const int *__restrict_
             sample3(seed, best, N, s);
             for (int q = 0; q < 3; ++q)
                 for (int k = 0; k < 3; ++k) out[1 + 3 * q + k] = pts[3 * s[q] + k];
+            for (int k = 0; k < 4; ++k) out[10 + k] = planes[4 * (size_t)best + k];
         }
     }
 }
@@ -1560,8 +1564,8 @@ int normals_core(pedp_ctx_t c, const double *d_pts, int64_t N, double radius, in
 
 // plane RANSAC: inlier counts of every iteration -> the best iteration (most inliers, earliest on ties) and its plane
 int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distance_threshold, int num_iterations, uint64_t seed,
-                    int *best_t, double best[4]) {
-    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + a256(sizeof(double) * (4 * (size_t)num_iterations + 16)) + 512);
+                    int *best_t, double best[4], double *d_keep = nullptr /* 14 doubles on the device: the result stays there */) {
+    int st = c->ops.reserve(a256(sizeof(int) * (size_t)num_iterations) + a256(sizeof(double) * (4 * (size_t)num_iterations + 32)) + 512);
     if (st) return st;
     int *d_cnt = (int *)c->ops.ptr;
     double *d_planes = (double *)((char *)c->ops.ptr + a256(sizeof(int) * (size_t)num_iterations));
@@ -1570,10 +1574,11 @@ int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distanc
     hipLaunchKernelGGL(ransac_count_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((num_iterations + RS_PLANES - 1) / RS_PLANES)),
                        dim3(256), 0, c->stream, d_pts, (long long)N, distance_threshold, num_iterations, (const double *)d_planes, d_cnt);
     PEDP_HIP_CHECK(hipGetLastError());
-    double *d_best = d_planes + 4 * (size_t)num_iterations, *h_best = (double *)((char *)c->pinned + 8192);
+    double *d_best = d_keep ? d_keep : d_planes + 4 * (size_t)num_iterations, *h_best = (double *)((char *)c->pinned + 8192);
     hipLaunchKernelGGL(ransac_best_kernel, dim3(1), dim3(256), 0, c->stream, (const int *)d_cnt, num_iterations, d_pts, (long long)N,
-                       (unsigned long long)seed, d_best);
+                       (unsigned long long)seed, (const double *)d_planes, d_best);
     PEDP_HIP_CHECK(hipGetLastError());
+    if (d_keep) return PEDP_OK;
     PEDP_HIP_CHECK(hipMemcpyAsync(h_best, d_best, sizeof(double) * 10, hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     const int bt = (int)h_best[0];
@@ -1627,6 +1632,14 @@ __global__ __launch_bounds__(256) void label_largest_kernel(const int *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) *label = lab_s[0];
+}
+// the same from the device block of ransac_best_kernel (no plane found: everything is kept)
+__global__ void plane_keep_best_kernel(const double *__restrict__ pts, int64_t N, const double *__restrict__ best, double thr,
+                                       unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double pl[4] = {best[10], best[11], best[12], best[13]};
+    flag[i] = (best[0] < 0.0 || !(plane_dist(pl, pts + 3 * i) < thr)) ? 1u : 0u;
 }
 __global__ void label_keep_kernel(const int32_t *__restrict__ labels, int64_t N, const int *__restrict__ label, unsigned *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1975,8 +1988,8 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     PEDP_HIP_CHECK(hipMemcpyAsync(A_pts, v_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
     // ---- table plane: the best of the sampled planes (the refit plane of segment_plane has no reader on this branch)
     int best_t = -1;
-    double best[4] = {0, 0, 0, 0};
-    rc = plane_best_core(c, A_pts, m1, prm->plane_distance, prm->plane_iterations, prm->seed, &best_t, best);
+    double best[4] = {0, 0, 0, 0}, *d_best = d_part + 6 * BND_BLOCKS;  // behind the partial bounds, untouched by the stages between
+    rc = plane_best_core(c, A_pts, m1, prm->plane_distance, prm->plane_iterations, prm->seed, &best_t, best, d_best);
     if (rc) return rc;
     double lo[3], hi[3];
     // ---- normals of the down-sampled cloud (they orient the final ones)
@@ -1988,15 +2001,10 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     }
     // ---- the plane's inliers removed (no plane found: nothing removed, like select_by_index of an empty list)
     int64_t m2 = m1;
-    if (best_t >= 0) {
-        hipLaunchKernelGGL(plane_keep_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1, best[0], best[1],
-                           best[2], best[3], prm->plane_distance, 0, flag);
-        rc = select_core(c, A_pts, nrm ? A_nrm : nullptr, m1, flag, B_pts, B_nrm, &m2);
-        if (rc) return rc;
-    } else {
-        PEDP_HIP_CHECK(hipMemcpyAsync(B_pts, A_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
-        if (nrm) PEDP_HIP_CHECK(hipMemcpyAsync(B_nrm, A_nrm, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
-    }
+    hipLaunchKernelGGL(plane_keep_best_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1, (const double *)d_best,
+                       prm->plane_distance, flag);
+    rc = select_core(c, A_pts, nrm ? A_nrm : nullptr, m1, flag, B_pts, B_nrm, &m2);
+    if (rc) return rc;
     if (stage_counts) stage_counts[1] = m2;
     if (m2 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
     // ---- DBSCAN, largest cluster (np.unique + argmax: the lowest label among the largest)
