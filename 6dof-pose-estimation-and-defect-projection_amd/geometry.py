@@ -31,29 +31,66 @@ class PointCloud:
 
     `points` may also be given as a float64 N x 3 torch tensor on the GPU (a scene back-projected there,
     estimater.py hands CUDA tensors around): the holder keeps the tensor, `voxel_down_sample` works from it,
-    and the numpy array is only made if somebody reads `points`."""
+    and the numpy array is only made if somebody reads `points`.
+
+    A holder made by `moved_copy` (the moved model `refine_pose_with_icp` returns and run.py:99 throws away) forms its
+    points and normals when they are first read: until then it keeps the source's arrays as they were handed over and the
+    4x4.  Our holders replace their arrays when they change, they do not write into them; a caller that edits the
+    source's arrays in place before reading the copy should read the copy first."""
 
     def __init__(self, points=None, normals=None, colors=None):
         self._dev_points = None
+        self._moved = None            # (points, normals, T): a moved copy that nobody has read yet
         if _on_device(points):
             self._dev_points, self._points = points.reshape(-1, 3), None
         else:
             self._points = _arr([] if points is None else points)
-        self.normals = _arr([] if normals is None else normals)
+        self._normals = _arr([] if normals is None else normals)
         self._uniform = None          # paint_uniform_color: one colour for every point, written out when read
         self.colors = _arr([] if colors is None else colors)
 
+    @classmethod
+    def moved_copy(cls, source, T):
+        """What copy.deepcopy(source).transform(T) gives (same arithmetic, pose_estimation.py:815-816), formed on first read."""
+        out = cls(colors=None if source._uniform is not None else np.array(source._colors))
+        if source._uniform is not None:
+            out.paint_uniform_color(source._uniform)
+        out._points = None
+        out._moved = (np.asarray(source.points, np.float64), np.asarray(source.normals, np.float64), np.array(T, dtype=np.float64))
+        return out
+
+    def _form(self):
+        if self._moved is not None:
+            pts, nrm, T = self._moved
+            self._moved = None
+            self._points = pts @ T[:3, :3].T + T[:3, 3]
+            self._normals = nrm @ T[:3, :3].T if len(nrm) else _arr([])
+
     @property
     def points(self):
+        self._form()
         if self._points is None:
             self._points = _arr(self._dev_points.detach().cpu().numpy())
         return self._points
 
     @points.setter
     def points(self, value):
+        self._form()
         self._points, self._dev_points = value, None
 
+    @property
+    def normals(self):
+        self._form()
+        return self._normals
+
+    @normals.setter
+    def normals(self, value):
+        self._form()
+        self._normals = value
+
     def _count(self):
+        if self._moved is not None:
+            return len(self._moved[0])
         return len(self._dev_points) if self._points is None else len(self._points)
 
     @property
@@ -69,7 +106,8 @@ class PointCloud:
         self._uniform = None
 
     def has_normals(self):
-        return len(self.normals) == self._count() and self._count() > 0
+        n = len(self._moved[1]) if self._moved is not None else len(self._normals)
+        return n == self._count() and self._count() > 0
 
     def has_colors(self):
         if self._uniform is not None:
@@ -121,7 +159,7 @@ class PointCloud:
     def voxel_down_sample(self, voxel_size):
         from . import cloud_ops
 
-        if self._points is None and not self.has_normals():      # device-resident scene: the grid is built from it
+        if self._dev_points is not None and self._points is None and not self.has_normals():      # device-resident scene: the grid is built from it
             pts, nrm = cloud_ops.voxel_down_sample(self._dev_points, voxel_size)
         else:
             pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)

@@ -40,16 +40,11 @@ def _copy_parameters(tree):
 
 
 def transform_object(pcd, transformation):
-    """Deep copy moved by `transformation` (pose_estimation.py:406-409).  Our own holder is built from the moved arrays
-    directly -- copy-then-transform writes the points twice -- with the same arithmetic as its transform()."""
+    """Deep copy moved by `transformation` (pose_estimation.py:406-409).  Our own holders are built from the moved arrays
+    directly -- copy-then-transform writes the points twice -- with the same arithmetic as their transform(); a point
+    cloud forms them when it is first read."""
     if type(pcd) is PointCloud:
-        T = np.asarray(transformation, dtype=np.float64)
-        pts = np.asarray(pcd.points, np.float64) @ T[:3, :3].T + T[:3, 3]
-        nrm = np.asarray(pcd.normals, np.float64) @ T[:3, :3].T if len(pcd.normals) else None
-        moved = PointCloud(pts, nrm, None if pcd._uniform is not None else np.array(pcd._colors))
-        if pcd._uniform is not None:
-            moved.paint_uniform_color(pcd._uniform)
-        return moved
+        return PointCloud.moved_copy(pcd, transformation)   # formed when first read (run.py:99 never reads it)
     if type(pcd) is TriangleMesh:
         T = np.asarray(transformation, dtype=np.float64)
         moved = TriangleMesh(np.asarray(pcd.vertices, np.float64) @ T[:3, :3].T + T[:3, 3], np.array(pcd.triangles))

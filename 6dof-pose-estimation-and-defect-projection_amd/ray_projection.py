@@ -103,10 +103,14 @@ def jet(values):
     """RGB of matplotlib's 256-entry 'jet' lookup: index floor(v * 256) clipped to 0..255;
     NaN maps to black (matplotlib's 'bad' colour is transparent black)."""
     v = np.asarray(values, dtype=np.float64)
-    idx = np.where(np.isnan(v), 0, np.clip(np.nan_to_num(v) * 256.0, -1, 256)).astype(np.int64)
-    idx = np.clip(idx, 0, 255)
-    rgb = _jet_lut()[idx]
-    rgb[np.isnan(v)] = 0.0
+    x = v * 256.0
+    bad = x != x
+    if bad.any():
+        x[bad] = 0.0
+    np.clip(x, 0.0, 255.0, out=x)          # below 0 -> entry 0, 1 and above -> entry 255 (truncation does the floor)
+    rgb = np.take(_jet_lut(), x.astype(np.intp), axis=0)
+    if bad.any():
+        rgb[bad] = 0.0
     return rgb
 
 

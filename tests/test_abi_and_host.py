@@ -295,6 +295,38 @@ def test_preprocess_target_subsamples_with_global_rng():
         preprocess_target(PointCloud(pts), {"preprocess_target": {"max_pcd": 1000, "keep_normals": True}})
 
 
+def test_moved_copy_of_a_holder_is_formed_on_first_read():
+    """transform_object on our PointCloud (the moved model refine_pose_with_icp returns and run.py:99 drops): equal to
+    deepcopy + transform bit for bit, whatever is read first, and nothing is computed before a read."""
+    import copy
+
+    from pedp_hip.geometry import PointCloud
+    from pedp_hip.icp_refine import transform_object
+
+    rng = np.random.default_rng(0)
+    src = PointCloud(rng.normal(size=(100, 3)), rng.normal(size=(100, 3)))
+    src.paint_uniform_color([0, 0, 1])
+    T = np.eye(4)
+    T[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    T[:3, 3] = [1, 2, 3]
+    ref = copy.deepcopy(src)
+    ref.transform(T)
+    m = transform_object(src, T)
+    assert m._moved is not None and len(m) == 100 and m.has_normals() and m.has_colors() and m.has_points()
+    assert np.array_equal(m.normals, ref.normals) and m._moved is None and np.array_equal(m.points, ref.points)
+    assert np.array_equal(m.colors, ref.colors)
+    again = copy.deepcopy(transform_object(src, T))
+    assert np.array_equal(again.points, ref.points) and np.array_equal(again.normals, ref.normals)
+    twice = transform_object(src, T).transform(T)
+    assert np.array_equal(twice.points, copy.deepcopy(ref).transform(T).points)
+    renormalled = transform_object(src, T)
+    renormalled.normals = np.zeros((100, 3))
+    assert np.array_equal(renormalled.points, ref.points) and not renormalled.normals.any()
+    empty = transform_object(PointCloud(), T)
+    assert len(empty) == 0 and not empty.has_normals() and empty.points.shape == (0, 3)
+    assert np.array_equal(np.asarray(src.points), np.asarray(copy.deepcopy(src).points))   # the source is untouched
+
+
 def test_load_extrinsics_and_shard_bounds(tmp_path):
     import json
 
