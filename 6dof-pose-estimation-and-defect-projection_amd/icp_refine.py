@@ -294,11 +294,9 @@ def predict_z_axis_adjustment(source, target, initial_fp_transformation, param, 
                         grown.append(path + (better,))
             frontier = grown
         paths = list(nodes)
-        starts = []
-        for path in paths:
-            probe = np.copy(initial_fp_transformation)
-            probe[2, 3] -= nodes[path][0]
-            starts.append(np.linalg.inv(probe))
+        probes = np.repeat(np.asarray(initial_fp_transformation, dtype=np.float64)[None], len(paths), axis=0)
+        probes[:, 2, 3] -= [nodes[path][0] for path in paths]
+        starts = np.linalg.inv(probes)                       # one call; the same LAPACK solve per matrix as one by one
         results = dict(zip(paths, reg.registration_icp_batch(d_src, d_tgt, [radius] * len(paths), starts, plane, one_iteration)))
         path = ()
         while path in results:
