@@ -192,8 +192,12 @@ def run(args):
     icp_be = pdist.HipBackend(local)
     ray_be = pdist.HipBackend(local)
     ctx, ray_ctx = icp_be.ctx, ray_be.ctx
+    # The collectives of the one-frame split go through torch.distributed (backend nccl = RCCL) on the library's streams
+    # unless PEDP_BENCH_NATIVE_RCCL=1 asks for the library's own communicators: those have only ever run on one-rank
+    # groups (no multi-GPU node was available to this build), and a first multi-rank run belongs in a test, not between
+    # the driver and its scaling curve.
     native = False
-    if world > 1 and not rehearsal:
+    if world > 1 and not rehearsal and os.environ.get("PEDP_BENCH_NATIVE_RCCL") == "1":
         native = bool(icp_be.init_comm()) & bool(ray_be.init_comm())
 
     frame = synth.Frame(args.config)
