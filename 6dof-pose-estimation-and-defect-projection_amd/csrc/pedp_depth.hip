@@ -180,22 +180,36 @@ __global__ __launch_bounds__(256) void erode_walk_kernel(const float *__restrict
     if (!walk_origin(w, p.H, x0, ys0, ys1)) return;  // workgroup-uniform
     const float inf = __builtin_inff(), nan = __builtin_nanf("");
     const int n_blocks = (ys1 - ys0 + WALK_BH - 1) / WALK_BH;
-    // element e of a block: row e / TW, column e % TW of the band with its halo columns
+    // element e of a block: row e / TW, column e % TW of the band with its halo columns.  What does not change from block to
+    // block is worked out once per thread: the element's offset into the image for block 0 (32 bits: an image is below
+    // 2^31 pixels), whether its column is in the image, its place in a ring slot.
+    unsigned f_off[NL];   // (ys0 + row) * W + gx for block 0 (meaningless where f_col is false)
+    int f_row[NL], f_lds[NL];
+    bool f_col[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = (int)threadIdx.x + 256 * i, row = e / TW, col = e - row * TW, gx = x0 - R + col;
+        f_row[i] = row;
+        f_lds[i] = row * TW + col;
+        f_col[i] = e < WALK_BH * TW && gx >= 0 && gx < p.W;
+        f_off[i] = (unsigned)((long long)(ys0 + row) * p.W + gx);
+    }
+    const int g_lo = max(ys0 - R, 0), g_hi = min(ys1 + R, p.H);  // the image rows this segment has any use for
+    float *const ring_flat = &ring[0][0];
     auto fetch = [&](int b, float (&v)[NL]) {
+        const unsigned step = (unsigned)(WALK_BH * b) * (unsigned)p.W;  // (wraps for b = -1 like the sum below)
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int e = (int)threadIdx.x + 256 * i, row = e / TW, col = e - row * TW;
-            const int g = ys0 + WALK_BH * b + row, gx = x0 - R + col;
-            const bool need = e < WALK_BH * TW && g >= max(ys0 - R, 0) && g < min(ys1 + R, p.H) && gx >= 0 && gx < p.W;
-            v[i] = need ? depth[(size_t)g * p.W + gx] : nan;  // outside the image (or of no use to this segment): NaN
+            const int g = ys0 + WALK_BH * b + f_row[i];
+            const bool need = f_col[i] && g >= g_lo && g < g_hi;
+            v[i] = need ? depth[f_off[i] + step] : nan;  // outside the image (or of no use to this segment): NaN
         }
     };
     auto park = [&](int b, const float (&v)[NL]) {  // block b (-1 ..) lives in slot (b + 1) % 4
+        const int slot = ((b + 1) & (WALK_SLOTS - 1)) * (WALK_BH * TW);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int e = (int)threadIdx.x + 256 * i, row = e / TW, col = e - row * TW;
-            if (e < WALK_BH * TW) ring[((b + 1) * WALK_BH + row) & (RING - 1)][col] = (v[i] < 0.001f || v[i] >= p.zfar) ? inf : v[i];
-        }
+        for (int i = 0; i < NL; ++i)
+            if ((int)threadIdx.x + 256 * i < WALK_BH * TW) ring_flat[slot + f_lds[i]] = (v[i] < 0.001f || v[i] >= p.zfar) ? inf : v[i];
     };
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx;
     const bool mine = x < p.W;
