@@ -22,7 +22,7 @@ class PreprocessParams(C.Structure):
     _fields_ = [("voxel_size", C.c_double), ("plane_distance", C.c_double), ("plane_iterations", C.c_int32),
                 ("first_frame", C.c_int32), ("seed", C.c_uint64), ("normal_radius", C.c_double), ("normal_max_nn", C.c_int32),
                 ("cluster_min_points", C.c_int32), ("cluster_eps", C.c_double), ("outlier_neighbors", C.c_int32),
-                ("reserved", C.c_int32), ("outlier_std_ratio", C.c_double)]
+                ("flags", C.c_int32), ("outlier_std_ratio", C.c_double), ("average_normal_voxel", C.c_double)]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
@@ -59,6 +59,10 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_mesh_posed_vertices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pedp_project_heatmap_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
+                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
+                                          _P(C.c_int64), C.c_void_p]),
     "pedp_erode_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_void_p]),
     "pedp_bilateral_filter_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -72,6 +76,9 @@ PROTOTYPES = {
                                                    _P(C.c_int64)]),
     "pedp_preprocess_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          _P(C.c_int64), _P(C.c_int64), _P(C.c_int)]),
+    "pedp_preprocess_source_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            _P(C.c_int64), _P(C.c_int64), _P(C.c_int), C.c_void_p]),
+    "pedp_transform_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pedp_cluster_dbscan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p]),
     "pedp_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pedp_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
@@ -207,6 +214,12 @@ class Pinhole(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class ProjectOpts(C.Structure):
+    """pedp_project_opts (include/pedp.h)."""
+    _fields_ = [("heat_f32", C.c_int32), ("heat_mem", C.c_int32), ("jet_lut", C.c_void_p), ("colors", C.c_void_p),
+                ("post", C.c_void_p)]
+
+
 class Mesh:
     """Device-resident triangle records of one posed mesh (RaycastingScene stand-in).
     posable=True keeps the model-frame float64 vertices on the device: set_pose(T) then stands for
@@ -222,6 +235,7 @@ class Mesh:
         t = np.ascontiguousarray(t, dtype=np.uint32).reshape(-1, 3)
         self.V, self.F = len(v), len(t)
         self.posable = bool(posable)
+        self._hit_cap = 0        # project_heatmap: room kept for the hits (last call's count and a margin)
         self._h = C.c_void_p()
         if posable:
             check(load().pedp_mesh_create_posable(ctx._h, _ptr(v), self.V, _ptr(t), self.F, C.byref(self._h)),
@@ -236,28 +250,74 @@ class Mesh:
         check(load().pedp_mesh_set_pose(self._h, _ptr(M)), "pedp_mesh_set_pose")
         return self
 
-    def project_heatmap(self, heatmap, intrinsic_matrix, threshold=0.5, origin=(0.0, 0.0, 0.0)):
-        """heatmap_to_points + compute_rays + intersect_rays_with_mesh fused on the device.
-        Returns dict(points M x 3 f64, intensities M f64, pixels M x 2 int32 (x, y),
-        primitive_ids M u32, n_rays)."""
-        h = np.ascontiguousarray(heatmap, dtype=np.float64)
-        if h.ndim != 2:
+    def posed_vertices(self, T):
+        """V x 3 float64 vertices of the resident model moved by T (pedp_mesh_posed_vertices); the mesh's pose stays."""
+        if not self.posable:
+            raise PedpError("posed_vertices needs a posable mesh")
+        M = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        out = np.empty((self.V, 3), np.float64)
+        check(load().pedp_mesh_posed_vertices(self._h, _ptr(M), HOST, _ptr(out)), "pedp_mesh_posed_vertices")
+        return out
+
+    def project_heatmap(self, heatmap, intrinsic_matrix, threshold=0.5, origin=(0.0, 0.0, 0.0), jet_lut=None, post=None):
+        """heatmap_to_points + compute_rays + intersect_rays_with_mesh fused on the device (pedp_project_heatmap_ex).
+        heatmap: H x W float64 or float32, a numpy array or a CUDA tensor (taken where and as it is).  jet_lut (256 x 3):
+        also return the hits' jet colours (create_intersection_pcd); post (4 x 4): the hit points moved by it on the device.
+        Returns dict(points M x 3 f64, intensities M f64, pixels M x 2 int32 (x, y), primitive_ids M u32, n_rays
+        [, colors M x 3 f64])."""
+        opts = ProjectOpts(0, HOST, None, None, None)
+        keep = []
+        if type(heatmap).__module__.startswith("torch"):
+            import torch
+
+            if not heatmap.is_cuda or heatmap.device.index != self.ctx.device:
+                raise PedpError(f"heat map tensor must be on cuda:{self.ctx.device}")
+            h = heatmap if heatmap.dtype in (torch.float32, torch.float64) else heatmap.double()
+            h = h.contiguous()
+            torch.cuda.current_stream(h.device).synchronize()       # the library reads it on its own stream
+            opts.heat_f32, opts.heat_mem, h_ptr, shape = int(h.dtype == torch.float32), DEVICE, C.c_void_p(h.data_ptr()), tuple(h.shape)
+            keep.append(h)
+        else:
+            h = np.asarray(heatmap)
+            h = np.ascontiguousarray(h, dtype=np.float32 if h.dtype == np.float32 else np.float64)
+            opts.heat_f32, h_ptr, shape = int(h.dtype == np.float32), _ptr(h), h.shape
+        if len(shape) != 2:
             raise PedpError("heat map must be 2-D")
         K = np.asarray(intrinsic_matrix, dtype=np.float64)
-        cam = Pinhole(K[0, 0], K[1, 1], K[0, 2], K[1, 2], h.shape[1], h.shape[0])
+        cam = Pinhole(K[0, 0], K[1, 1], K[0, 2], K[1, 2], shape[1], shape[0])
         o = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
-        cap = int(np.count_nonzero(h > threshold))  # upper bound of the hit count
-        pts = np.empty((cap, 3), np.float64)
-        inten = np.empty(cap, np.float64)
-        pix = np.empty((cap, 2), np.int32)
-        prim = np.empty(cap, np.uint32)
-        n_rays, n_hits = C.c_int64(), C.c_int64()
-        check(load().pedp_project_heatmap(self.ctx._h, self._h, C.byref(cam), _ptr(h), float(threshold), _ptr(o), HOST,
-                                          cap, _ptr(pts), _ptr(inten), _ptr(pix), _ptr(prim), C.byref(n_rays),
-                                          C.byref(n_hits)), "pedp_project_heatmap")
+        cap = self._hit_cap if self._hit_cap > 0 else max(shape[0] * shape[1], 1)   # room for the hits: every pixel the first
+        # time, then the last call's count and a margin, grown on demand
+        while True:
+            pts = np.empty((cap, 3), np.float64)
+            inten = np.empty(cap, np.float64)
+            pix = np.empty((cap, 2), np.int32)
+            prim = np.empty(cap, np.uint32)
+            cols = None
+            if jet_lut is not None:
+                lut = np.ascontiguousarray(jet_lut, dtype=np.float64).reshape(256, 3)
+                cols = np.empty((cap, 3), np.float64)
+                opts.jet_lut, opts.colors = lut.ctypes.data, cols.ctypes.data
+                keep.append(lut)
+            if post is not None:
+                pT = np.ascontiguousarray(post, dtype=np.float64).reshape(16)
+                opts.post = pT.ctypes.data
+                keep.append(pT)
+            n_rays, n_hits = C.c_int64(), C.c_int64()
+            rc = load().pedp_project_heatmap_ex(self.ctx._h, self._h, C.byref(cam), h_ptr, float(threshold), _ptr(o), HOST,
+                                                cap, _ptr(pts), _ptr(inten), _ptr(pix), _ptr(prim), C.byref(n_rays),
+                                                C.byref(n_hits), C.byref(opts))
+            if rc != 0 and n_hits.value > cap:   # more hits than room (the count is reported): once more with room for them
+                cap = n_hits.value
+                continue
+            check(rc, "pedp_project_heatmap")
+            break
         m = n_hits.value
-        return {"points": pts[:m], "intensities": inten[:m], "pixels": pix[:m], "primitive_ids": prim[:m],
-                "n_rays": n_rays.value}
+        self._hit_cap = m + m // 4 + 1024
+        out = {"points": pts[:m], "intensities": inten[:m], "pixels": pix[:m], "primitive_ids": prim[:m], "n_rays": n_rays.value}
+        if cols is not None:
+            out["colors"] = cols[:m]
+        return out
 
     def cast_rays(self, rays6, want_uv=True):
         """rays6: N x 6 float32 host array.  Returns dict like RaycastingScene.cast_rays:
@@ -536,3 +596,13 @@ def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
     check(load().pedp_cluster_poses(float(angle_diff), float(dist_diff), _ptr(p), len(p), _ptr(s), len(s),
                                     _ptr(keep), C.byref(nk)), "pedp_cluster_poses")
     return keep[: nk.value].copy()
+
+
+def transform_points(T, points, rotate_only=False):
+    """pedp_transform_points: rows of `points` (N x 3 float64) moved by the 4x4 `T` (rotation only for normals), the
+    oracle's operation order; a fresh array.  Host arithmetic of the library (no GPU, no context)."""
+    p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    M = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    out = np.empty_like(p)
+    check(load().pedp_transform_points(_ptr(M), _ptr(p), len(p), 1 if rotate_only else 0, _ptr(out)), "pedp_transform_points")
+    return out

@@ -60,15 +60,18 @@ def voxel_down_sample(points, voxel_size, normals=None, ctx=None):
 
 def preprocess_source_fused(points, voxel_size, plane_distance, plane_iterations, first_frame, seed=None, normal_radius=2.0,
                             normal_max_nn=5, cluster_eps=10.0, cluster_min_points=10, outlier_neighbors=75, outlier_std_ratio=0.01,
-                            ctx=None):
-    """pedp_preprocess_source: the reference's preprocess_source chain (pose_estimation.py:186-268, no box / mesh / background)
-    with the scene staying on the device between the stages.  `points`: N x 3 float64 numpy array, or a float64 torch
-    tensor on the GPU.  Returns (points, normals or None, stage_counts, status); status != 0: nothing was produced (no
-    cluster / fewer than three points) and the caller takes the step-by-step path to reproduce the reference's behaviour."""
+                            ctx=None, box=False, report=False):
+    """pedp_preprocess_source[_ex]: the reference's preprocess_source chain (pose_estimation.py:186-268; every branch but
+    param['mesh']) with the scene staying on the device between the stages.  `points`: N x 3 float64 numpy array, or a
+    float64 torch tensor on the GPU.  box: param['box'] (half-space cut instead of the plane removal).  report: also return
+    what the reference's INFO lines print.  Returns (points, normals or None, stage_counts, status[, report]); status != 0:
+    nothing was produced (no cluster / fewer than three points / an undecidable plane flip) and the caller takes the
+    step-by-step path to reproduce the reference's behaviour.  report = {"plane_model": refit plane (4,), "mean_normal":
+    (3,) un-normalised mean of the 10-unit voxel normals (1, 1, 1 on tracking frames), "flipped": bool (box only)}."""
     ctx = ctx or _lib.default_context()
     prm = _lib.PreprocessParams(float(voxel_size), float(plane_distance), int(plane_iterations), 1 if first_frame else 0,
                                 int(_SEED if seed is None else seed), float(normal_radius), int(normal_max_nn), int(cluster_min_points),
-                                float(cluster_eps), int(outlier_neighbors), 0, float(outlier_std_ratio))
+                                float(cluster_eps), int(outlier_neighbors), 1 if box else 0, float(outlier_std_ratio), 0.0)
     if _is_device_tensor(points):
         import torch
 
@@ -82,6 +85,7 @@ def preprocess_source_fused(points, voxel_size, plane_distance, plane_iterations
     else:
         p = _pts(points)
         n, ptr, on_dev, keep = len(p), _lib._ptr(p), 0, p
+    rep = np.zeros(12, np.float64) if report else None
     # the result is a small fraction of the frame: room for a tenth (at least 64 k points), the whole cloud if that is short
     for cap in (max(n // 10, 65536), n):
         cap = min(cap, max(n, 1))
@@ -89,14 +93,17 @@ def preprocess_source_fused(points, voxel_size, plane_distance, plane_iterations
         outn = np.empty((cap, 3), np.float64) if first_frame else None
         m, status = C.c_int64(), C.c_int()
         counts = (C.c_int64 * 4)()
-        rc = _lib.load().pedp_preprocess_source(ctx._h, ptr, n, on_dev, C.byref(prm), _lib._ptr(out), _lib._ptr(outn), cap,
-                                                C.byref(m), counts, C.byref(status))
+        rc = _lib.load().pedp_preprocess_source_ex(ctx._h, ptr, n, on_dev, C.byref(prm), _lib._ptr(out), _lib._ptr(outn), cap,
+                                                   C.byref(m), counts, C.byref(status), _lib._ptr(rep))
         if rc != 0 and m.value > cap and cap < n:
             continue                                           # (more points survived than a tenth: once more with full room)
         _lib.check(rc, "pedp_preprocess_source")
         break
     del keep
-    return out[:m.value].copy(), (None if outn is None else outn[:m.value].copy()), list(counts), status.value
+    res = (out[:m.value].copy(), (None if outn is None else outn[:m.value].copy()), list(counts), status.value)
+    if report:
+        res += ({"plane_model": rep[:4].copy(), "mean_normal": rep[4:7].copy(), "flipped": bool(rep[7]), "inliers": int(rep[8])},)
+    return res
 
 
 def cluster_dbscan(points, eps, min_points, ctx=None):

@@ -28,6 +28,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace {
 
@@ -1176,29 +1177,245 @@ __global__ __launch_bounds__(256) void ransac_best_kernel(const int *__restrict_
     }
 }
 
-// host: GetPlaneFromPoints, oracle/cloudops.c pedp_oracle_plane_from_points
-void plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
+// GetPlaneFromPoints, oracle/cloudops.c pedp_oracle_plane_from_points: centroid of the inliers, their six second moments
+// about it, the largest-determinant closed form.  Every sum is taken in BLOCKS of the cloud -- the 256 points [256 j, 256 j +
+// 256) contribute their value if they are inliers and zero otherwise, a block is added in a fixed binary tree, t[i] += t[i + w]
+// for w = 128 ... 1, the block sums are added in order of j -- the order the device takes (refit_* kernels below:
+// pedp_preprocess_source refits without a trip to the host and without compacting the inliers); this host statement serves
+// pedp_segment_plane.  Differs from Open3D's running sums by rounding only.  idx ascends.
+inline double block_tree_sum(double *t) {
+    for (int w = 128; w >= 1; w >>= 1)
+        for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    return t[0];
+}
+__host__ __device__ inline void plane_closed_form(const double c[3], const double m[6], double pl[4]) {
     pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
-    if (n < 3) return;
-    double c[3] = {0, 0, 0};
-    for (int64_t i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) c[k] += pts[3 * (int64_t)idx[i] + k];
-    for (int k = 0; k < 3; ++k) c[k] /= (double)n;
-    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double *p = pts + 3 * (int64_t)idx[i];
-        const double rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
-        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-    }
+    const double xx = m[0], xy = m[1], xz = m[2], yy = m[3], yz = m[4], zz = m[5];
     const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
     double a, b, cc;
     if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }
     else if (det_y >= det_z) { a = xz * yz - xy * zz; b = det_y; cc = xy * xz - yz * xx; }
     else { a = xy * yz - xz * yy; b = xy * xz - yz * xx; cc = det_z; }
-    const double nrm = std::sqrt((a * a + b * b) + cc * cc);
+    const double nrm = sqrt((a * a + b * b) + cc * cc);
     if (!(nrm > 0.0)) return;
     pl[0] = a / nrm; pl[1] = b / nrm; pl[2] = cc / nrm;
     pl[3] = -((pl[0] * c[0] + pl[1] * c[1]) + pl[2] * c[2]);
+}
+void blocked_sums(const double *pts, const int32_t *idx, int64_t n, const double *r0, int nq, double *out) {
+    const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {0, 1, 2, 1, 2, 2};
+    double t[6][256];
+    for (int q = 0; q < nq; ++q) out[q] = 0.0;
+    int64_t i = 0;
+    while (i < n) {
+        const int64_t blk = idx[i] / 256;
+        for (int q = 0; q < nq; ++q)
+            for (int k = 0; k < 256; ++k) t[q][k] = 0.0;
+        for (; i < n && idx[i] / 256 == blk; ++i) {
+            const double *p = pts + 3 * (int64_t)idx[i];
+            const int k = (int)(idx[i] % 256);
+            if (!r0) { t[0][k] = p[0]; t[1][k] = p[1]; t[2][k] = p[2]; continue; }
+            const double r[3] = {p[0] - r0[0], p[1] - r0[1], p[2] - r0[2]};
+            for (int q = 0; q < nq; ++q) t[q][k] = r[A[q]] * r[B[q]];
+        }
+        for (int q = 0; q < nq; ++q) out[q] += block_tree_sum(t[q]);
+    }
+}
+void plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (n < 3) return;
+    double c[3], m[6];
+    blocked_sums(pts, idx, n, nullptr, 3, c);
+    for (int k = 0; k < 3; ++k) c[k] /= (double)n;
+    blocked_sums(pts, idx, n, c, 6, m);
+    plane_closed_form(c, m, pl);
+}
+
+// ---- the same on the device: per block of 256 points the tree sums of NV values per inlier (and, NV = 3, the block's
+// inlier count), then the blocks added in order.
+// NV = 3: the coordinates; NV = 6: the products of the residuals about the centroid in res[0..2].  part: NV (+ 1) per block.
+template <int NV>
+__global__ __launch_bounds__(256) void refit_block_kernel(const double *__restrict__ pts, int64_t N, const double *__restrict__ best, double thr,
+                                                          const double *__restrict__ res, double *__restrict__ part) {
+    constexpr int NP = NV == 3 ? 4 : 6;
+    __shared__ double t[NP][256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) v[k] = 0.0;
+    if (i < N && best[0] >= 0.0) {
+        const double pl[4] = {best[10], best[11], best[12], best[13]};
+        const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        const double p[3] = {x, y, z};
+        if (plane_dist(pl, p) < thr) {
+            if constexpr (NV == 3) { v[0] = x; v[1] = y; v[2] = z; v[3] = 1.0; }
+            else {
+                const double rx = x - res[0], ry = y - res[1], rz = z - res[2];
+                v[0] = rx * rx; v[1] = rx * ry; v[2] = rx * rz; v[3] = ry * ry; v[4] = ry * rz; v[5] = rz * rz;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) t[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {  // t[i] += t[i + w], i < w: the oracle's tree
+        if ((int)threadIdx.x < w)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) t[k][threadIdx.x] += t[k][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < NP) part[NP * (size_t)blockIdx.x + threadIdx.x] = t[threadIdx.x][0];
+}
+// NV = 3: res[0..2] = centroid, res[7] = number of inliers.  NV = 6: res[3..6] = the plane (res[0..2], res[7] are read).
+template <int NV>
+__global__ __launch_bounds__(256) void refit_fold_kernel(const double *__restrict__ part, int64_t n_blocks, double *__restrict__ res) {
+    constexpr int NP = NV == 3 ? 4 : 6;
+    __shared__ double stage[NP * 1024];
+    __shared__ double m[6];
+    double s = 0.0;
+    for (int64_t base = 0; base < n_blocks; base += 1024) {  // the block sums through LDS, then added in order: a lane per value
+        const int nb = (int)(n_blocks - base < 1024 ? n_blocks - base : 1024);
+        for (int j = threadIdx.x; j < NP * nb; j += 256) stage[j] = part[NP * (size_t)base + j];
+        __syncthreads();
+        if ((int)threadIdx.x < NP)
+            for (int b = 0; b < nb; b += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = b + j < nb ? stage[NP * (b + j) + threadIdx.x] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b + j < nb) s += v[j];
+            }
+        __syncthreads();
+    }
+    if (NV == 3) {  // (the count is a sum of ones: exact in any order)
+        if (threadIdx.x == 3) m[0] = s;
+        __syncthreads();
+        if (threadIdx.x < 3) res[threadIdx.x] = s / m[0];
+        if (threadIdx.x == 3) res[7] = s;
+        return;
+    }
+    if (threadIdx.x < 6) m[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double pl[4] = {0, 0, 0, 0};
+        if (res[7] >= 3.0) {
+            const double c[3] = {res[0], res[1], res[2]};
+            plane_closed_form(c, m, pl);
+        }
+        for (int k = 0; k < 4; ++k) res[3 + k] = pl[k];
+    }
+}
+
+// ------------------------------------------------------------------ compute_average_normal on the device
+// src/pose_estimation.py:314-321: the normals' averages over a 10-unit voxel grid (voxel_down_sample: members summed in
+// point order, divided by the count; voxels in ascending (ix, iy, iz)), then numpy's mean over the voxels (row by row).
+// The sort-based grid above costs two dozen launches and two trips to the host for the 38 k points of a frame; here the
+// voxels are cells of a dense grid (ids ascending in (ix, iy, iz)), members are counted and placed, and a thread per
+// cell adds its members in ascending point index by repeated selection (a few dozen members).  No trip to the host:
+// the grid's origin (the cloud's own minimum, less half a voxel: voxel_down_sample's) is folded on the device, its
+// dimensions come from a box the caller knows to contain the cloud.  Same sums in the same order as the grid above.
+struct AvgGrid { int dim[3]; double voxel; };
+__global__ __launch_bounds__(256) void avgn_origin_kernel(const double *__restrict__ part /* n_part x 6 */, int n_part, double voxel,
+                                                          double *__restrict__ org) {
+    __shared__ double red[4][3];
+    double lo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = (int)threadIdx.x < n_part ? part[6 * threadIdx.x + k] : __longlong_as_double(0x7FF0000000000000ll);
+        for (int b = threadIdx.x + 256; b < n_part; b += 256) lo[k] = part[6 * b + k] < lo[k] ? part[6 * b + k] : lo[k];
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(lo[k], off, 64);
+            lo[k] = o < lo[k] ? o : lo[k];
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = lo[k];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = red[w][threadIdx.x] < v ? red[w][threadIdx.x] : v;
+        org[threadIdx.x] = v - voxel * 0.5;
+    }
+}
+__device__ __forceinline__ unsigned avgn_cell(const double *p, const double *org, const AvgGrid &g) {
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const long long v = (long long)floor((p[k] - org[k]) / g.voxel);
+        c[k] = v < 0 ? 0 : (v >= g.dim[k] ? g.dim[k] - 1 : (int)v);  // (never clamps: the box contains the cloud)
+    }
+    return (unsigned)((c[0] * g.dim[1] + c[1]) * g.dim[2] + c[2]);
+}
+__global__ void avgn_count_kernel(const double *__restrict__ pts, int64_t N, const double *__restrict__ org, AvgGrid g,
+                                  unsigned *__restrict__ cell, int *__restrict__ slot, unsigned *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned c = avgn_cell(pts + 3 * i, org, g);
+    cell[i] = c;
+    slot[i] = (int)atomicAdd(&count[c], 1u);
+}
+__global__ void avgn_place_kernel(int64_t N, const unsigned *__restrict__ cell, const int *__restrict__ slot, const unsigned *__restrict__ begin,
+                                  int *__restrict__ member) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) member[begin[cell[i]] + (unsigned)slot[i]] = (int)i;
+}
+struct NonEmpty { __host__ __device__ unsigned operator()(unsigned n) const { return n != 0u ? 1u : 0u; } };
+constexpr int AVGN_MAX_MEMBERS = 512, AVGN_WPB = 4;
+// A wave per 64 consecutive cells; every non-empty cell of them is served by the whole wave: the members' indices go to
+// LDS, every member's rank among them is the number of smaller indices, its normal goes to the LDS row of that rank, and
+// three lanes -- one per component -- add the rows in order (eight reads in flight, then their additions).
+__global__ __launch_bounds__(AVGN_WPB * 64) void avgn_mean_kernel(int64_t n_cells, const unsigned *__restrict__ begin,
+                                                                   const unsigned *__restrict__ rank, const int *__restrict__ member,
+                                                                   const double *__restrict__ nrm, double *__restrict__ means,
+                                                                   int *__restrict__ overflow) {
+    __shared__ int idx_s[AVGN_WPB][AVGN_MAX_MEMBERS];
+    __shared__ double row_s[AVGN_WPB][3 * AVGN_MAX_MEMBERS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * AVGN_WPB + wv) * 64, cl = c0 + lane;
+    const unsigned b = cl < n_cells ? begin[cl] : 0u, e = cl < n_cells ? begin[cl + 1] : 0u;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(e > b);
+    int *ids = idx_s[wv];
+    double *rows = row_s[wv];
+    while (todo) {  // wave-uniform
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned cb = __builtin_amdgcn_readlane(b, j), k = __builtin_amdgcn_readlane(e, j) - cb;
+        if (k > (unsigned)AVGN_MAX_MEMBERS) { if (lane == 0) *overflow = 1; continue; }
+        for (unsigned t = lane; t < k; t += 64) ids[t] = member[cb + t];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // (this wave's LDS writes are complete: lgkmcnt(0))
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned t = lane; t < k; t += 64) {
+            const int mine = ids[t];
+            unsigned r = 0;
+            for (unsigned u = 0; u < k; ++u) r += ids[u] < mine ? 1u : 0u;
+            rows[3 * r] = nrm[3 * (size_t)mine];
+            rows[3 * r + 1] = nrm[3 * (size_t)mine + 1];
+            rows[3 * r + 2] = nrm[3 * (size_t)mine + 2];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 3) {
+            double s = 0.0;
+            for (unsigned t = 0; t < k; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = t + q < k ? rows[3 * (t + q) + lane] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (t + q < k) s += v[q];
+            }
+            means[3 * (size_t)rank[c0 + j] + lane] = s / (double)k;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// numpy's mean over axis 0 adds the rows one after the other: a serial chain of a few thousand additions, which one GPU
+// thread takes 170 us over.  The means are therefore written straight into pinned host memory by the kernel above, and the
+// host adds them after the stream's next wait (microseconds); this kernel only reports how many there are.
+__global__ void avgn_rows_kernel(int64_t n_cells, const unsigned *__restrict__ rank, const unsigned *__restrict__ count,
+                                 const int *__restrict__ overflow, double *__restrict__ res) {
+    res[3] = (double)((int64_t)rank[n_cells - 1] + (count[n_cells - 1] != 0u ? 1 : 0));
+    res[4] = (double)*overflow;
 }
 
 int check_cloud(pedp_ctx_t c, const double *pts, int64_t N, const char *who) {
@@ -1562,6 +1779,70 @@ int normals_core(pedp_ctx_t c, const double *d_pts, int64_t N, double radius, in
     return PEDP_OK;
 }
 
+// compute_average_normal's voxel means on the device (kernels above), nothing read back here: the means go to the context's
+// pinned block as the kernel writes them, their number and the overflow flag (h_res[3], [4]) are on their way to `h_res`
+// (pinned) when the call returns; all valid after the stream's next synchronisation.  *enqueued = false: the dense grid does not fit (the caller takes the sort-based grid).
+int average_normal_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t N, double voxel, const double box_lo[3],
+                        const double box_hi[3], double *d_part /* partial bounds + room behind them */, double *h_res, bool *enqueued) {
+    *enqueued = false;
+    AvgGrid g;
+    g.voxel = voxel;
+    double cells = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        const double d = std::floor((box_hi[k] - box_lo[k]) / voxel) + 3.0;  // origin >= box_lo - voxel / 2, points <= box_hi
+        if (!(d >= 1.0) || d > 4194304.0) return PEDP_OK;
+        g.dim[k] = (int)d;
+        cells *= d;
+    }
+    if (cells > 4194304.0) return PEDP_OK;
+    const int64_t n_cells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    size_t tmp_a = 0, tmp_b = 0;
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_a, (unsigned *)nullptr, (unsigned *)nullptr, 0u, (size_t)n_cells + 1,
+                                         rocprim::plus<unsigned>(), c->stream));
+    auto flags_null = rocprim::make_transform_iterator((const unsigned *)nullptr, NonEmpty());
+    PEDP_ROCPRIM(rocprim::exclusive_scan(nullptr, tmp_b, flags_null, (unsigned *)nullptr, 0u, (size_t)n_cells, rocprim::plus<unsigned>(), c->stream));
+    const size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b;
+    const int64_t max_rows = n_cells < N ? n_cells : N;
+    if (sizeof(double) * 3 * (size_t)max_rows > c->avg_host_cap) {
+        if (c->avg_host) { PEDP_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->avg_host); }
+        c->avg_host = nullptr;
+        c->avg_host_cap = 0;
+        const size_t want = sizeof(double) * 3 * (size_t)max_rows + sizeof(double) * 3 * (size_t)max_rows / 4 + 4096;
+        PEDP_HIP_CHECK(hipHostMalloc(&c->avg_host, want, hipHostMallocDefault));
+        c->avg_host_cap = want;
+    }
+    int st = c->ops.reserve(a256(sizeof(unsigned) * ((size_t)n_cells + 1)) * 3 + a256(sizeof(unsigned) * N) + a256(sizeof(int) * N) * 2 +
+                            a256(tmp) + 4096);
+    if (st) return st;
+    Carver cv{(char *)c->ops.ptr};
+    unsigned *count = cv.take<unsigned>((size_t)n_cells + 1), *begin = cv.take<unsigned>((size_t)n_cells + 1),
+             *rank = cv.take<unsigned>((size_t)n_cells + 1), *cell = cv.take<unsigned>(N);
+    int *slot = cv.take<int>(N), *member = cv.take<int>(N);
+    double *means = (double *)c->avg_host;  // (pinned host memory, written by the device)
+    void *d_tmp = cv.take<char>(tmp);
+    double *d_org = d_part + 6 * BND_BLOCKS + 16, *d_res = d_org + 4;  // behind the partial bounds and the best plane's block
+    int *d_over = (int *)(d_res + 8);
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(bounds_kernel, dim3(BND_BLOCKS), dim3(256), 0, c->stream, d_pts, N, d_part);
+    hipLaunchKernelGGL(avgn_origin_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)d_part, BND_BLOCKS, voxel, d_org);
+    PEDP_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(unsigned) * ((size_t)n_cells + 1), c->stream));
+    PEDP_HIP_CHECK(hipMemsetAsync(d_over, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(avgn_count_kernel, dim3(grid), dim3(256), 0, c->stream, d_pts, N, (const double *)d_org, g, cell, slot, count);
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_a, count, begin, 0u, (size_t)n_cells + 1, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(avgn_place_kernel, dim3(grid), dim3(256), 0, c->stream, N, (const unsigned *)cell, (const int *)slot,
+                       (const unsigned *)begin, member);
+    auto flags = rocprim::make_transform_iterator((const unsigned *)count, NonEmpty());
+    PEDP_ROCPRIM(rocprim::exclusive_scan(d_tmp, tmp_b, flags, rank, 0u, (size_t)n_cells, rocprim::plus<unsigned>(), c->stream));
+    hipLaunchKernelGGL(avgn_mean_kernel, dim3((unsigned)((n_cells + 64 * AVGN_WPB - 1) / (64 * AVGN_WPB))), dim3(64 * AVGN_WPB), 0, c->stream, n_cells, (const unsigned *)begin,
+                       (const unsigned *)rank, (const int *)member, d_nrm, means, d_over);
+    hipLaunchKernelGGL(avgn_rows_kernel, dim3(1), dim3(1), 0, c->stream, n_cells, (const unsigned *)rank, (const unsigned *)count,
+                       (const int *)d_over, d_res);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+    *enqueued = true;
+    return PEDP_OK;
+}
+
 // plane RANSAC: inlier counts of every iteration -> the best iteration (most inliers, earliest on ties) and its plane
 int plane_best_core(pedp_ctx_t c, const double *d_pts, int64_t N, double distance_threshold, int num_iterations, uint64_t seed,
                     int *best_t, double best[4], double *d_keep = nullptr /* 14 doubles on the device: the result stays there */) {
@@ -1641,6 +1922,16 @@ __global__ void plane_keep_best_kernel(const double *__restrict__ pts, int64_t N
     const double pl[4] = {best[10], best[11], best[12], best[13]};
     flag[i] = (best[0] < 0.0 || !(plane_dist(pl, pts + 3 * i) < thr)) ? 1u : 0u;
 }
+// remove_points_below_plane (src/pose_estimation.py:366-378): keep `(a x + b y + c z + d) / sqrt(a^2 + b^2 + c^2) <= 0`.
+// The divisor is positive, so the sign is the numerator's: numpy's left-to-right sum of three products and d, one
+// rounding each (no contraction in this build).  A flipped plane negates every term exactly: `>= 0` on the same sum.
+__global__ void halfspace_keep_kernel(const double *__restrict__ pts, int64_t N, double a, double b, double cc, double d, int flipped,
+                                      unsigned *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double s = ((a * pts[3 * i] + b * pts[3 * i + 1]) + cc * pts[3 * i + 2]) + d;
+    flag[i] = (flipped ? s >= 0.0 : s <= 0.0) ? 1u : 0u;
+}
 __global__ void label_keep_kernel(const int32_t *__restrict__ labels, int64_t N, const int *__restrict__ label, unsigned *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) flag[i] = (*label >= 0 && labels[i] == *label) ? 1u : 0u;
@@ -1682,6 +1973,24 @@ int select_core(pedp_ctx_t c, const double *d_pts, const double *d_nrm, int64_t 
     PEDP_HIP_CHECK(hipMemcpyAsync(h, count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     *n_out = *h;
+    return PEDP_OK;
+}
+
+// The plane segment_plane returns -- the best plane refit over its inliers (plane_from_points' blocked sums) -- on the
+// device, nothing read back here: res[3..6] the plane, res[7] the inlier count are on their way to `h_res` (pinned, 8
+// doubles) when the call returns and valid after the stream's next synchronisation.
+int refit_core(pedp_ctx_t c, const double *d_pts, int64_t N, const double *d_best, double thr, double *d_res, double *h_res) {
+    const size_t n_blocks = (size_t)((N + 255) / 256);
+    int st = c->ops.reserve(a256(sizeof(double) * 6 * n_blocks) + 1024);
+    if (st) return st;
+    double *part = (double *)c->ops.ptr;
+    const unsigned grid = (unsigned)n_blocks;
+    hipLaunchKernelGGL(refit_block_kernel<3>, dim3(grid), dim3(256), 0, c->stream, d_pts, N, d_best, thr, (const double *)d_res, part);
+    hipLaunchKernelGGL(refit_fold_kernel<3>, dim3(1), dim3(256), 0, c->stream, (const double *)part, (int64_t)n_blocks, d_res);
+    hipLaunchKernelGGL(refit_block_kernel<6>, dim3(grid), dim3(256), 0, c->stream, d_pts, N, d_best, thr, (const double *)d_res, part);
+    hipLaunchKernelGGL(refit_fold_kernel<6>, dim3(1), dim3(256), 0, c->stream, (const double *)part, (int64_t)n_blocks, d_res);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
     return PEDP_OK;
 }
 
@@ -1949,6 +2258,12 @@ int pedp_segment_plane(pedp_ctx_t c, const double *pts, int64_t N, double distan
 int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
                            double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
                            int *status) {
+    return pedp_preprocess_source_ex(c, pts, N, pts_on_device, prm, out_pts, out_normals, capacity, n_out, stage_counts, status, nullptr);
+}
+
+int pedp_preprocess_source_ex(pedp_ctx_t c, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
+                              double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
+                              int *status, double report[PEDP_PREPROCESS_REPORT_DOUBLES]) {
     int rc = check_cloud(c, pts, N, "pedp_preprocess_source");
     if (rc) return rc;
     PEDP_REQUIRE(prm && n_out && status && out_pts, "pedp_preprocess_source: null argument");
@@ -1964,6 +2279,11 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     if (N < 3) { *status = PEDP_PREPROCESS_DEGENERATE; return PEDP_OK; }
     PEDP_HIP_CHECK(hipSetDevice(c->device));
     const bool nrm = prm->first_frame != 0;
+    const bool box = (prm->flags & PEDP_PREPROCESS_BOX) != 0;
+    const bool seen = box || report != nullptr;  // someone reads the refit plane and the average normal (box cut / INFO lines)
+    const bool carry = nrm && !box;              // remove_points_below_plane returns points only (:375-377)
+    const double avg_voxel = prm->average_normal_voxel > 0.0 ? prm->average_normal_voxel : 10.0;
+    if (report) for (int k = 0; k < PEDP_PREPROCESS_REPORT_DOUBLES; ++k) report[k] = 0.0;
     double *d_in = const_cast<double *>(pts);
     if (!pts_on_device) { rc = upload_in(c, pts, nullptr, N, &d_in, nullptr); if (rc) return rc; }
     // ---- voxel grid
@@ -1986,11 +2306,28 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     unsigned *flag = (unsigned *)(cb + 6 * one);
     int *d_members = (int *)(cb + 6 * one + a256(sizeof(unsigned) * (size_t)m1));  // members per label, then the largest cluster's label
     PEDP_HIP_CHECK(hipMemcpyAsync(A_pts, v_pts, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
-    // ---- table plane: the best of the sampled planes (the refit plane of segment_plane has no reader on this branch)
+    // ---- table plane: the best of the sampled planes
     int best_t = -1;
     double best[4] = {0, 0, 0, 0}, *d_best = d_part + 6 * BND_BLOCKS;  // behind the partial bounds, untouched by the stages between
     rc = plane_best_core(c, A_pts, m1, prm->plane_distance, prm->plane_iterations, prm->seed, &best_t, best, d_best);
     if (rc) return rc;
+    // ---- someone reads the plane segment_plane returns (the best plane refit over its inliers): refit on the device,
+    // behind the plane kernels; the result is picked up after the stream's next wait
+    double refit[4] = {0, 0, 0, 0};
+    double *h_refit = (double *)((char *)c->pinned + 66560), *d_refit = d_part + 6 * BND_BLOCKS + 48;  // (behind the average normal's block)
+    bool plane_found = false, refit_pending = false;
+    if (seen) {
+        rc = refit_core(c, A_pts, m1, d_best, prm->plane_distance, d_refit, h_refit);
+        if (rc) return rc;
+        refit_pending = true;
+    }
+    auto refit_collect = [&]() {  // after a wait on the stream
+        if (!refit_pending) return;
+        refit_pending = false;
+        plane_found = h_refit[7] > 0.0;
+        for (int k = 0; k < 4; ++k) refit[k] = h_refit[3 + k];
+        if (report) { for (int k = 0; k < 4; ++k) report[k] = refit[k]; report[8] = h_refit[7]; }
+    };
     double lo[3], hi[3];
     // ---- normals of the down-sampled cloud (they orient the final ones)
     if (nrm) {
@@ -1999,12 +2336,72 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
         if (rc) return rc;
         PEDP_HIP_CHECK(hipMemcpyAsync(A_nrm, n_out_d, sizeof(double) * 3 * (size_t)m1, hipMemcpyDeviceToDevice, c->stream));
     }
-    // ---- the plane's inliers removed (no plane found: nothing removed, like select_by_index of an empty list)
+    // ---- compute_average_normal (:314-321): the normals' voxel averages on a 10-unit grid, their mean in row order
+    // (numpy's reduction over axis 0 adds row by row).  The caller normalises it -- numpy's norm is the caller's.
+    double avg[3] = {1.0, 1.0, 1.0};  // tracking frames: the reference's np.array([1, 1, 1]) (:217)
+    double *h_avg = (double *)((char *)c->pinned + 65536);  // sum xyz, voxels, overflow: valid after the stream's next wait
+    bool avg_pending = false;
+    auto average_by_sort = [&]() -> int {  // the sort-based grid (a grid too large for dense cells, or a crowded voxel)
+        double *g_pts = nullptr, *g_nrm = nullptr;
+        int64_t m10 = 0;
+        int st_ = voxel_core(c, A_pts, A_nrm, m1, avg_voxel, &g_pts, &g_nrm, &m10);
+        if (st_) return st_;
+        std::vector<double> vn(3 * (size_t)m10);
+        { int dn_ = pedp_download(c, vn.data(), g_nrm, sizeof(double) * 3 * (size_t)m10); if (dn_) return dn_; }
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (int64_t i = 0; i < m10; ++i)
+            for (int k = 0; k < 3; ++k) sum[k] += vn[3 * (size_t)i + k];
+        for (int k = 0; k < 3; ++k) avg[k] = sum[k] / (double)m10;
+        if (report) report[9] = (double)m10;
+        return PEDP_OK;
+    };
+    auto average_collect = [&]() -> int {  // after a wait on the stream
+        if (!avg_pending) return PEDP_OK;
+        avg_pending = false;
+        if (h_avg[4] != 0.0) return average_by_sort();   // (A_pts / A_nrm are still the down-sampled cloud here)
+        const int64_t m10 = (int64_t)h_avg[3];
+        const double *vn = (const double *)c->avg_host;  // the voxel means, written by avgn_mean_kernel
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (int64_t i = 0; i < m10; ++i)
+            for (int k = 0; k < 3; ++k) sum[k] += vn[3 * (size_t)i + k];
+        for (int k = 0; k < 3; ++k) avg[k] = sum[k] / (double)m10;
+        if (report) report[9] = h_avg[3];
+        return PEDP_OK;
+    };
+    if (seen && nrm) {
+        rc = average_normal_core(c, A_pts, A_nrm, m1, avg_voxel, box_lo, box_hi, d_part, h_avg, &avg_pending);
+        if (rc) return rc;
+        if (!avg_pending) { rc = average_by_sort(); if (rc) return rc; }
+    }
     int64_t m2 = m1;
-    hipLaunchKernelGGL(plane_keep_best_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1, (const double *)d_best,
-                       prm->plane_distance, flag);
-    rc = select_core(c, A_pts, nrm ? A_nrm : nullptr, m1, flag, B_pts, B_nrm, &m2);
+    if (box) {
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        rc = average_collect();
+        if (rc) return rc;
+        refit_collect();
+        // ---- flip_plane_normal_if_needed (:342-359) + remove_points_below_plane (:366-378).  Only the SIGN of
+        // dot(plane normal, average normal) is used; a dot product within rounding of zero is left to the step-by-step
+        // path (status AMBIGUOUS), whose numpy arithmetic is then the reference's to the letter.
+        if (!plane_found) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
+        const double pn = std::sqrt((refit[0] * refit[0] + refit[1] * refit[1]) + refit[2] * refit[2]);
+        const double an = nrm ? std::sqrt((avg[0] * avg[0] + avg[1] * avg[1]) + avg[2] * avg[2]) : 1.0;
+        const double dot = ((refit[0] * avg[0] + refit[1] * avg[1]) + refit[2] * avg[2]) / (pn * an);
+        if (!(std::fabs(dot) > 1e-9)) { *status = PEDP_PREPROCESS_AMBIGUOUS; return PEDP_OK; }
+        const int flipped = dot < 0.0 ? 1 : 0;
+        if (report) report[7] = (double)flipped;
+        hipLaunchKernelGGL(halfspace_keep_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1, refit[0], refit[1],
+                           refit[2], refit[3], flipped, flag);
+    } else {
+        // ---- the plane's inliers removed (no plane found: nothing removed, like select_by_index of an empty list)
+        hipLaunchKernelGGL(plane_keep_best_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, c->stream, A_pts, m1,
+                           (const double *)d_best, prm->plane_distance, flag);
+    }
+    rc = select_core(c, A_pts, carry ? A_nrm : nullptr, m1, flag, B_pts, B_nrm, &m2);
     if (rc) return rc;
+    rc = average_collect();  // (select_core has waited for the stream)
+    if (rc) return rc;
+    refit_collect();
+    if (report) for (int k = 0; k < 3; ++k) report[4 + k] = avg[k];
     if (stage_counts) stage_counts[1] = m2;
     if (m2 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }
     // ---- DBSCAN, largest cluster (np.unique + argmax: the lowest label among the largest)
@@ -2018,7 +2415,7 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     hipLaunchKernelGGL(label_keep_kernel, dim3((unsigned)((m2 + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_labels, m2,
                        (const int *)(d_members + m2), flag);
     int64_t m3 = 0;
-    rc = select_core(c, B_pts, nrm ? B_nrm : nullptr, m2, flag, C_pts, C_nrm, &m3);
+    rc = select_core(c, B_pts, carry ? B_nrm : nullptr, m2, flag, C_pts, C_nrm, &m3);
     if (rc) return rc;
     if (stage_counts) stage_counts[2] = m3;
     if (m3 == 0) { *status = PEDP_PREPROCESS_NO_CLUSTER; return PEDP_OK; }  // every label was noise
@@ -2031,22 +2428,22 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
     double *d_avg = nullptr;
     rc = knn_core(c, C_pts, m3, prm->outlier_neighbors, lo, hi, &d_avg);
     if (rc) return rc;
-    std::vector<double> avg((size_t)m3);
-    { int dn_ = pedp_download(c, avg.data(), d_avg, sizeof(double) * (size_t)m3); if (dn_) return dn_; }
+    std::vector<double> dist((size_t)m3);
+    { int dn_ = pedp_download(c, dist.data(), d_avg, sizeof(double) * (size_t)m3); if (dn_) return dn_; }
     int64_t valid = 0;
-    for (int64_t i = 0; i < m3; ++i) valid += avg[i] >= 0.0 ? 1 : 0;
+    for (int64_t i = 0; i < m3; ++i) valid += dist[i] >= 0.0 ? 1 : 0;
     int64_t m4 = 0;
     if (valid > 0) {
         double sum = 0.0;
-        for (int64_t i = 0; i < m3; ++i) sum += avg[i] > 0.0 ? avg[i] : 0.0;
+        for (int64_t i = 0; i < m3; ++i) sum += dist[i] > 0.0 ? dist[i] : 0.0;
         const double mean = sum / (double)valid;
         double sq = 0.0;
-        for (int64_t i = 0; i < m3; ++i) sq += avg[i] > 0.0 ? (avg[i] - mean) * (avg[i] - mean) : 0.0;
+        for (int64_t i = 0; i < m3; ++i) sq += dist[i] > 0.0 ? (dist[i] - mean) * (dist[i] - mean) : 0.0;
         const double sd = valid > 1 ? std::sqrt(sq / (double)(valid - 1)) : std::nan("");
         const double limit = mean + prm->outlier_std_ratio * sd;
         hipLaunchKernelGGL(range_keep_kernel, dim3((unsigned)((m3 + 255) / 256)), dim3(256), 0, c->stream, (const double *)d_avg, m3, limit,
                            flag);
-        rc = select_core(c, C_pts, nrm ? C_nrm : nullptr, m3, flag, A_pts, A_nrm, &m4);
+        rc = select_core(c, C_pts, carry ? C_nrm : nullptr, m3, flag, A_pts, A_nrm, &m4);
         if (rc) return rc;
     }
     if (stage_counts) stage_counts[3] = m4;
@@ -2058,7 +2455,7 @@ int pedp_preprocess_source(pedp_ctx_t c, const double *pts, int64_t N, int pts_o
         rc = bounds_device(c, A_pts, m4, d_part, lo, hi);
         if (rc) return rc;
         double *n_fin = nullptr;
-        rc = normals_core(c, A_pts, m4, prm->normal_radius, prm->normal_max_nn, A_nrm, lo, hi, &n_fin);
+        rc = normals_core(c, A_pts, m4, prm->normal_radius, prm->normal_max_nn, carry ? A_nrm : nullptr, lo, hi, &n_fin);
         if (rc) return rc;
         { int dn_ = pedp_download(c, out_normals, n_fin, sizeof(double) * 3 * (size_t)m4); if (dn_) return dn_; }
     }

@@ -77,3 +77,28 @@ extern "C" int pedp_cluster_poses(float angle_diff_deg, float dist_diff, const f
     *n_keep = nk;
     return PEDP_OK;
 }
+
+// Rigid transform of a host array (include/pedp.h): the holders' transform().  -ffp-contract=off: no fused multiply-add.
+extern "C" int pedp_transform_points(const double T[16], const double *in, int64_t n, int rotate_only, double *out) {
+    if (!T || n < 0 || (n > 0 && (!in || !out))) {
+        pedp_set_error("pedp_transform_points: bad arguments (n=%lld)", (long long)n);
+        return PEDP_ERR_BAD_ARG;
+    }
+    const double t0 = rotate_only ? 0.0 : T[3], t1 = rotate_only ? 0.0 : T[7], t2 = rotate_only ? 0.0 : T[11];
+    if (rotate_only) {
+        for (int64_t i = 0; i < n; ++i) {
+            const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+            out[3 * i] = (T[0] * x + T[1] * y) + T[2] * z;
+            out[3 * i + 1] = (T[4] * x + T[5] * y) + T[6] * z;
+            out[3 * i + 2] = (T[8] * x + T[9] * y) + T[10] * z;
+        }
+        return PEDP_OK;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = ((T[0] * x + T[1] * y) + T[2] * z) + t0;
+        out[3 * i + 1] = ((T[4] * x + T[5] * y) + T[6] * z) + t1;
+        out[3 * i + 2] = ((T[8] * x + T[9] * y) + T[10] * z) + t2;
+    }
+    return PEDP_OK;
+}

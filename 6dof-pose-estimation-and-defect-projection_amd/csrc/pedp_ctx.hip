@@ -206,7 +206,7 @@ int pedp_ctx_create(int device, void *stream, pedp_ctx_t *out) {
         pedp_ctx_destroy(c);
         return PEDP_ERR_HIP;
     }
-    c->pinned_cap = 1 << 16;
+    c->pinned_cap = 1 << 17;  // [0, 64 K): the registrations' states and the operations' counters; above: preprocess_source's average normal (64 K) and refit plane (65 K), the jet table (68 K)
     if (hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault) != hipSuccess) {
         pedp_set_error("pedp_ctx_create: hipHostMalloc failed");
         pedp_ctx_destroy(c);
@@ -247,6 +247,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
     c->ops.release();
     c->proj_out.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->avg_host) (void)hipHostFree(c->avg_host);
     for (int k = 0; k < 2; ++k)
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -119,6 +119,8 @@ struct pedp_ctx_s {
     pedp_pool cloud_pool;    // buffers of destroyed cloud handles
     pedp_scratch ops_small;  // partial bounds and counters of the point-cloud operations
     pedp_scratch chain;      // pedp_preprocess_source: the clouds between its stages
+    void *avg_host = nullptr;  // pinned: preprocess_source's voxel means of the normals, written by the kernel itself (zero copy)
+    size_t avg_host_cap = 0;
     pedp_scratch ops_in;     // a large cloud's points, uploaded ahead of the workspace sizing (its box comes from the device copy)
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)

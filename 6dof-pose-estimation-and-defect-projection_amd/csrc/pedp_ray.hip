@@ -1426,6 +1426,20 @@ __global__ void pose_verts_kernel(const double *__restrict__ v64, int64_t V, Pos
     v32[3 * i + 2] = (float)(h[2] / h[3]);
 }
 
+// the same T * (x, y, z, 1) / w in float64, kept as float64: what TriangleMesh.transform leaves in `vertices`
+__global__ void pose_verts64_kernel(const double *__restrict__ v64, int64_t V, Pose16 T, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const double x = v64[3 * i], y = v64[3 * i + 1], z = v64[3 * i + 2];
+    double h[4];
+    for (int r = 0; r < 4; ++r)
+        h[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T.m[4 * r], x), __dmul_rn(T.m[4 * r + 1], y)),
+                                   __dmul_rn(T.m[4 * r + 2], z)), T.m[4 * r + 3]);
+    out[3 * i] = h[0] / h[3];
+    out[3 * i + 1] = h[1] / h[3];
+    out[3 * i + 2] = h[2] / h[3];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1533,6 +1547,27 @@ int pedp_mesh_set_pose(pedp_mesh_t m, const double T[16]) {
                            m->V, P, T ? 0 : 1, m->verts32);
     PEDP_HIP_CHECK(hipGetLastError());
     PEDP_HIP_CHECK(mesh_build_records(c, m, m->verts32, m->idx));
+    return PEDP_OK;
+}
+
+int pedp_mesh_posed_vertices(pedp_mesh_t m, const double T[16], int mem, double *out) {
+    PEDP_REQUIRE(m && T && out, "pedp_mesh_posed_vertices: null argument");
+    PEDP_REQUIRE(m->verts64, "pedp_mesh_posed_vertices: mesh was not created with pedp_mesh_create_posable");
+    PEDP_REQUIRE(mem == PEDP_HOST || mem == PEDP_DEVICE, "pedp_mesh_posed_vertices: bad mem flag %d", mem);
+    if (m->V == 0) return PEDP_OK;
+    pedp_ctx_t c = m->ctx;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    Pose16 P;
+    for (int k = 0; k < 16; ++k) P.m[k] = T[k];
+    double *d_out = out;
+    if (mem == PEDP_HOST) {
+        int st = c->ray_out.reserve(sizeof(double) * 3 * (size_t)m->V);
+        if (st) return st;
+        d_out = (double *)c->ray_out.ptr;
+    }
+    hipLaunchKernelGGL(pose_verts64_kernel, dim3((unsigned)((m->V + 255) / 256)), dim3(256), 0, c->stream, m->verts64, m->V, P, d_out);
+    PEDP_HIP_CHECK(hipGetLastError());
+    if (mem == PEDP_HOST) { int dn_ = pedp_download(c, out, d_out, sizeof(double) * 3 * (size_t)m->V); if (dn_) return dn_; }
     return PEDP_OK;
 }
 

@@ -26,57 +26,120 @@ def _on_device(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
+def _frozen(a):
+    """True when nobody can write to the array's memory through numpy: it (or the array it views) owns the data and is
+    read-only.  Such arrays are passed between holders without a copy."""
+    if a.flags.writeable:
+        return False
+    base = a if a.flags.owndata else a.base
+    return isinstance(base, np.ndarray) and base.flags.owndata and not base.flags.writeable
+
+
+def _own(x, cols=3, dtype=np.float64, adopt=False):
+    """The holder's own, immutable array of `x` (N x cols): frozen arrays are taken as they are; `adopt` freezes the
+    caller's fresh array in place (the caller gives it up); everything else is copied, like Open3D's Vector3dVector(array)."""
+    a = np.asarray(x, dtype=dtype)
+    fresh = a is not x and a.base is None                       # np.asarray had to convert: nobody else holds the result
+    a = a.reshape(-1, cols) if a.size else np.zeros((0, cols), dtype)
+    if _frozen(a):
+        return a
+    base = a if a.flags.owndata else a.base
+    if not ((adopt or fresh) and isinstance(base, np.ndarray) and base.flags.owndata and a.flags.c_contiguous):
+        a = np.array(a, dtype=dtype, order="C")
+        base = a
+    base.setflags(write=False)
+    a.setflags(write=False)
+    return a
+
+
+def rigid(points, T, rotate_only=False):
+    """Rows moved by the 4x4 T (normals: rotation only) -- pedp_transform_points, the oracle's operation order."""
+    from . import _lib
+
+    if len(points) == 0:
+        return np.zeros((0, 3))
+    return _lib.transform_points(T, points, rotate_only)
+
+
 class PointCloud:
     """Open3D-shaped holder: `points` / `normals` / `colors` are N x 3 float64 numpy arrays.
+
+    The holder OWNS its arrays, like an Open3D cloud owns its vectors: the constructor and the setters copy what they are
+    given (Vector3dVector(array) does), and what the accessors hand out is read-only -- an in-place edit
+    (`np.asarray(pcd.points)[mask] = ...`, which Open3D lets through) raises instead of leaving a stale device copy
+    behind; assign a new array (`pcd.points = edited`).  That makes the kept device copy of a holder exact: it is valid as
+    long as the holder's version counter, bumped by every setter and transform, has not moved (pedp_hip.registration.upload).
+    `PointCloud.adopt(points, normals)` takes fresh arrays without a copy (the caller gives them up);
+    `PointCloud.borrowed(points)` wraps a large array the caller keeps -- a frame's full scene cloud in a pinned buffer --
+    without a copy and WITHOUT a kept device copy (the caller may rewrite the buffer for the next frame).
 
     `points` may also be given as a float64 N x 3 torch tensor on the GPU (a scene back-projected there,
     estimater.py hands CUDA tensors around): the holder keeps the tensor, `voxel_down_sample` works from it,
     and the numpy array is only made if somebody reads `points`.
 
     A holder made by `moved_copy` (the moved model `refine_pose_with_icp` returns and run.py:99 throws away) forms its
-    points and normals when they are first read: until then it keeps the source's arrays as they were handed over and the
-    4x4.  Our holders replace their arrays when they change, they do not write into them; a caller that edits the
-    source's arrays in place before reading the copy should read the copy first."""
+    points and normals when they are first read: until then it keeps the source's (immutable) arrays and the 4x4."""
 
-    def __init__(self, points=None, normals=None, colors=None):
+    def __init__(self, points=None, normals=None, colors=None, _adopt=False):
         self._dev_points = None
         self._moved = None            # (points, normals, T): a moved copy that nobody has read yet
+        self._version = 0             # bumped whenever points or normals change: keys the kept device copy
+        self._borrowed = False
         if _on_device(points):
             self._dev_points, self._points = points.reshape(-1, 3), None
         else:
-            self._points = _arr([] if points is None else points)
-        self._normals = _arr([] if normals is None else normals)
+            self._points = _own([] if points is None else points, adopt=_adopt)
+        self._normals = _own([] if normals is None else normals, adopt=_adopt)
         self._uniform = None          # paint_uniform_color: one colour for every point, written out when read
-        self.colors = _arr([] if colors is None else colors)
+        self._colors = _own([] if colors is None else colors, adopt=_adopt)
+
+    @classmethod
+    def adopt(cls, points, normals=None, colors=None):
+        """A holder over fresh arrays the caller hands over for good (results of the library's operations): no copy."""
+        return cls(points, normals, colors, _adopt=True)
+
+    @classmethod
+    def borrowed(cls, points):
+        """A holder over an array the caller keeps and may rewrite after the holder has served (a frame's scene cloud in a
+        pinned buffer): no copy, no kept device copy."""
+        out = cls()
+        a = np.asarray(points, dtype=np.float64)
+        out._points = a.reshape(-1, 3) if a.size else np.zeros((0, 3))
+        out._borrowed = True
+        return out
 
     @classmethod
     def moved_copy(cls, source, T):
         """What copy.deepcopy(source).transform(T) gives (same arithmetic, pose_estimation.py:815-816), formed on first read."""
-        out = cls(colors=None if source._uniform is not None else np.array(source._colors))
+        out = cls(colors=None if source._uniform is not None else source._colors)
         if source._uniform is not None:
             out.paint_uniform_color(source._uniform)
         out._points = None
-        out._moved = (np.asarray(source.points, np.float64), np.asarray(source.normals, np.float64), np.array(T, dtype=np.float64))
+        pts, nrm = source.points, source.normals
+        if source._borrowed:
+            pts = np.array(pts)
+        out._moved = (pts, nrm, np.array(T, dtype=np.float64))
         return out
 
     def _form(self):
         if self._moved is not None:
             pts, nrm, T = self._moved
             self._moved = None
-            self._points = pts @ T[:3, :3].T + T[:3, 3]
-            self._normals = nrm @ T[:3, :3].T if len(nrm) else _arr([])
+            self._points = _own(rigid(pts, T), adopt=True)
+            self._normals = _own(rigid(nrm, T, rotate_only=True) if len(nrm) else [], adopt=True)
 
     @property
     def points(self):
         self._form()
         if self._points is None:
-            self._points = _arr(self._dev_points.detach().cpu().numpy())
+            self._points = _own(self._dev_points.detach().cpu().numpy(), adopt=True)
         return self._points
 
     @points.setter
     def points(self, value):
         self._form()
-        self._points, self._dev_points = value, None
+        self._points, self._dev_points, self._borrowed = _own(value), None, False
+        self._version += 1
 
     @property
     def normals(self):
@@ -86,7 +149,8 @@ class PointCloud:
     @normals.setter
     def normals(self, value):
         self._form()
-        self._normals = value
+        self._normals = _own(value)
+        self._version += 1
 
     def _count(self):
         if self._moved is not None:
@@ -96,13 +160,13 @@ class PointCloud:
     @property
     def colors(self):
         if self._uniform is not None:
-            self._colors = np.tile(self._uniform, (self._count(), 1))
+            self._colors = _own(np.tile(self._uniform, (self._count(), 1)), adopt=True)
             self._uniform = None
         return self._colors
 
     @colors.setter
     def colors(self, value):
-        self._colors = value
+        self._colors = _own(value)
         self._uniform = None
 
     def has_normals(self):
@@ -118,11 +182,13 @@ class PointCloud:
         return self._count() > 0
 
     def transform(self, T):
-        """In place, float64, like Open3D: points by the full 4x4, normals by the rotation."""
+        """In place, float64, like Open3D: points by the full 4x4, normals by the rotation (pedp_transform_points)."""
         T = np.asarray(T, dtype=np.float64)
-        self.points = np.asarray(self.points, np.float64) @ T[:3, :3].T + T[:3, 3]
-        if len(self.normals):
-            self.normals = np.asarray(self.normals, np.float64) @ T[:3, :3].T
+        pts, nrm = self.points, self.normals
+        self._points, self._dev_points, self._borrowed = _own(rigid(pts, T), adopt=True), None, False
+        if len(nrm):
+            self._normals = _own(rigid(nrm, T, rotate_only=True), adopt=True)
+        self._version += 1
         return self
 
     def paint_uniform_color(self, rgb):
@@ -136,7 +202,9 @@ class PointCloud:
         return self._count()
 
     def __deepcopy__(self, memo):
-        out = PointCloud(np.array(self.points), np.array(self.normals), None if self._uniform is not None else np.array(self._colors))
+        out = PointCloud(self.points, self.normals, None if self._uniform is not None else self._colors)   # (immutable arrays: shared)
+        if self._borrowed:
+            out._points = _own(np.array(self._points), adopt=True)
         if self._uniform is not None:
             out.paint_uniform_color(self._uniform)
         return out
@@ -150,8 +218,8 @@ class PointCloud:
             mask = np.ones(len(self.points), bool)
             mask[idx] = False
             idx = np.nonzero(mask)[0]
-        out = PointCloud(np.asarray(self.points)[idx], self.normals[idx] if self.has_normals() else None,
-                         self._colors[idx] if self._uniform is None and self.has_colors() else None)
+        out = PointCloud.adopt(np.asarray(self.points)[idx], self.normals[idx] if self.has_normals() else None,
+                               self._colors[idx] if self._uniform is None and self.has_colors() else None)
         if self._uniform is not None:
             out.paint_uniform_color(self._uniform)
         return out
@@ -163,7 +231,7 @@ class PointCloud:
             pts, nrm = cloud_ops.voxel_down_sample(self._dev_points, voxel_size)
         else:
             pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)
-        return PointCloud(pts, nrm)
+        return PointCloud.adopt(pts, nrm)
 
     def segment_plane(self, distance_threshold, ransac_n, num_iterations, probability=0.99999999):
         from . import cloud_ops
@@ -181,8 +249,9 @@ class PointCloud:
         from . import cloud_ops
 
         sp = search_param or KDTreeSearchParamHybrid(radius=0.1, max_nn=30)
-        self.normals = cloud_ops.estimate_normals(self.points, sp.radius, sp.max_nn,
-                                                  self.normals if self.has_normals() else None)
+        self._normals = _own(cloud_ops.estimate_normals(self.points, sp.radius, sp.max_nn,
+                                                        self.normals if self.has_normals() else None), adopt=True)
+        self._version += 1
         return self
 
     def remove_statistical_outlier(self, nb_neighbors, std_ratio, print_progress=False):
@@ -208,11 +277,11 @@ class TriangleMesh:
 
     def transform(self, T):
         T = np.asarray(T, dtype=np.float64)
-        self.vertices = np.asarray(self.vertices, np.float64) @ T[:3, :3].T + T[:3, 3]
+        self.vertices = rigid(self.vertices, T)
         if len(self.vertex_normals):
-            self.vertex_normals = self.vertex_normals @ T[:3, :3].T
+            self.vertex_normals = rigid(self.vertex_normals, T, rotate_only=True)
         if len(self.triangle_normals):
-            self.triangle_normals = self.triangle_normals @ T[:3, :3].T
+            self.triangle_normals = rigid(self.triangle_normals, T, rotate_only=True)
         return self
 
     def has_triangle_normals(self):
@@ -259,7 +328,7 @@ class LineSet:
 
     def transform(self, T):
         T = np.asarray(T, dtype=np.float64)
-        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        self.points = rigid(self.points, T)
         return self
 
 

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import registration as reg
 from .geometry import (KDTreeSearchParamHybrid, PointCloud, RegistrationResult, TriangleMesh, as_holder, clone, normals_of,
-                       points_of)
+                       points_of, rigid)
 
 
 def _copy_parameters(tree):
@@ -47,9 +47,9 @@ def transform_object(pcd, transformation):
         return PointCloud.moved_copy(pcd, transformation)   # formed when first read (run.py:99 never reads it)
     if type(pcd) is TriangleMesh:
         T = np.asarray(transformation, dtype=np.float64)
-        moved = TriangleMesh(np.asarray(pcd.vertices, np.float64) @ T[:3, :3].T + T[:3, 3], np.array(pcd.triangles))
-        moved.vertex_normals = pcd.vertex_normals @ T[:3, :3].T if len(pcd.vertex_normals) else np.array(pcd.vertex_normals)
-        moved.triangle_normals = pcd.triangle_normals @ T[:3, :3].T if len(pcd.triangle_normals) else np.array(pcd.triangle_normals)
+        moved = TriangleMesh(rigid(pcd.vertices, T), np.array(pcd.triangles))
+        moved.vertex_normals = rigid(pcd.vertex_normals, T, rotate_only=True) if len(pcd.vertex_normals) else np.array(pcd.vertex_normals)
+        moved.triangle_normals = rigid(pcd.triangle_normals, T, rotate_only=True) if len(pcd.triangle_normals) else np.array(pcd.triangle_normals)
         return moved
     moved = clone(pcd)
     moved.transform(transformation)
@@ -88,7 +88,7 @@ def preprocess_target(pcd, param):
     pts, nrm = points_of(pcd), normals_of(pcd)
     if len(pts) > cap:
         keep = np.random.choice(len(pts), cap, replace=False)
-        out = PointCloud(pts[keep], None if nrm is None else nrm[keep])
+        out = PointCloud.adopt(pts[keep], None if nrm is None else nrm[keep])
         if hasattr(pcd, "has_colors") and pcd.has_colors():
             out.colors = np.asarray(pcd.colors)[keep]
     else:
@@ -148,7 +148,7 @@ def remove_points_below_plane(pcd, plane_model):
     a, b, c, d = plane_model
     points = points_of(pcd)
     distances = (a * points[:, 0] + b * points[:, 1] + c * points[:, 2] + d) / np.sqrt(a ** 2 + b ** 2 + c ** 2)
-    return PointCloud(points[distances <= 0])
+    return PointCloud.adopt(points[distances <= 0])
 
 
 def background_removal(pcd, background_pcd, threshold=10):
@@ -193,21 +193,40 @@ def preprocess_source(pcd, background, param, i=0):
     if i > 0:
         params["down_sample"] = 5
     pcd, background = as_holder(pcd), as_holder(background)  # Open3D inputs: the GPU methods, not Open3D's
-    # The branch run.py takes -- no box, no mesh, no background cloud, nobody reading the INFO lines -- runs as ONE
-    # library call with the scene on the device between the stages (pedp_preprocess_source): the same kernels and
-    # rules as the calls below, bit for bit the same cloud (tests/test_cloudops_gpu.py).  Anything else, and a
-    # frame that leaves no cluster, goes through the steps, whose behaviour is then the reference's to the letter.
-    if (background is None and not param.get("box") and not param.get("mesh")
-            and not logging.getLogger().isEnabledFor(logging.INFO) and not _FORCE_STEPS):
+    # Every branch run.py can take except param['mesh'] runs as ONE library call with the scene on the device between
+    # the stages (pedp_preprocess_source_ex): the same kernels and rules as the calls below, bit for bit the same cloud
+    # (tests/test_cloudops_gpu.py).  run.py always passes reader.background (run.py:99-101, :154-156) and logs at INFO
+    # (run.py:252, :260): the background cloud changes nothing a caller can see -- its down-sampled copy and normals
+    # (:204, :252) are locals of the reference's function, without param['box'] the cut it could take part in is
+    # overwritten (:232-236) and with it background_removal returns its input (:386-388) -- so its work is skipped; the
+    # two INFO lines (:220, :356) get the average normal and the refit plane back from the call.  A frame that leaves no
+    # cluster, an undecidable plane flip and param['debug_vis'] (the reference's screenshots, :206-268) go through the
+    # steps, whose behaviour is then the reference's to the letter.
+    box = bool(param.get("box"))
+    info = logging.getLogger().isEnabledFor(logging.INFO)
+    if not param.get("mesh") and not param.get("debug_vis") and not _FORCE_STEPS:
         from . import cloud_ops
 
         src_pts = pcd._dev_points if getattr(pcd, "_points", 0) is None and pcd._dev_points is not None else points_of(pcd)
         plane = params["plane_removal"]
-        out_p, out_n, _, status = cloud_ops.preprocess_source_fused(src_pts, params["down_sample"], plane["distance_threshold"],
-                                                                    plane["num_iterations"], first_frame=(i == 0))
-        if status == 0:
-            source_processed = PointCloud(out_p, out_n)
-            return source_processed, source_processed, (fpfh_of(source_processed, params) if i == 0 else 0)
+        res = cloud_ops.preprocess_source_fused(src_pts, params["down_sample"], plane["distance_threshold"], plane["num_iterations"],
+                                                first_frame=(i == 0), box=box, report=(info or box))
+        if res[3] == 0:
+            flipped, average_normal = None, np.array([1, 1, 1], dtype=float)
+            if info or box:           # the reference's own numpy expressions (:217-222, :342-359) on the call's report
+                rep = res[4]
+                if i == 0:
+                    average_normal = rep["mean_normal"] / np.linalg.norm(rep["mean_normal"])
+                plane_normal = np.array(rep["plane_model"][:3], dtype=np.float64)
+                plane_normal /= np.linalg.norm(plane_normal)
+                flipped = bool(np.dot(plane_normal, average_normal) < 0)
+            if not box or flipped == rep["flipped"]:
+                if i == 0 and info:
+                    logging.info(f":: Average Normal for Source = {average_normal}")
+                if flipped:
+                    logging.info(":: Plane normal was flipped to match the majority of normals.")
+                source_processed = PointCloud.adopt(res[0], res[1])
+                return source_processed, source_processed, (fpfh_of(source_processed, params) if i == 0 else 0)
     if background is not None:
         background = background.voxel_down_sample(voxel_size=params["down_sample"] * 2)
     pcd_down = pcd.voxel_down_sample(voxel_size=params["down_sample"])
@@ -215,8 +234,7 @@ def preprocess_source(pcd, background, param, i=0):
     # Without param['box'] the half-space cut below is thrown away (the reference overwrites it, :232-236), and
     # with it the only reader of the flipped plane and of the average normal -- apart from two log lines.
     # They are worked out when something can see them: the box branch, or INFO logging.
-    box = bool(param.get("box"))
-    seen = box or logging.getLogger().isEnabledFor(logging.INFO)
+    seen = box or info
     average_normal = np.array([1, 1, 1], dtype=float)
     if i == 0:
         estimate_normals(pcd_down, params)      # (kept either way: these normals orient the final ones)

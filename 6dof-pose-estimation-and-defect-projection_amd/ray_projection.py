@@ -118,7 +118,7 @@ def create_intersection_pcd(intersections, intensities):
     """Hit points coloured by min-max normalised intensity through 'jet'
     (defect_projection.py:268-294).  Equal intensities divide by zero in the reference too
     (NaN -> black)."""
-    pcd = PointCloud(intersections)
+    pcd = PointCloud.adopt(intersections) if isinstance(intersections, np.ndarray) and intersections.flags.owndata else PointCloud(intersections)
     intensities = np.asarray(intensities, dtype=np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
         scaled = (intensities - np.min(intensities)) / (np.max(intensities) - np.min(intensities))
@@ -198,16 +198,36 @@ class FrameProjector:
         self.mesh = _lib.Mesh(self.ctx, np.asarray(model_mesh.vertices, np.float64), np.asarray(model_mesh.triangles),
                               posable=True)
 
-    def project(self, pose, heatmap, heatmap_threshold=0.5, details=None):
-        """pose: model -> depth-camera 4x4.  Returns the jet-coloured hit cloud, or None when
-        no ray hits; `details` (dict) receives pixels / primitive_ids / n_rays."""
+    def project(self, pose, heatmap, heatmap_threshold=0.5, details=None, into=None):
+        """pose: model -> depth-camera 4x4.  heatmap: H x W float64 / float32, a numpy array or a CUDA tensor (a
+        detector's output, or a map kept on the device between detections: no upload).  into (4 x 4, optional): the hit
+        cloud is moved by it on the device -- run.py:118 / :200 `cloud.transform(reader.color_to_depth)` in the same
+        call.  Returns the jet-coloured hit cloud (colours from the device, create_intersection_pcd's arithmetic), or
+        None when no ray hits; `details` (dict) receives pixels / primitive_ids / n_rays."""
         self.mesh.set_pose(self.depth_to_color @ np.asarray(pose, dtype=np.float64))
-        out = self.mesh.project_heatmap(heatmap, self.K, heatmap_threshold)
+        out = self.mesh.project_heatmap(heatmap, self.K, heatmap_threshold, jet_lut=_jet_lut(), post=into)
         if details is not None:
             details.update(out)
         if len(out["points"]) == 0:
             return None
-        return create_intersection_pcd(out["points"], out["intensities"])
+        return PointCloud.adopt(out["points"], colors=out["colors"])
+
+    def posed_mesh(self, pose, template):
+        """transform_object(reader.target_mesh, pose) (run.py:109-110, :179-181) from the resident model: the float64
+        posed vertices come from the device (pedp_mesh_posed_vertices: the arithmetic pedp_mesh_set_pose starts from),
+        the triangles are the template's (read-only, shared: the copy the viewer gets is never written to)."""
+        from .geometry import TriangleMesh
+
+        tris = np.asarray(template.triangles)
+        tris = tris.view()
+        tris.setflags(write=False)
+        mesh = TriangleMesh(self.mesh.posed_vertices(pose))
+        mesh.triangles = tris
+        if len(template.vertex_normals) or len(template.triangle_normals):
+            from .geometry import rigid
+            mesh.vertex_normals = rigid(template.vertex_normals, pose, rotate_only=True) if len(template.vertex_normals) else np.zeros((0, 3))
+            mesh.triangle_normals = rigid(template.triangle_normals, pose, rotate_only=True) if len(template.triangle_normals) else np.zeros((0, 3))
+        return mesh
 
 
 # ---------------------------------------------------------------- depth-based projection

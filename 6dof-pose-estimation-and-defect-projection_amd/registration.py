@@ -57,21 +57,8 @@ def get_rotation_matrix_from_xyz(rotation):
     ])
 
 
-def _fingerprint(pts, nrm):
-    """Cheap identity of a holder's arrays: their memory (address, shape) and 32 sampled rows, so that a holder whose
-    points were replaced (transform assigns new arrays) or rewritten in place is uploaded again.  Not the array
-    OBJECTS: the holder's accessors hand out a fresh view of the same memory on every call."""
-    step = max(len(pts) // 32, 1)
-    key = (pts.ctypes.data, pts.shape, pts[::step].tobytes())
-    if nrm is not None:
-        key += (nrm.ctypes.data, nrm[::step].tobytes())
-    return key
-
-
 def forget_device_copy(cloud):
-    """Drop a holder's kept device copy.  The key above notices a replaced array and a rewrite that touches the sampled
-    rows (any transform does); a caller that edits single rows of `points` in place between two registrations calls this
-    (or assigns a new array) to have the cloud uploaded again."""
+    """Drop a holder's kept device copy (it is dropped by itself whenever the holder's points or normals change)."""
     if hasattr(cloud, "_device_copy"):
         cloud._device_copy = None
 
@@ -80,19 +67,20 @@ def upload(cloud, ctx=None):
     """Device copy of a PointCloud-like object; pass the returned handle to registration_icp
     when the same cloud is registered many times (improve_result does ~50 calls per frame).
     A PointCloud holder keeps its device copy: the model cloud of a camera loop -- the same holder in every frame's
-    z search and restarts -- is uploaded, ordered and packed once, not twice per frame."""
+    z search and restarts -- is uploaded, ordered and packed once, not twice per frame.  The kept copy is EXACT: a holder
+    owns immutable arrays (geometry.PointCloud: in-place edits raise, setters and transforms replace the arrays and bump
+    the holder's version), so the copy is valid exactly as long as the version it was made from is the holder's.
+    Holders over borrowed memory (PointCloud.borrowed) and foreign objects are uploaded every time."""
     if isinstance(cloud, _lib.Cloud):
         return cloud
     ctx = ctx or _lib.default_context()
     pts, nrm = points_of(cloud), normals_of(cloud)
-    if isinstance(cloud, PointCloud) and len(pts):
-        p64 = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
-        n64 = None if nrm is None else np.ascontiguousarray(nrm, np.float64).reshape(-1, 3)
-        key = (id(ctx),) + _fingerprint(p64, n64)
+    if isinstance(cloud, PointCloud) and len(pts) and not cloud._borrowed:
+        key = (id(ctx), cloud._version)
         kept = getattr(cloud, "_device_copy", None)
         if kept is not None and kept[0] == key:
             return kept[1]
-        handle = _lib.Cloud(ctx, p64, n64)
+        handle = _lib.Cloud(ctx, pts, nrm)
         cloud._device_copy = (key, handle)
         return handle
     return _lib.Cloud(ctx, pts, nrm)

@@ -354,12 +354,21 @@ def run(args):
             fr_elapsed, fr_res, _ = timed_region(step_fresh, args.steps, 2)
             extras["fresh_frame"] = (fr_elapsed, fr_res, np.array(fresh_wall[-args.steps:]), _lib.raycast_last_variant(ray_ctx))
             del pmesh, base_dev, noise_dev
-            # ---- frame_chain region: BASELINE config 5's geometry chain, a new depth image per frame
+            # ---- frame_chain / tracking_frame regions: BASELINE config 5's geometry chain, a new depth image per frame,
+            # both branches of run.py's loop with the arguments run.py passes: the reader's background cloud
+            # (run.py:99-101, :154-156) and the root logger at INFO in the reference's format (run.py:252, :260;
+            # Utils.py:94-99) -- the lines are formatted and written like the reference's, to a null sink
+            import logging
             import queue as _queue
             from pedp_hip import viewer_wire
             from pedp_hip.frame_chain import bench_frame_setup
             chain, depth_m, heat, init_pose = bench_frame_setup(frame, depth)
             viewer_wire.attach_queues(_queue.Queue())
+            root_log = logging.getLogger()
+            log_level, log_sink = root_log.level, logging.StreamHandler(open(os.devnull, "w"))
+            log_sink.setFormatter(logging.Formatter("[%(funcName)s()] %(message)s"))
+            root_log.addHandler(log_sink)
+            root_log.setLevel(logging.INFO)
             drng = np.random.default_rng(7)
             depth_k = [(depth_m + drng.normal(0.0, 2e-4, depth_m.shape)).astype(np.float32) for _ in range(4)]
             n_done = [0]
@@ -381,8 +390,31 @@ def run(args):
                 return {"T": out_k["icp"].transformation}
 
             fd_elapsed, fd_res, _ = timed_region(step_chain_dev, fc_steps, 2)
+            # run.py:132-207: every step a tracking frame with a defect detection pending -- preprocess_source(i > 0),
+            # improve_result from the tracker's bare 4x4, delta_pose, posed mesh, projection of a new heat map, the earlier
+            # hit clouds moved by relative_transformation (two detections are kept: the list of run.py:61 grows with the
+            # run; the bench holds it at frame 0's cloud plus the last one), update_dash_data
+            out0 = chain.process(depth_k[0], init_pose(), heat, seed=0)          # frame 0 of this run (run.py:79-131)
+            tracker_pose = np.linalg.inv(out0["icp"].transformation)
+            tracker_pose[:3, 3] += (0.8, -0.5, 1.0)                               # est.track_one's estimate: close, not equal
+            heat_t = np.zeros_like(heat)
+            heat_t[150:330, 260:460] = np.linspace(0.76, 1.0, 200)[None, :]
+            n_done[0] = 1
+
+            def step_tracking():
+                del chain.intersection_pcds[1:]
+                out_k = chain.process_tracking(depth_k[n_done[0] % 4], tracker_pose.copy(), heat_t, i=n_done[0], seed=n_done[0])
+                n_done[0] += 1
+                return {"T": out_k["icp"].transformation, "fitness": out_k["icp"].fitness, "n_hits": len(out_k["cloud"].points),
+                        "n_processed": len(out_k["source_processed"].points)}
+
+            tf_elapsed, tf_res, _ = timed_region(step_tracking, fc_steps, 2)
+            chain.process_tracking(depth_k[0], tracker_pose.copy(), heat_t, i=n_done[0], seed=0, timed=True)
             extras["frame_chain"] = (fc_steps, fc_elapsed, fc_res, stage_ms, fd_elapsed)
+            extras["tracking_frame"] = (fc_steps, tf_elapsed, tf_res, dict(chain.stage_ms))
             viewer_wire.attach_queues(None)
+            root_log.removeHandler(log_sink)
+            root_log.setLevel(log_level)
         # ---- BASELINE config 3: 256 start poses refined concurrently (groups of 32 share launches), poses sharded over the ranks
         inits = np.stack([np.linalg.inv(T) for T in synth.batched_start_poses(256)])
         lo, hi = pdist.shard_bounds(len(inits), rank, world)
@@ -561,10 +593,22 @@ def run(args):
                 "ms_per_frame_device_scene": 1e3 * fd_elapsed / fc_steps,   # PointCloud over the CUDA tensor: no 9 MB down and up again
                 "stage_ms": fc_stage, "icp_fitness": fc_res["fitness"], "projected_hits": fc_res["n_hits"],
                 "pose_error_vs_gt": float(np.abs(np.linalg.inv(fc_res["T"]) - frame.T_gt).max()),
-                "note": "BASELINE config 5, geometry part (pedp_hip.frame_chain; tests/test_stream_gpu.py checks every stage "
-                        "against the oracle): a new 640x576 depth image per frame -> depth filters -> back-projection -> "
-                        "preprocess_source -> z search -> randomised ICP restarts -> posed mesh -> heat-map projection -> "
+                "arguments": "run.py's: reader.background passed (368,640-point empty scene), root logger at INFO",
+                "note": "BASELINE config 5, geometry part, run.py:79-131 (pedp_hip.frame_chain; tests/test_stream_gpu.py checks "
+                        "every stage against the oracle): a new 640x576 depth image per frame -> depth filters -> back-projection "
+                        "-> preprocess_source -> z search -> randomised ICP restarts -> posed mesh -> heat-map projection -> "
                         "viewer message.  stage_ms from one extra, synchronised frame outside the timed region"}
+        if "tracking_frame" in extras:
+            tf_steps, tf_elapsed, tf_res, tf_stage = extras["tracking_frame"]
+            out["tracking_frame"] = {
+                "frames": tf_steps, "ms_per_frame": 1e3 * tf_elapsed / tf_steps, "frames_per_s": tf_steps / tf_elapsed,
+                "stage_ms": tf_stage, "icp_fitness": tf_res["fitness"], "projected_hits": tf_res["n_hits"],
+                "processed_points": tf_res["n_processed"],
+                "pose_error_vs_gt": float(np.abs(np.linalg.inv(tf_res["T"]) - frame.T_gt).max()),
+                "arguments": "run.py's: reader.background passed, root logger at INFO, parameters mutated to down_sample = 5",
+                "note": "run.py:132-207, a tracking frame with a defect detection pending: depth filters -> back-projection -> "
+                        "preprocess_source(i > 0) -> improve_result from the tracker's bare 4x4 -> delta_pose -> posed mesh -> "
+                        "projection of a new heat map -> earlier hit clouds moved by relative_transformation -> viewer message"}
         if "scene_sharded" in extras:
             ss_steps, ss_elapsed, ss_res, ss_rows = extras["scene_sharded"]
             out["icp_scene_sharded"] = {

@@ -117,6 +117,11 @@ int pedp_raycast_last_sweep_ms(pedp_ctx_t ctx, float *ms);
 int pedp_mesh_create_posable(pedp_ctx_t ctx, const double *verts, int64_t V, const uint32_t *tris,
                              int64_t F, pedp_mesh_t *out);
 int pedp_mesh_set_pose(pedp_mesh_t mesh, const double T[16]);
+/* transform_object(reader.target_mesh, T) (src/pose_estimation.py:406-409; run.py:109-110, :179-181) for the viewer's
+ * copy of the mesh: the V x 3 float64 vertices T * (x, y, z, 1) / w of a posable mesh's model, the arithmetic
+ * pedp_mesh_set_pose starts from, before the float32 cast.  The mesh's own pose is not changed.  out: host
+ * (returns after completion) or device memory. */
+int pedp_mesh_posed_vertices(pedp_mesh_t mesh, const double T[16], int mem, double *out);
 
 /* Pinhole intrinsics as read from PinholeCameraIntrinsic.intrinsic_matrix
  * (src/defect_projection.py:209-212) plus the heat map's size. */
@@ -141,6 +146,30 @@ int pedp_project_heatmap(pedp_ctx_t ctx, pedp_mesh_t mesh, const pedp_pinhole *c
                          double threshold, const double origin[3], int mem, int64_t capacity,
                          double *points, double *intensities, int32_t *pixels, uint32_t *prim_id,
                          int64_t *n_rays, int64_t *n_hits);
+
+/* The same with what the reference does to the hits right after (src/defect_projection.py:268-294
+ * create_intersection_pcd; run.py:118, :200 `.transform(reader.color_to_depth)`), and with the heat map where and as
+ * it is.  opts (NULL = the call above):
+ *   heat_f32   the heat map is float32 (upcast exactly; every comparison and the intensities in float64)
+ *   heat_mem   PEDP_HOST / PEDP_DEVICE for the heat map alone (a detector's output already on the GPU, or a map
+ *              kept resident between detections, run.py:66, :147), whatever `mem` says about the outputs
+ *   jet_lut    256 x 3 float64 on the host: matplotlib's `jet` lookup table (pedp_hip.ray_projection builds it);
+ *   colors     capacity x 3 float64 (where `mem` says): jet_lut[clip(trunc(s * 256), 0, 255)] of the min-max
+ *              normalised hit intensities s = (I - min I) / (max I - min I), float64, one rounding per operation;
+ *              equal intensities divide by zero like the reference (NaN -> black).  Both NULL: no colours.
+ *   post       4x4 float64 on the host (nullable): the hit points are moved by it -- ((T0 x + T1 y) + T2 z) + T3 per
+ *              row, pedp_transform_points' order -- before they are written. */
+typedef struct {
+    int32_t heat_f32;
+    int32_t heat_mem;
+    const double *jet_lut;
+    double *colors;
+    const double *post;
+} pedp_project_opts;
+int pedp_project_heatmap_ex(pedp_ctx_t ctx, pedp_mesh_t mesh, const pedp_pinhole *cam, const void *heatmap,
+                            double threshold, const double origin[3], int mem, int64_t capacity,
+                            double *points, double *intensities, int32_t *pixels, uint32_t *prim_id,
+                            int64_t *n_rays, int64_t *n_hits, const pedp_project_opts *opts);
 
 /* ---------------------------------------------------------------- depth pre-filters
  * the reference's warp-lang kernels (CUDA-only JIT) and its depth back-projection.
@@ -219,8 +248,8 @@ int pedp_feature_match(pedp_ctx_t ctx, const double *fs, int64_t Ns, const doubl
 int pedp_segment_plane(pedp_ctx_t ctx, const double *pts, int64_t N, double distance_threshold, int num_iterations,
                        uint64_t seed, double plane[4], int32_t *inliers, int64_t *n_inliers);
 
-/* preprocess_source of a frame in one call (src/pose_estimation.py:186-268; the branch run.py takes: no
- * param['box'], no param['mesh'], no background cloud), the scene staying on the device between the stages:
+/* preprocess_source of a frame in one call (src/pose_estimation.py:186-268; every branch run.py can take except
+ * param['mesh']), the scene staying on the device between the stages:
  *     voxel_down_sample(down_sample) :204-205 -> segment_plane :323-329 -> [i == 0: estimate_normals of the
  *     down-sampled cloud :216] -> select_by_index(inliers, invert=True) :234 -> cluster_dbscan(eps 10, 10) +
  *     largest cluster :270-299 -> remove_statistical_outlier(75, 0.01) :308-312 -> [i == 0: estimate_normals
@@ -230,8 +259,25 @@ int pedp_segment_plane(pedp_ctx_t ctx, const double *pts, int64_t N, double dist
  * ordered before the call.  out_pts / out_normals (normals only when first_frame): capacity x 3 float64 host
  * arrays; capacity = N always fits.  stage_counts (nullable): points after the voxel grid, the plane removal,
  * the cluster selection, the outlier filter.  status: PEDP_PREPROCESS_OK, _NO_CLUSTER (nothing left after the
- * plane, or DBSCAN found noise only -- the reference prints "No valid clusters found." and fails on None) or
- * _DEGENERATE (fewer than three points); n_out is 0 for the latter two. */
+ * plane, or DBSCAN found noise only -- the reference prints "No valid clusters found." and fails on None),
+ * _DEGENERATE (fewer than three points) or _AMBIGUOUS (box cut only: the plane normal is perpendicular to the
+ * average normal within rounding, the caller's own arithmetic decides the flip); n_out is 0 for those three.
+ *
+ * The background cloud run.py passes (run.py:99-101, :154-156) has no entry here: without param['box'] nothing of
+ * it is read (:232-236 overwrite the cut), with param['box'] background_removal returns its input (:386-388), and
+ * its down-sampled copy and normals (:204, :252) are locals of the reference's function.
+ *
+ * flags & PEDP_PREPROCESS_BOX: param['box'] -- the plane's inliers stay, the cloud is cut by the half space
+ * remove_points_below_plane keeps (:366-378: signed distance <= 0 to the refit plane, flipped towards the average
+ * normal by flip_plane_normal_if_needed :342-359); like the reference's, the cut cloud carries no normals, so the
+ * final ones (first frame) take Open3D's default orientation.
+ *
+ * pedp_preprocess_source_ex, report (nullable): what the reference's two INFO lines print (:220, :356) and the box
+ * cut uses --
+ *     [0..3] the plane segment_plane returns (refit over the best plane's inliers, unflipped)
+ *     [4..6] mean normal of the down-sampled cloud on the 10-unit grid, NOT normalised (first frame; else 1, 1, 1)
+ *     [7]    box cut only: 1 if the plane was flipped        [8] inliers of the refit   [9] voxels of the 10-unit grid
+ * Without a report and without the box flag none of this is computed (nothing can observe it). */
 typedef struct pedp_preprocess_params {
     double voxel_size;          /* params['down_sample'] */
     double plane_distance;      /* params['plane_removal']['distance_threshold'] */
@@ -243,15 +289,22 @@ typedef struct pedp_preprocess_params {
     int32_t cluster_min_points; /* filter_largest_cluster: 10 */
     double cluster_eps;         /*                         10 */
     int32_t outlier_neighbors;  /* remove_statistical_outliers: 75 */
-    int32_t reserved;
+    int32_t flags;              /* PEDP_PREPROCESS_BOX */
     double outlier_std_ratio;   /*                              0.01 */
+    double average_normal_voxel; /* compute_average_normal's grid: 10 (0 = that default) */
 } pedp_preprocess_params;
+#define PEDP_PREPROCESS_BOX 1
 #define PEDP_PREPROCESS_OK 0
 #define PEDP_PREPROCESS_NO_CLUSTER 1
 #define PEDP_PREPROCESS_DEGENERATE 2
+#define PEDP_PREPROCESS_AMBIGUOUS 3
+#define PEDP_PREPROCESS_REPORT_DOUBLES 12
 int pedp_preprocess_source(pedp_ctx_t ctx, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
                            double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
                            int *status);
+int pedp_preprocess_source_ex(pedp_ctx_t ctx, const double *pts, int64_t N, int pts_on_device, const pedp_preprocess_params *prm,
+                              double *out_pts, double *out_normals, int64_t capacity, int64_t *n_out, int64_t stage_counts[4],
+                              int *status, double report[PEDP_PREPROCESS_REPORT_DOUBLES]);
 
 /* ---------------------------------------------------------------- ICP
  * Replaces src/pose_estimation.py:519-521 and :654-660:
@@ -383,6 +436,14 @@ int pedp_comm_allreduce_f64(pedp_ctx_t ctx, double *buf, int64_t n);
  * keep_idx: caller array of n ints, receives the indices of the kept poses. */
 int pedp_cluster_poses(float angle_diff_deg, float dist_diff, const float *poses, int n,
                        const float *syms, int s, int32_t *keep_idx, int *n_keep);
+
+/* ---------------------------------------------------------------- rigid transform of host arrays
+ * What o3d.geometry.PointCloud.transform / TriangleMesh.transform do to the holders' float64 arrays on the path
+ * (src/pose_estimation.py:406-409 transform_object, :815-816; run.py:118, :197, :200): out_i = R in_i + t with
+ * ((T0 x + T1 y) + T2 z) + T3 per row, one rounding per operation (the oracle's order); rotate_only != 0 leaves the
+ * translation out (normals).  Host only, out may be in.  A numpy (N, 3) @ (3, 3) product takes ten times as long
+ * (a BLAS call with inner dimension 3) and its rounding depends on the BLAS build. */
+int pedp_transform_points(const double T[16], const double *in, int64_t n, int rotate_only, double *out);
 
 #ifdef __cplusplus
 }

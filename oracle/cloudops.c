@@ -178,19 +178,47 @@ static int triangle_plane(const double *p0, const double *p1, const double *p2, 
 static double plane_dist(const double pl[4], const double *p) {
     return fabs(((pl[0] * p[0] + pl[1] * p[1]) + pl[2] * p[2]) + pl[3]);
 }
+/* GetPlaneFromPoints (Open3D 0.18 PointCloudSegmentation.cpp: centroid of the inliers, their six second moments about it,
+ * the largest-determinant closed form).  Open3D adds the inliers up one after the other; here every sum is taken in BLOCKS
+ * of the CLOUD: the 256 points [256 j, 256 j + 256) contribute their value if they are inliers and zero otherwise, a block
+ * is added in a fixed binary tree -- t[i] += t[i + w] for w = 128, 64 ... 1 -- and the block sums are added in order of j.
+ * That is the order a GPU takes without a trip to the host and without compacting the inliers (pedp_preprocess_source
+ * refits on the device), a pairwise-style sum that lies closer to the exact one than the running sum, and it differs from
+ * Open3D's result by rounding only (1e-16 relative; the build's tolerance to Open3D's arithmetic is 1e-5).  Every product
+ * and difference is one rounding, no contraction.  idx must ascend (segment_plane lists the inliers in index order). */
+static double block_tree_sum(double *t /* 256 values, overwritten */) {
+    for (int w = 128; w >= 1; w >>= 1)
+        for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    return t[0];
+}
+/* sum over the inliers of f_q(point), q < nq, blocked as above; r0: subtracted from the point first (NULL: nothing) */
+static void blocked_sums(const double *pts, const int32_t *idx, int64_t n, const double *r0, int nq, double *out) {
+    static const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {0, 1, 2, 1, 2, 2};
+    double t[6][256];
+    for (int q = 0; q < nq; ++q) out[q] = 0.0;
+    int64_t i = 0;
+    while (i < n) {
+        const int64_t blk = idx[i] / 256;
+        for (int q = 0; q < nq; ++q)
+            for (int k = 0; k < 256; ++k) t[q][k] = 0.0;
+        for (; i < n && idx[i] / 256 == blk; ++i) {
+            const double *p = pts + 3 * (int64_t)idx[i];
+            const int k = (int)(idx[i] % 256);
+            if (!r0) { t[0][k] = p[0]; t[1][k] = p[1]; t[2][k] = p[2]; continue; }
+            const double r[3] = {p[0] - r0[0], p[1] - r0[1], p[2] - r0[2]};
+            for (int q = 0; q < nq; ++q) t[q][k] = r[A[q]] * r[B[q]];
+        }
+        for (int q = 0; q < nq; ++q) out[q] += block_tree_sum(t[q]);
+    }
+}
 void pedp_oracle_plane_from_points(const double *pts, const int32_t *idx, int64_t n, double pl[4]) {
     pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
     if (n < 3) return;
-    double c[3] = {0, 0, 0};
-    for (int64_t i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) c[k] += pts[3 * (int64_t)idx[i] + k];
+    double c[3], m[6];
+    blocked_sums(pts, idx, n, NULL, 3, c);
     for (int k = 0; k < 3; ++k) c[k] /= (double)n;
-    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double *p = pts + 3 * (int64_t)idx[i];
-        const double rx = p[0] - c[0], ry = p[1] - c[1], rz = p[2] - c[2];
-        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-    }
+    blocked_sums(pts, idx, n, c, 6, m);
+    const double xx = m[0], xy = m[1], xz = m[2], yy = m[3], yz = m[4], zz = m[5];
     const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
     double a, b, cc;
     if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }

@@ -123,15 +123,16 @@ def transform(T, pts):
     return out
 
 
-def pose_vertices(T, verts):
+def pose_vertices(T, verts, dtype=np.float32):
     """TriangleMesh.transform (pose_estimation.py:406-409) + from_legacy's float32 cast
     (defect_projection.py:245): Open3D forms T * (x, y, z, 1) in float64 and divides by the
-    fourth component.  Fixed order ((T0 x + T1 y) + T2 z) + T3, elementwise numpy (no FMA)."""
+    fourth component.  Fixed order ((T0 x + T1 y) + T2 z) + T3, elementwise numpy (no FMA).
+    dtype=np.float64: the vertices before the cast (what the transformed mesh itself holds)."""
     v = np.ascontiguousarray(verts, np.float64).reshape(-1, 3)
     M = np.asarray(T, np.float64).reshape(4, 4)
     x, y, z = v[:, 0], v[:, 1], v[:, 2]
     h = [((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3] for r in range(4)]
-    return np.stack([h[0] / h[3], h[1] / h[3], h[2] / h[3]], axis=1).astype(np.float32)
+    return np.stack([h[0] / h[3], h[1] / h[3], h[2] / h[3]], axis=1).astype(dtype)
 
 
 def project_heatmap(verts32, tris, heatmap, K, threshold=0.5, origin=(0, 0, 0), bvh=True):

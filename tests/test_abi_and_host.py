@@ -131,6 +131,30 @@ def test_geometry_holders_and_transform_object():
     assert m.compute_triangle_normals().triangle_normals.tolist() == [[0, 0, 1]]
 
 
+def test_transform_points_is_the_oracles_operation_order(oracle):
+    """pedp_transform_points (host arithmetic of the library: the holders' transform()) against the oracle's transform bit
+    for bit, normals by the rotation alone, in place, empty; and the holders built on it."""
+    from pedp_hip import _lib
+    from pedp_hip.compat import PointCloud, TriangleMesh
+
+    rng = np.random.default_rng(4)
+    T = np.eye(4)
+    T[:3, :3] = oracle.rot_xyz([0.3, -1.1, 2.0])
+    T[:3, 3] = (12.5, -340.0, 0.125)
+    p = rng.normal(0.0, 200.0, (5003, 3))
+    assert np.array_equal(_lib.transform_points(T, p), oracle.transform(T, p))
+    R = T.copy()
+    R[:3, 3] = 0.0
+    assert np.array_equal(_lib.transform_points(T, p, rotate_only=True), oracle.transform(R, p) + 0.0)
+    assert _lib.transform_points(T, np.zeros((0, 3))).shape == (0, 3)
+    cloud = PointCloud(p, normals=p[::-1])
+    cloud.transform(T)
+    assert np.array_equal(cloud.points, oracle.transform(T, p)) and np.array_equal(cloud.normals, oracle.transform(R, p[::-1]))
+    mesh = TriangleMesh(p[:300], [[0, 1, 2]]).transform(T)
+    assert np.array_equal(mesh.vertices, oracle.transform(T, p[:300]))
+    assert np.abs(cloud.points - (p @ T[:3, :3].T + T[:3, 3])).max() < 1e-10
+
+
 def test_rotation_helper_matches_oracle(oracle):
     from pedp_hip.compat import get_rotation_matrix_from_xyz
 

@@ -336,6 +336,62 @@ def test_preprocess_source_in_one_call_equals_the_steps(ctx, oracle):
             assert np.array_equal(one.normals, steps.normals) and fp is None
         dev, _, _ = preprocess_source(PointCloud(torch.from_numpy(scene).cuda()), None, dict(param), i=i)
         assert np.array_equal(dev.points, steps.points) and (i != 0 or np.array_equal(dev.normals, steps.normals))
+    # ---- the arguments run.py really passes (run.py:99-101, :154-156, :252-260): a background cloud, the root logger at
+    # INFO; and param['box'].  One call again, the same cloud bit for bit, and the reference's two INFO lines with the
+    # same text as the steps print them
+    import logging
+
+    background = PointCloud(scene[::7] + np.array([0.0, 0.0, 40.0]))
+    root = logging.getLogger()
+    level = root.level
+    lines = []
+
+    class Tap(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+
+    tap = Tap()
+    root.addHandler(tap)
+    try:
+        for box in (False, True):
+            for i in (0, 1):
+                got = {}
+                for name, force, lvl in (("steps", True, logging.INFO), ("one", False, logging.INFO), ("quiet", False, logging.WARNING)):
+                    param = {"preprocess_source": {"down_sample": 4, "plane_removal": {"distance_threshold": 2.0, "num_iterations": 200}},
+                             "box": box, "mesh": False}
+                    root.setLevel(lvl)
+                    del lines[:]
+                    icp_refine._FORCE_STEPS = force
+                    calls = []
+                    fused = cloud_ops.preprocess_source_fused
+                    cloud_ops.preprocess_source_fused = lambda *a, **k: (calls.append(k), fused(*a, **k))[1]
+                    try:
+                        cloud, _, _ = preprocess_source(PointCloud(scene), background, param, i=i)
+                    finally:
+                        icp_refine._FORCE_STEPS = False
+                        cloud_ops.preprocess_source_fused = fused
+                    assert len(calls) == (0 if force else 1)                # the one-call path really ran (and only once)
+                    got[name] = (cloud, [ln for ln in lines if ln.startswith(":: ")])
+                    assert param["preprocess_source"]["down_sample"] == (5 if i else 4)
+                steps, one, quiet = got["steps"], got["one"], got["quiet"]
+                assert np.array_equal(one[0].points, steps[0].points) and np.array_equal(quiet[0].points, steps[0].points)
+                assert len(steps[0].points) > 200 and one[0].has_normals() == steps[0].has_normals() == (i == 0)
+                if i == 0:
+                    assert np.array_equal(one[0].normals, steps[0].normals) and np.array_equal(quiet[0].normals, steps[0].normals)
+                assert one[1] == steps[1] and quiet[1] == []
+                assert (i != 0) or any(ln.startswith(":: Average Normal for Source = [") for ln in one[1])
+            if not box:     # without the box nothing of the background or the logging reaches the result
+                assert np.array_equal(steps[0].points, preprocess_source(PointCloud(scene), None, dict(param), i=1)[0].points)
+    finally:
+        root.removeHandler(tap)
+        root.setLevel(level)
+    # the report itself: the plane segment_plane returns and compute_average_normal's mean, against the oracle
+    p, n, counts, status, rep = cloud_ops.preprocess_source_fused(scene, 4, 2.0, 200, first_frame=True, ctx=ctx, report=True)
+    down, _ = oracle.voxel_down_sample(scene, 4)
+    plane_ref, inl_ref = oracle.segment_plane(down, 2.0, 200, seed=0)
+    assert status == 0 and rep["inliers"] == len(inl_ref) and np.abs(rep["plane_model"] - plane_ref).max() < 1e-12
+    _, coarse = oracle.voxel_down_sample(down, 10, oracle.estimate_normals(down, 2.0, 5))
+    assert np.abs(rep["mean_normal"] - coarse.mean(axis=0)).max() < 1e-9
     # the counters of the stages, and the statuses
     voxel = 4 if True else 0
     p, n, counts, status = cloud_ops.preprocess_source_fused(scene, voxel, 2.0, 200, first_frame=True, ctx=ctx)

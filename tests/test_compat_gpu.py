@@ -160,25 +160,45 @@ def test_refine_pose_with_icp_from_raw_frame(oracle):
 
 
 def test_a_holder_keeps_its_device_copy_between_calls():
-    """reg.upload: the model cloud of a camera loop is uploaded, ordered and packed once -- the same handle comes back as
-    long as the holder's arrays are the same memory with the same (sampled) contents; a transform, a new array or
-    forget_device_copy make a new one."""
+    """reg.upload: the model cloud of a camera loop is uploaded, ordered and packed once -- the same handle comes back
+    exactly as long as the holder's points and normals are what the copy was made from: the holder owns immutable arrays
+    (an in-place edit raises, the caller's source array is copied like Vector3dVector does), and every setter and
+    transform bumps its version (the sampled fingerprint missed edits between the sampled rows)."""
     from pedp_hip import registration as reg, synth
     from pedp_hip.compat import PointCloud
 
     f = synth.Frame("parity")
-    cloud = PointCloud(f.model_points, normals=f.normals)
+    mine = f.model_points.copy()
+    cloud = PointCloud(mine, normals=f.normals)
     a = reg.upload(cloud)
-    assert reg.upload(cloud) is a and reg.upload(cloud) is a          # fresh views of the same arrays: the same handle
-    np.asarray(cloud.points)[:] += 1.0                                   # rewritten in place
+    assert reg.upload(cloud) is a and reg.upload(cloud) is a          # nothing changed: the same handle
+    with pytest.raises(ValueError):
+        np.asarray(cloud.points)[3] += 1.0                               # in place: refused, never silently stale
+    with pytest.raises(ValueError):
+        cloud.normals[5:9] *= -1.0
+    mine[3] += 1.0                                                       # the caller's own array is not the holder's
+    assert reg.upload(cloud) is a and np.array_equal(cloud.points[3], f.model_points[3])
+    edited = np.array(cloud.points)
+    edited[3] += 1.0                                                     # one row, none of the old fingerprint's samples
+    cloud.points = edited
     b = reg.upload(cloud)
     assert b is not a and reg.upload(cloud) is b
-    cloud.transform(np.eye(4))                                           # new arrays
+    flipped = np.array(cloud.normals)
+    flipped[::7] *= -1.0
+    cloud.normals = flipped
     c = reg.upload(cloud)
     assert c is not b
+    cloud.transform(np.eye(4))
+    d = reg.upload(cloud)
+    assert d is not c
+    moved = PointCloud.moved_copy(cloud, np.eye(4))                      # aliases the source's arrays until read: immutable ones
+    cloud.points = np.array(cloud.points) + 1.0
+    assert np.array_equal(moved.points, edited)
     reg.forget_device_copy(cloud)
-    assert reg.upload(cloud) is not c
+    assert reg.upload(cloud) is not d
     assert reg.upload(a) is a                                            # a handle passes through
+    borrowed = PointCloud.borrowed(mine)                                 # memory the caller keeps rewriting: never kept
+    assert reg.upload(borrowed) is not reg.upload(borrowed)
 
 
 def test_dist_hip_backend_single_rank(oracle):

@@ -137,6 +137,59 @@ def test_frame_projector_and_ray_tracing(ctx, oracle, tmp_path):
     assert np.array_equal(np.asarray(cloud2.colors), np.asarray(compat.create_intersection_pcd(ref2["points"], ref2["intensities"]).colors))
 
 
+def test_projection_with_colours_move_and_resident_heat_map(ctx, oracle):
+    """pedp_project_heatmap_ex: the hits' jet colours (create_intersection_pcd's arithmetic, bit for bit), the trailing
+    `.transform(color_to_depth)` on the device (the oracle's operation order, bit for bit), the heat map as float32 and
+    as a CUDA tensor (taken where and as it is: same selection, same hits), and the viewer's float64 posed vertices."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import _lib, compat, synth
+    from pedp_hip.ray_projection import FrameProjector, _jet_lut
+
+    f = synth.Frame("parity")
+    hm = _heatmap(f.height, f.width, 8, fill=0.5)
+    c2d = np.eye(4)
+    c2d[:3, :3] = oracle.rot_xyz([0.02, -0.01, 0.03])
+    c2d[:3, 3] = (31.0, -2.5, 1.75)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    ref = oracle.project_heatmap(f.verts_posed, f.tris, hm, f.K, 0.6)
+    assert len(ref["points"]) > 50
+    plain = mesh.project_heatmap(hm, f.K, 0.6)
+    out = mesh.project_heatmap(hm, f.K, 0.6, jet_lut=_jet_lut(), post=c2d)
+    for k in ("pixels", "primitive_ids", "intensities"):
+        assert np.array_equal(out[k], ref[k])
+    assert np.array_equal(out["points"], oracle.transform(c2d, plain["points"]))
+    assert np.array_equal(out["colors"], np.asarray(compat.create_intersection_pcd(ref["points"], ref["intensities"]).colors))
+    # equal intensities divide by zero like the reference: NaN -> black
+    flat = np.where(hm > 0.6, 0.8, 0.0)
+    black = mesh.project_heatmap(flat, f.K, 0.6, jet_lut=_jet_lut())
+    assert len(black["colors"]) == len(ref["points"]) and not black["colors"].any()
+    # float32 heat map: upcast exactly -- the selection and the hits of its float64 copy
+    hm32 = np.nan_to_num(hm, nan=0.0).astype(np.float32)
+    ref32 = oracle.project_heatmap(f.verts_posed, f.tris, hm32.astype(np.float64), f.K, 0.6)
+    out32 = mesh.project_heatmap(hm32, f.K, 0.6, jet_lut=_jet_lut())
+    _check(out32, ref32)
+    assert np.array_equal(out32["colors"], np.asarray(compat.create_intersection_pcd(ref32["points"], ref32["intensities"]).colors))
+    # resident heat maps (CUDA tensors, both types)
+    for dev in (torch.from_numpy(hm32).cuda(), torch.from_numpy(np.nan_to_num(hm, nan=0.0)).cuda()):
+        got = mesh.project_heatmap(dev, f.K, 0.6, jet_lut=_jet_lut())
+        want = ref32 if dev.dtype == torch.float32 else oracle.project_heatmap(f.verts_posed, f.tris, np.nan_to_num(hm, nan=0.0), f.K, 0.6)
+        _check(got, want)
+    # fewer, then more hits than the room kept from the last call
+    few = np.zeros_like(hm); few[ref["pixels"][0][1], ref["pixels"][0][0]] = 1.0
+    assert len(mesh.project_heatmap(few, f.K, 0.5)["points"]) == 1
+    _check(mesh.project_heatmap(np.ones_like(hm), f.K, 0.5), oracle.project_heatmap(f.verts_posed, f.tris, np.ones_like(hm), f.K, 0.5))
+    # the viewer's copy of the posed mesh
+    intr = compat.PinholeCameraIntrinsic(f.width, f.height, intrinsic_matrix=f.K)
+    model = compat.TriangleMesh(f.model_points, f.tris)
+    proj = FrameProjector(model, intr, c2d)
+    posed = proj.posed_mesh(f.T_gt, model)
+    assert np.array_equal(posed.vertices, oracle.pose_vertices(f.T_gt, f.model_points, dtype=np.float64))
+    assert np.array_equal(posed.triangles, f.tris) and np.abs(posed.vertices - compat.transform_object(model, f.T_gt).vertices).max() < 1e-9
+    cloud = proj.project(f.T_gt, hm, 0.6, into=c2d)
+    direct = proj.project(f.T_gt, hm, 0.6)
+    assert np.array_equal(cloud.points, oracle.transform(c2d, direct.points)) and np.array_equal(cloud.colors, direct.colors)
+
+
 def test_align_to_surface_matches_oracle_nn(ctx, oracle):
     """align_to_surface (defect_projection.py:413-460): nearest model point by the exact NN pass,
     offset along its normal; indices equal the oracle's KD-tree search."""
