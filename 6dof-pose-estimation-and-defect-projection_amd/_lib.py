@@ -370,7 +370,8 @@ class Cloud:
     @classmethod
     def from_device(cls, ctx, points_ptr, n, normals_ptr=None):
         """Cloud from device memory: N x 3 float64 at `points_ptr` (e.g. tensor.data_ptr() of a
-        contiguous torch.float64 CUDA tensor) on the context's GPU; the data are copied.  The caller
+        contiguous torch.float64 CUDA tensor) on the context's GPU; the data are copied, and the copy is
+        complete when the call returns (the tensor may be freed or overwritten at once).  The caller
         makes sure the producing work is complete or ordered on the context's stream."""
         self = cls.__new__(cls)
         self.ctx, self.N, self.has_normals = ctx, int(n), normals_ptr is not None

@@ -21,6 +21,7 @@ bool pedp_ctx_is_live(pedp_ctx_t c) {
 }
 
 void *pedp_pool::take(size_t bytes, size_t *cap) {
+    std::lock_guard<std::mutex> lock(mu);
     int best = -1;
     for (int i = 0; i < (int)free_.size(); ++i)
         if (free_[i].cap >= bytes && free_[i].cap <= 2 * bytes + 4096 && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
@@ -38,6 +39,7 @@ void *pedp_pool::take(size_t bytes, size_t *cap) {
 }
 void pedp_pool::give(void *p, size_t cap) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(mu);
     if (free_.size() >= 24) {  // keep the pool small: drop the oldest entry
         (void)hipFree(free_.front().p);
         free_.erase(free_.begin());
@@ -45,6 +47,7 @@ void pedp_pool::give(void *p, size_t cap) {
     free_.push_back({p, cap});
 }
 void pedp_pool::clear() {
+    std::lock_guard<std::mutex> lock(mu);
     for (auto &e : free_) (void)hipFree(e.p);
     free_.clear();
 }
@@ -457,7 +460,8 @@ int pedp_cloud_create(pedp_ctx_t c, const double *pts, const double *normals, in
 }
 
 // Cloud from device memory (a scene back-projected on the GPU): one device-to-device copy and the bounding box
-// by two small kernels, all on the context's stream -- no read-back, no synchronisation, buffers from the pool.
+// by two small kernels, all on the context's stream -- no read-back, buffers from the pool.  The call returns when the
+// COPIES are complete (the source may be freed or overwritten); the box kernels may still be running.
 int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_normals, int64_t N, pedp_cloud_t *out) {
     PEDP_REQUIRE(c && out, "pedp_cloud_create_device: null context/output");
     *out = nullptr;
@@ -476,6 +480,11 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
         ok = (cl->normals = (double *)c->cloud_pool.take(bytes, &cl->normals_cap)) != nullptr;
         if (ok && N > 0) e = hipMemcpyAsync(cl->normals, d_normals, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
     }
+    // the caller's arrays are free again when the call returns: the host waits for the copies (an event behind them; a
+    // few microseconds, no read-back) -- torch hands a freed tensor's block to the next allocation on ITS stream, which
+    // this context's stream is not ordered with
+    if (ok && e == hipSuccess && N > 0) e = hipEventRecord(c->ev1, c->stream);
+    const bool wait_copies = ok && e == hipSuccess && N > 0;
     if (ok && e == hipSuccess && N > 0) {
         const int st = c->sort_ws.reserve(sizeof(double) * CS_BLOCKS * 9 + 512);   // (the order's scratch: next in line on this stream)
         if (st) { pedp_cloud_destroy(cl); return st; }
@@ -486,6 +495,7 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
     } else if (N == 0) {
         cl->host_stats = true;
     }
+    if (wait_copies && e == hipSuccess) e = hipEventSynchronize(c->ev1);   // (the box kernels are already queued behind)
     if (!ok || e != hipSuccess) {
         pedp_set_error("pedp_cloud_create_device: %s", ok ? hipGetErrorString(e) : "allocation failed");
         pedp_cloud_destroy(cl);
@@ -500,7 +510,10 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     (void)hipSetDevice(cl->device);
     // points, normals, order, chunk spheres and box go back to the context's pool (the next frame's cloud takes
     // them: reuse is ordered by the stream); everything else, and all of it if the context is gone, is freed
-    pedp_pool *pool = pedp_ctx_is_live(cl->ctx) ? &cl->ctx->cloud_pool : nullptr;
+    // the context's liveness is checked and its pool used under ONE lock (a context destroyed in between, or one
+    // re-created at the same address for another device, never gets these buffers)
+    std::lock_guard<std::mutex> live(g_ctx_mutex);
+    pedp_pool *pool = g_ctx_live.count(cl->ctx) != 0 && cl->ctx->device == cl->device ? &cl->ctx->cloud_pool : nullptr;
     auto drop = [&](void *p, size_t cap) {
         if (!p) return;
         if (pool && cap) pool->give(p, cap);

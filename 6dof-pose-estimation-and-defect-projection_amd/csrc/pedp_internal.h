@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "../../include/pedp.h"
 
@@ -56,6 +57,7 @@ struct pedp_scratch {
 struct pedp_pool {
     struct entry { void *p; size_t cap; };
     std::vector<entry> free_;
+    std::mutex mu;  // a handle may be destroyed on another thread (Python drops the last reference wherever it likes)
     void *take(size_t bytes, size_t *cap);   // a pooled buffer of cap >= bytes (not wastefully larger), or a new one
     void give(void *p, size_t cap);
     void clear();

@@ -103,6 +103,8 @@ def jet(values):
     """RGB of matplotlib's 256-entry 'jet' lookup: index floor(v * 256) clipped to 0..255;
     NaN maps to black (matplotlib's 'bad' colour is transparent black)."""
     v = np.asarray(values, dtype=np.float64)
+    if v.ndim == 0:                        # a scalar: one colour
+        return jet(v.reshape(1))[0]
     x = v * 256.0
     bad = x != x
     if bad.any():

@@ -315,8 +315,11 @@ int pedp_preprocess_source_ex(pedp_ctx_t ctx, const double *pts, int64_t N, int 
 int pedp_cloud_create(pedp_ctx_t ctx, const double *pts, const double *normals, int64_t N,
                       pedp_cloud_t *out);
 /* The same from DEVICE memory (N x 3 float64 on the context's GPU, e.g. a torch tensor built from
- * depth2xyzmap's output): device-to-device copies, centroid / bounds / magnitudes by a reduction
- * on the device.  The call synchronises the stream. */
+ * depth2xyzmap's output): device-to-device copies on the context's stream, the bounding box by a reduction on the
+ * device behind them (no read-back; centroid and magnitudes only when the cloud is first used as a target).
+ * The caller orders its own work on the arrays BEFORE the call (the library reads them on the context's stream);
+ * the call returns when the copies are complete -- the arrays may then be freed or overwritten at once -- while the
+ * box reduction may still be running. */
 int pedp_cloud_create_device(pedp_ctx_t ctx, const double *d_pts, const double *d_normals, int64_t N,
                              pedp_cloud_t *out);
 void pedp_cloud_destroy(pedp_cloud_t cloud);

@@ -205,9 +205,14 @@ def test_device_resident_chain_depth_to_registration(ctx, oracle):
     pts = (xyz[xyz[..., 2] > 0].double() * 1000.0).contiguous()
     torch.cuda.synchronize()
     assert pts.is_cuda and len(pts) > 500
-    src_dev = _lib.Cloud.from_device(ctx, pts.data_ptr(), len(pts))
-    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
     host_pts = pts.cpu().numpy()
+    src_dev = _lib.Cloud.from_device(ctx, pts.data_ptr(), len(pts))
+    pts.fill_(float("nan"))                        # the copy is complete when from_device returns: overwriting
+    del pts                                        # or freeing the source right away must not reach the cloud
+    junk = torch.full((len(host_pts), 3), 7.0, dtype=torch.float64, device="cuda")   # (takes the freed block)
+    torch.cuda.synchronize()
+    tgt = _lib.Cloud(ctx, f.model_points, f.normals)
+    pts = torch.from_numpy(host_pts).cuda()
     a = _lib.icp(ctx, src_dev, tgt, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1, relative_rmse=-1, want_corr=True)
     b = _lib.icp(ctx, _lib.Cloud(ctx, host_pts), tgt, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1,
                  relative_rmse=-1, want_corr=True)
