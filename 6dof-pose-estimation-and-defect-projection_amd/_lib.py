@@ -59,6 +59,7 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_debug_mfma_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pedp_mesh_posed_vertices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pedp_project_heatmap_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
@@ -607,3 +608,12 @@ def transform_points(T, points, rotate_only=False):
     out = np.empty_like(p)
     check(load().pedp_transform_points(_ptr(M), _ptr(p), len(p), 1 if rotate_only else 0, _ptr(out)), "pedp_transform_points")
     return out
+
+
+def debug_mfma_scores(ctx, mesh, rays6):
+    """pedp_debug_mfma_scores: (score, slack), N x F float32 each, of the exhaustive sweep's matrix-pipe filter."""
+    r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
+    score = np.empty((len(r), mesh.F), np.float32)
+    slack = np.empty((len(r), mesh.F), np.float32)
+    check(load().pedp_debug_mfma_scores(ctx._h, mesh._h, _ptr(r), len(r), _ptr(score), _ptr(slack)), "pedp_debug_mfma_scores")
+    return score, slack

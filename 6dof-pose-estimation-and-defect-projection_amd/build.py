@@ -17,10 +17,10 @@ OUT = os.path.join(HERE, "libpedp_hip.so")
 # source -> extra flags.  pedp_icp.hip: MFMA results stay in VGPRs (no v_accvgpr_read
 # copies) and min/med3 on them need no sNaN-quieting v_max (its inputs are never NaN:
 # finite coordinates, +inf only as the running-min seed).  pedp_ray.hip keeps strict
-# IEEE semantics everywhere.
+# IEEE semantics everywhere (its one extra flag only picks the register file of MFMA results).
 SOURCES = {
     "pedp_ctx.hip": [],
-    "pedp_ray.hip": [],
+    "pedp_ray.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],   # (MFMA results in VGPRs: no v_accvgpr_read copies in the matrix sweep)
     "pedp_icp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "pedp_project.hip": [],
     "pedp_depth.hip": [],

@@ -103,8 +103,14 @@ int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
         const size_t n = bytes - off < c->stage_cap[0] ? bytes - off : c->stage_cap[0];
         // the DMA that last read the buffer (an earlier upload on this stream) must be done
         if (c->stage_busy || off > 0) PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
-        memcpy(c->stage[0], (const char *)src + off, n);
-        PEDP_HIP_CHECK(hipMemcpyAsync((char *)dst + off, c->stage[0], n, hipMemcpyHostToDevice, c->stream));
+        // in pieces: the DMA of one piece runs while the host copies the next into its own part of the staging buffer (a
+        // caller's array that has left the CPU caches is read at DRAM speed -- about as long as the DMA takes)
+        constexpr size_t PIECE = 512u << 10;
+        for (size_t p = 0; p < n; p += PIECE) {
+            const size_t m = n - p < PIECE ? n - p : PIECE;
+            memcpy((char *)c->stage[0] + p, (const char *)src + off + p, m);
+            PEDP_HIP_CHECK(hipMemcpyAsync((char *)dst + off + p, (char *)c->stage[0] + p, m, hipMemcpyHostToDevice, c->stream));
+        }
         c->stage_busy = true;
     }
     return PEDP_OK;
@@ -204,6 +210,7 @@ int pedp_ctx_create(int device, void *stream, pedp_ctx_t *out) {
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->nn_ev0) != hipSuccess || hipEventCreate(&c->nn_ev1) != hipSuccess) {
         pedp_set_error("pedp_ctx_create: hipEventCreate failed");
         pedp_ctx_destroy(c);
@@ -255,6 +262,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
         if (c->stage[k]) (void)hipHostFree(c->stage[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
     if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
     for (hipEvent_t e : c->nn_evs)
@@ -483,7 +491,7 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
     // the caller's arrays are free again when the call returns: the host waits for the copies (an event behind them; a
     // few microseconds, no read-back) -- torch hands a freed tensor's block to the next allocation on ITS stream, which
     // this context's stream is not ordered with
-    if (ok && e == hipSuccess && N > 0) e = hipEventRecord(c->ev1, c->stream);
+    if (ok && e == hipSuccess && N > 0) e = hipEventRecord(c->ev_copy, c->stream);
     const bool wait_copies = ok && e == hipSuccess && N > 0;
     if (ok && e == hipSuccess && N > 0) {
         const int st = c->sort_ws.reserve(sizeof(double) * CS_BLOCKS * 9 + 512);   // (the order's scratch: next in line on this stream)
@@ -495,7 +503,7 @@ int pedp_cloud_create_device(pedp_ctx_t c, const double *d_pts, const double *d_
     } else if (N == 0) {
         cl->host_stats = true;
     }
-    if (wait_copies && e == hipSuccess) e = hipEventSynchronize(c->ev1);   // (the box kernels are already queued behind)
+    if (wait_copies && e == hipSuccess) e = hipEventSynchronize(c->ev_copy);   // (the box kernels are already queued behind)
     if (!ok || e != hipSuccess) {
         pedp_set_error("pedp_cloud_create_device: %s", ok ? hipGetErrorString(e) : "allocation failed");
         pedp_cloud_destroy(cl);

@@ -106,6 +106,7 @@ struct pedp_ctx_s {
     int ray_tri_chunks = 0;  // 0 = auto
     int ray_variant = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // sweep timing
+    hipEvent_t ev_copy = nullptr;             // pedp_cloud_create_device: behind its copies (the host waits on it)
     bool ray_timed = false;
     bool nn_timed = false;
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;

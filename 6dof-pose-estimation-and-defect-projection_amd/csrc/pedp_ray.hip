@@ -331,6 +331,243 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
     if (ray < N && best != KEY_MISS) atomicMin(&keys[ray], best);
 }
 
+// ------------------------------------------------------------------ exhaustive sweep on the matrix pipe (shared origin)
+// The three scores of score_pair_shared -- d . a', d . b', d . c' + kappa |d|_1 -- are K = 3 dot products per (ray,
+// triangle): the one contraction of this stage.  v_mfma_f32_16x16x32_bf16 takes it as a FILTER in front of the exact
+// test (mt_eval / mt_accept / mt_key on the rare branch: not one result bit changes):
+//   * every float splits EXACTLY into three bf16 pieces by truncation (hi = top 16 bits of x, mid = top 16 bits of x - hi,
+//     lo = x - hi - mid: 3 x 8 mantissa bits, all of x's sign), so d_c x_c = sum over the nine piece products, each exact
+//     in f32; one dot product = 27 products, laid along K:  k = 9 c + 3 p + q  <->  d_{c,p} * x_{c,q};
+//   * K slot 27 carries the slack: A = |d|_1 rounded up, B = the triangle edge's bound rounded up (below);
+//   * A (16 rays x 32) is built once per wave and ray group and stays in registers for the whole sweep; B (32 x 16
+//     triangles of one edge) streams: one coalesced 1-KB load per fragment from a per-call record buffer laid out in
+//     fragment order ([16-triangle group][edge][K quarter][triangle][8 bf16]);
+//   * a wave owns 128 rays (8 A fragments): per 16 triangles 24 MFMAs (16 cycles each) and, per three of them, four
+//     v_min3 and two v_max3 -- issued in the half of each MFMA's 16 cycles the vector pipe is free.
+// Superset proof.  The oracle accepts only if fl(d . a') >= 0, fl(d . b') >= 0 and fl(d . c') + kappa |d|_1 >= 0
+// (pair_shared_kernel), fl = the three-rounding fma chain: |fl(d . x) - d . x| <= 4 u S, S = sum_c |d_c| |x_c| <= |d|_1 |x|_inf,
+// u = 2^-24.  The MFMA returns M = d . x + slack + delta: the pieces are exact, and its f32 accumulation of 29 terms --
+// whatever its order and rounding mode, truncation included (unit 2^-23) -- errs by at most 28 * 2^-23 * (S + slack)
+// < 2^-18 (S + slack).  With slack = (|d|_1 + 1e-18) * ((2^-17 + 2^-22) |x|_inf [+ kappa for c'] + 1e-18) the value M is >= 0 whenever the
+// oracle's own score is: 2^-17 is more than twice what the accumulation can lose, 2^-22 = 4 u covers fl.  Measured
+// (tests/test_ray_gpu.py::test_mfma_filter_*): no accepted pair of the oracle is ever rejected, and the filter's actual
+// error stays below a hundredth of the slack.  Non-finite or astronomically large operands (> 1e15: their products
+// could overflow inside the pipe) never reach it: such a ray or triangle gets zero pieces and a slack that always
+// passes, and the exact test decides.
+constexpr int MF_RG = 8;                   // ray groups (16 rays) per wave
+constexpr int MF_WAVES = 4;                // waves per workgroup
+constexpr int MF_RAYS = 16 * MF_RG * MF_WAVES;   // 512 rays per workgroup
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+union Frag { bf8 v; unsigned short h[8]; uint4 q; };
+
+__device__ __forceinline__ void split3(float x, unsigned short out[3]) {  // x = hi + mid + lo exactly, bf16 each (truncation)
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    const float r1 = subr(x, hi);
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    const float lo = subr(r1, mid);
+    out[0] = (unsigned short)(__float_as_uint(hi) >> 16);
+    out[1] = (unsigned short)(__float_as_uint(mid) >> 16);
+    out[2] = (unsigned short)(__float_as_uint(lo) >> 16);
+}
+__device__ __forceinline__ unsigned short bf16_up(float x) {  // smallest bf16 >= x, x >= 0 finite
+    const unsigned b = __float_as_uint(x);
+    return (unsigned short)((b >> 16) + ((b & 0xFFFFu) ? 1u : 0u));
+}
+
+// A pair passes the filter iff none of its three scores is negative.  That is asked of the SIGN BITS with integer
+// instructions -- t = a | b | c is negative iff one of them is, and "some pair passed" is max over the t's >= 0 -- because
+// fminf / fmaxf on values that come out of the matrix pipe cost a quieting v_max each in this strict-IEEE file, and an
+// inline-asm v_min3 hides its reads of MFMA results from the compiler's hazard recogniser (the hardware does not
+// interlock them: measured garbage).  A score of -0.0 would count as negative; the slack term is a strictly positive
+// normal number (both of its factors are floored at 1e-18), so a sum is never -0.
+__device__ __forceinline__ int sign3(float a, float b, float c) {
+    return (int)(__float_as_uint(a) | __float_as_uint(b) | __float_as_uint(c));
+}
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
+
+// per-call records of the shared-origin rays for the matrix sweep: a', b', c', kappa as pair_shared_kernel forms them,
+// split and laid out in fragment order.  One thread per triangle.
+__global__ void mfma_rec_kernel(const float *__restrict__ aos, int64_t F_padded, const float *__restrict__ rays6,
+                                const int *__restrict__ shared_flag, unsigned short *__restrict__ out) {
+    if (*shared_flag == 0) return;
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F_padded) return;
+    const float *r = aos + f * PEDP_TRI_STRIDE;
+    const float e1x = r[3], e1y = r[4], e1z = r[5], e2x = r[6], e2y = r[7], e2z = r[8];
+    const float mx = r[9], my = r[10], mz = r[11];
+    const float sx = subr(rays6[0], r[0]), sy = subr(rays6[1], r[1]), sz = subr(rays6[2], r[2]);
+    const float ax = fmar(e2y, sz, -mulr(e2z, sy));
+    const float ay = fmar(e2z, sx, -mulr(e2x, sz));
+    const float az = fmar(e2x, sy, -mulr(e2y, sx));
+    const float bx = fmar(sy, e1z, -mulr(sz, e1y));
+    const float by = fmar(sz, e1x, -mulr(sx, e1z));
+    const float bz = fmar(sx, e1y, -mulr(sy, e1x));
+    const float tn = -dot3(sx, sy, sz, mx, my, mz);
+    float v[9], slack[3];
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fmaxf(fabsf(az), fabsf(bx))),
+                            fmaxf(fmaxf(fabsf(by), fabsf(bz)), fmaxf(fmaxf(fabsf(mx), fabsf(my)), fabsf(mz))));
+    for (int k = 0; k < 9; ++k) v[k] = 0.0f;
+    bool never = false;
+    if (mx == 0.0f && my == 0.0f && mz == 0.0f) {              // never accepted (pad records, zero-area triangles: det = 0 for every ray)
+        never = true;
+        slack[0] = slack[1] = slack[2] = 0.0f;
+    } else if ((!(tn > 0.0f) && !(tn < 0.0f)) || !(big < 1e15f)) {   // tn == 0 / NaN, or operands the pipe must not see: always to the exact test
+        slack[0] = slack[1] = slack[2] = 1e30f;
+    } else {
+        const float sg = tn < 0.0f ? -1.0f : 1.0f;
+        v[0] = sg * ax; v[1] = sg * ay; v[2] = sg * az;
+        v[3] = sg * bx; v[4] = sg * by; v[5] = sg * bz;
+        v[6] = sg * subr(subr(mx, ax), bx); v[7] = sg * subr(subr(my, ay), by); v[8] = sg * subr(subr(mz, az), bz);
+        const float kappa = 1.2e-6f * ((fabsf(mx) + fabsf(my) + fabsf(mz)) + (fabsf(ax) + fabsf(ay) + fabsf(az)) + (fabsf(bx) + fabsf(by) + fabsf(bz))) + 1e-37f;
+        const float w = 7.9e-6f;                               // > 2^-17 + 2^-22
+        slack[0] = w * fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2])) * 1.0001f + 1e-18f;
+        slack[1] = w * fmaxf(fmaxf(fabsf(v[3]), fabsf(v[4])), fabsf(v[5])) * 1.0001f + 1e-18f;
+        slack[2] = (w * fmaxf(fmaxf(fabsf(v[6]), fabsf(v[7])), fabsf(v[8])) + kappa) * 1.0001f + 1e-18f;
+    }
+    const int64_t G = f >> 4, t = f & 15;
+    for (int e = 0; e < 3; ++e) {
+        unsigned short piece[3][3];
+        for (int c = 0; c < 3; ++c) split3(v[3 * e + c], piece[c]);
+        for (int k = 0; k < 32; ++k) {
+            unsigned short val = 0;
+            if (k < 27) val = piece[k / 9][k % 3];
+            else if (k == 27) val = never ? (unsigned short)0xBF80 /* -1 times the ray's positive slot: the score is negative */ : bf16_up(slack[e]);
+            out[((((G * 3 + e) * 4 + (k >> 3)) * 16 + t) << 3) + (k & 7)] = val;
+        }
+    }
+}
+
+// A fragment of ray (d) for the lane's K quarter h: k = 8 h + j
+__device__ __forceinline__ bf8 mfma_ray_frag(float dx, float dy, float dz, int h) {
+    const float dn = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
+    const bool ok = dn < 1e15f;                                 // (false for NaN / inf too)
+    unsigned short piece[3][3];
+    split3(ok ? dx : 0.0f, piece[0]);
+    split3(ok ? dy : 0.0f, piece[1]);
+    split3(ok ? dz : 0.0f, piece[2]);
+    const unsigned short sl = ok ? bf16_up(dn * 1.0001f + 1e-18f) : (unsigned short)0x7149 /* 1e30 */;
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned short val = 0;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const int k = 8 * hh + j;
+            const unsigned short cand = k < 27 ? piece[k / 9][(k % 9) / 3] : (k == 27 ? sl : (unsigned short)0);
+            val = h == hh ? cand : val;
+        }
+        f.h[j] = val;
+    }
+    return f.v;
+}
+
+__device__ __forceinline__ void mfma_exact(const float *__restrict__ rays6, const float *__restrict__ aos, int64_t ray, int64_t N, unsigned tri,
+                                           unsigned long long *__restrict__ keys) {
+    if (ray >= N) return;
+    Ray r;
+    r.ox = rays6[6 * ray + 0]; r.oy = rays6[6 * ray + 1]; r.oz = rays6[6 * ray + 2];
+    r.dx = rays6[6 * ray + 3]; r.dy = rays6[6 * ray + 4]; r.dz = rays6[6 * ray + 5];
+    const MT m = mt_eval(r, aos + (size_t)tri * PEDP_TRI_STRIDE);
+    if (mt_accept(m)) atomicMin(&keys[ray], mt_key(m, tri));
+}
+
+__global__ __launch_bounds__(64 * MF_WAVES) void ray_sweep_mfma_kernel(
+    const uint4 *__restrict__ rec, const float *__restrict__ aos, int tgroups_total, int tgroups_per_chunk, int n_chunks,
+    const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys, const int *__restrict__ shared_flag) {
+    if (*shared_flag == 0) return;
+    const int b = blockIdx.x;
+    const int chunk = b % n_chunks;  // n_chunks % 8 == 0: one XCD per chunk
+    const int64_t rb = b / n_chunks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, h = lane >> 4;
+    const int64_t ray_base = (rb * MF_WAVES + wave) * (16 * MF_RG);
+    if (ray_base >= N) return;
+    bf8 A[MF_RG];
+#pragma unroll
+    for (int g = 0; g < MF_RG; ++g) {
+        const int64_t ray = ray_base + 16 * g + row;
+        const int64_t rl = ray < N ? ray : N - 1;  // tail rows repeat the last ray; their hits are dropped (ray >= N)
+        A[g] = mfma_ray_frag(rays6[6 * rl + 3], rays6[6 * rl + 4], rays6[6 * rl + 5], h);
+    }
+    int g0 = chunk * tgroups_per_chunk, g1 = g0 + tgroups_per_chunk;
+    if (g1 > tgroups_total) g1 = tgroups_total;
+    if (g0 >= g1) return;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const uint4 *p = rec + (size_t)g0 * 192 + lane;
+    Frag B0, B1, B2, N0, N1, N2;
+    B0.q = p[0]; B1.q = p[64]; B2.q = p[128];
+    for (int tg = g0; tg < g1; ++tg) {
+        const uint4 *pn = rec + (size_t)(tg + 1 < g1 ? tg + 1 : tg) * 192 + lane;   // the next group's fragments, in flight over this one's MFMAs
+        N0.q = pn[0]; N1.q = pn[64]; N2.q = pn[128];
+        int any = (int)0x80000000;   // max over the pairs' sign words: >= 0 iff some pair has no negative score
+#pragma unroll
+        for (int g = 0; g < MF_RG; ++g) {
+            const f4 ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B0.v, zero, 0, 0, 0);
+            const f4 rb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B1.v, zero, 0, 0, 0);
+            const f4 rc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B2.v, zero, 0, 0, 0);
+            any = imax3(any, sign3(ra[0], rb2[0], rc[0]), sign3(ra[1], rb2[1], rc[1]));
+            any = imax3(any, sign3(ra[2], rb2[2], rc[2]), sign3(ra[3], rb2[3], rc[3]));
+        }
+        if (__builtin_amdgcn_ballot_w64(any >= 0) != 0) {   // wave-uniform, rarely taken: which pairs, and the exact test for them
+#pragma unroll
+            for (int g = 0; g < MF_RG; ++g) {
+                const f4 ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B0.v, zero, 0, 0, 0);
+                const f4 rb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B1.v, zero, 0, 0, 0);
+                const f4 rc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g], B2.v, zero, 0, 0, 0);
+                const int t0 = sign3(ra[0], rb2[0], rc[0]), t1 = sign3(ra[1], rb2[1], rc[1]), t2 = sign3(ra[2], rb2[2], rc[2]),
+                          t3 = sign3(ra[3], rb2[3], rc[3]);
+                if (__builtin_amdgcn_ballot_w64(imax3(t0, t1, max(t2, t3)) >= 0) == 0) continue;   // (no pair of this ray group)
+                const int64_t r0 = ray_base + 16 * g + 4 * h;
+                const unsigned tri = (unsigned)(tg * 16 + row);
+                if (t0 >= 0) mfma_exact(rays6, aos, r0, N, tri, keys);
+                if (t1 >= 0) mfma_exact(rays6, aos, r0 + 1, N, tri, keys);
+                if (t2 >= 0) mfma_exact(rays6, aos, r0 + 2, N, tri, keys);
+                if (t3 >= 0) mfma_exact(rays6, aos, r0 + 3, N, tri, keys);
+            }
+        }
+        B0 = N0; B1 = N1; B2 = N2;
+    }
+}
+
+// diagnostics (tests/test_ray_gpu.py::test_mfma_filter_*): the filter's score of EVERY (ray, triangle) pair and, beside it,
+// the slack alone (the same MFMAs with every K slot of A but the slack's cleared): score - slack is what the pipe made
+// of d . x', and how far below zero it falls on a pair the oracle accepts is the share of the slack that pair uses
+__global__ __launch_bounds__(64) void mfma_debug_kernel(const uint4 *__restrict__ rec, int tgroups_total, const float *__restrict__ rays6,
+                                                        int64_t N, int64_t F, float *__restrict__ score, float *__restrict__ slack) {
+    const int lane = threadIdx.x & 63, row = lane & 15, h = lane >> 4;
+    const int64_t ray_base = (int64_t)blockIdx.x * 16;
+    const int64_t ray = ray_base + row, rl = ray < N ? ray : N - 1;
+    Frag A, S;
+    A.v = mfma_ray_frag(rays6[6 * rl + 3], rays6[6 * rl + 4], rays6[6 * rl + 5], h);
+    S = A;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (!(h == 3 && j == 3)) S.h[j] = 0;   // K slot 27 = quarter 3, element 3
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int tg = 0; tg < tgroups_total; ++tg) {
+        const uint4 *p = rec + (size_t)tg * 192 + lane;
+        Frag B0, B1, B2;
+        B0.q = p[0]; B1.q = p[64]; B2.q = p[128];
+        const f4 ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, B0.v, zero, 0, 0, 0), rb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, B1.v, zero, 0, 0, 0),
+                 rc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, B2.v, zero, 0, 0, 0);
+        const f4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.v, B0.v, zero, 0, 0, 0), sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.v, B1.v, zero, 0, 0, 0),
+                 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.v, B2.v, zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = ray_base + 4 * h + i, t = (int64_t)tg * 16 + row;
+            if (r < N && t < F) {
+                // the edge with the smallest score decides; report that edge's slack
+                float m = ra[i], sl = sa[i];
+                if (rb[i] < m) { m = rb[i]; sl = sb[i]; }
+                if (rc[i] < m) { m = rc[i]; sl = sc[i]; }
+                if (sign3(ra[i], rb[i], rc[i]) < 0 && !(m < 0.0f)) m = -0.0f;   // (the kernel's rule: a sign bit set is a rejection)
+                score[r * F + t] = m;
+                slack[r * F + t] = sl;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ culled sweep (shared origin)
 constexpr int CL_TRIS = 16;                              // triangles per cluster
 constexpr int CL_GROUPS = CL_TRIS / (2 * RPL_PAIRS);     // loop groups per cluster (4)
@@ -1596,7 +1833,7 @@ int pedp_mesh_size(pedp_mesh_t m, int64_t *V, int64_t *F) {
 int pedp_raycast_configure(pedp_ctx_t c, int tri_chunks, int variant) {
     PEDP_REQUIRE(c, "pedp_raycast_configure: null context");
     PEDP_REQUIRE(tri_chunks >= 0 && tri_chunks % 8 == 0, "pedp_raycast_configure: tri_chunks must be a multiple of 8");
-    PEDP_REQUIRE(variant >= 0 && variant <= 4, "pedp_raycast_configure: variant must be 0..4");
+    PEDP_REQUIRE(variant >= 0 && variant <= 5, "pedp_raycast_configure: variant must be 0..5");
     c->ray_tri_chunks = tri_chunks;
     c->ray_variant = variant;
     return PEDP_OK;
@@ -1696,7 +1933,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         PEDP_HIP_CHECK(hipGetLastError());
         c->rast_hdr_ready = (void *)base;
         c->rast_seq += 1;
-    } else if (variant == 1 || variant == 3) {
+    } else if (variant == 1 || variant == 3 || variant == 5) {
         // aux layout: [flag + bounds + seg info: 256 B][shared pair records][cone records][hist][perm]
         //             [packet masks][packet counts][segment table]
         const int64_t n_packets = (N + 63) / 64;
@@ -1711,7 +1948,9 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         const size_t sz_mask = align256(sizeof(unsigned long long) * (size_t)n_packets * (size_t)n_cwords);
         const size_t sz_pcnt = align256(sizeof(int) * (size_t)n_packets);
         const size_t sz_seg = align256(sizeof(int) * (size_t)max_segs);
-        st = c->ray_aux.reserve(256 + sz_tri3 + sz_cone + sz_hist + sz_perm + sz_mask + sz_pcnt + 3 * sz_seg);
+        const size_t sz_mf = variant == 1 ? align256((size_t)192 * (size_t)mesh->F_padded) : 0;   // matrix-sweep records: 3 x 32 bf16 per triangle
+        PEDP_REQUIRE(mesh->F_padded % 16 == 0, "pedp_raycast: padded triangle count is not a multiple of 16");
+        st = c->ray_aux.reserve(256 + sz_tri3 + sz_cone + sz_hist + sz_perm + sz_mask + sz_pcnt + 3 * sz_seg + sz_mf);
         if (st) return st;
         char *aux = (char *)c->ray_aux.ptr;
         int *flag = (int *)aux;
@@ -1734,6 +1973,7 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         int *seg_pk = (int *)((char *)pk_cnt + sz_pcnt);
         int *seg_rank0 = (int *)((char *)seg_pk + sz_seg);
         int *seg_n = (int *)((char *)seg_rank0 + sz_seg);
+        unsigned short *mf_rec = (unsigned short *)((char *)seg_n + sz_seg);
         PEDP_HIP_CHECK(hipMemsetAsync(flag, 0xFF, sizeof(int), c->stream));
         hipLaunchKernelGGL(origin_check_kernel, dim3(2 * c->num_cus), dim3(256), 0, c->stream, d_rays, N, flag);
         hipLaunchKernelGGL(pair_shared_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream,
@@ -1776,9 +2016,17 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
             hipLaunchKernelGGL(ray_sweep_seg_kernel, dim3((unsigned)((max_segs + 3) / 4)), dim3(RPL_BLOCK), 0, c->stream,
                                (const f2 *)tri3, mesh->tri, n_cwords, pmask, seg_pk, seg_rank0, seg_n, seg_info, d_rays,
                                perm, N, keys);
-        } else {
+        } else if (variant == 5) {   // round 3's exhaustive kernel: the packed fp32 loop on the vector pipe
             hipLaunchKernelGGL(ray_sweep_rpl_kernel<true>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
                                (const f2 *)tri3, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
+        } else {                     // exhaustive on the matrix pipe: bf16 filter, exact test on the rare branch
+            hipLaunchKernelGGL(mfma_rec_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream, mesh->tri,
+                               mesh->F_padded, d_rays, flag, mf_rec);
+            const int tg_total = (int)(mesh->F_padded / 16), tgpc = (tg_total + n_chunks - 1) / n_chunks;
+            const int64_t mf_grid = ((N + MF_RAYS - 1) / MF_RAYS) * n_chunks;
+            PEDP_REQUIRE(mf_grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
+            hipLaunchKernelGGL(ray_sweep_mfma_kernel, dim3((unsigned)mf_grid), dim3(64 * MF_WAVES), 0, c->stream, (const uint4 *)mf_rec,
+                               mesh->tri, tg_total, tgpc, n_chunks, d_rays, N, keys, flag);
         }
         hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
                            (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);
@@ -1856,6 +2104,38 @@ int pedp_debug_rast_rects(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, in
     (void)hipFree(d_ray);
     PEDP_HIP_CHECK(e);
     grid[0] = hh.GX; grid[1] = hh.GY; grid[2] = c->rast_status ? c->rast_status[0] : -1;
+    return PEDP_OK;
+}
+
+/* Diagnostics of the matrix-pipe filter of the exhaustive sweep: for N host rays of ONE origin the filter's score of every
+ * (ray, triangle) pair (>= 0: the pair goes to the exact test) and the slack inside it, N x F float32 each, row-major. */
+int pedp_debug_mfma_scores(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, float *score, float *slack) {
+    PEDP_REQUIRE(c && mesh && rays6 && score && slack && N > 0 && mesh->F > 0, "pedp_debug_mfma_scores: bad argument");
+    PEDP_REQUIRE(mesh->ctx == c && N * mesh->F <= ((int64_t)1 << 27), "pedp_debug_mfma_scores: foreign mesh, or more than 2^27 pairs");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    float *d_rays = nullptr, *d_sc = nullptr, *d_sl = nullptr;
+    unsigned short *d_rec = nullptr;
+    int *d_flag = nullptr;
+    const size_t pairs = (size_t)N * (size_t)mesh->F;
+    hipError_t e = hipMalloc((void **)&d_rays, sizeof(float) * 6 * (size_t)N);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sc, sizeof(float) * pairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sl, sizeof(float) * pairs);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rec, (size_t)192 * (size_t)mesh->F_padded);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays6, sizeof(float) * 6 * (size_t)N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0xFF, sizeof(int), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mfma_rec_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, mesh->F_padded,
+                           (const float *)d_rays, (const int *)d_flag, d_rec);
+        hipLaunchKernelGGL(mfma_debug_kernel, dim3((unsigned)((N + 15) / 16)), dim3(64), 0, c->stream, (const uint4 *)d_rec,
+                           (int)(mesh->F_padded / 16), (const float *)d_rays, N, mesh->F, d_sc, d_sl);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(score, d_sc, sizeof(float) * pairs, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(slack, d_sl, sizeof(float) * pairs, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rays); (void)hipFree(d_sc); (void)hipFree(d_sl); (void)hipFree(d_rec); (void)hipFree(d_flag);
+    PEDP_HIP_CHECK(e);
     return PEDP_OK;
 }
 

@@ -56,13 +56,17 @@ class FrameChain:
 
     # ------------------------------------------------------------------ the stages both branches share
     def _laps(self, timed):
-        torch, laps = self.torch, [time.perf_counter()]
+        torch, laps, marks = self.torch, [time.perf_counter()], {}
 
         def lap(name):
             if timed:
                 torch.cuda.synchronize()
                 laps.append(time.perf_counter())
-                self.stage_ms[name] = 1e3 * (laps[-1] - laps[-2])
+                if name.startswith("  "):          # a part of the stage that follows: timed, and the stage still spans it
+                    marks.setdefault("t0", laps[-2])
+                    self.stage_ms[name] = 1e3 * (laps[-1] - laps[-2])
+                else:
+                    self.stage_ms[name] = 1e3 * (laps[-1] - marks.pop("t0", laps[-2]))
 
         return lap
 
@@ -89,10 +93,14 @@ class FrameChain:
         lap("scene cloud")
         return d, xyz, pts, int(len(dev_pts)), source
 
-    def _project(self, model_in_scene, heat):
+    def _project(self, model_in_scene, heat, lap=None):
         """transform_object + ray_tracing + the move into the depth camera's frame (run.py:109-118, :179-200)."""
         mesh_copy = self.proj.posed_mesh(model_in_scene, self.mesh)           # transform_object(reader.target_mesh, ...)
+        if lap:
+            lap("  posed mesh (viewer's copy)")
         cloud = self.proj.project(model_in_scene, heat, self.heat_threshold, into=self.color_to_depth)
+        if lap:
+            lap("  heat-map projection")
         return mesh_copy, cloud
 
     # ------------------------------------------------------------------ run.py:79-131
@@ -110,7 +118,7 @@ class FrameChain:
         model_in_scene = np.linalg.inv(icp.transformation)
         self.delta_pose = np.linalg.inv(init) @ model_in_scene                                          # run.py:104-105
         self.current_transformation = self.previous_transformation = icp.transformation                 # run.py:107, :129
-        mesh_copy, cloud = self._project(model_in_scene, heat)                                          # run.py:109-118
+        mesh_copy, cloud = self._project(model_in_scene, heat, lap if timed else None)                  # run.py:109-118
         if cloud is not None:
             self.intersection_pcds.append(cloud)
         lap("posed mesh + projection")
@@ -138,7 +146,7 @@ class FrameChain:
         model_in_scene = np.linalg.inv(current)
         self.delta_pose = np.linalg.inv(init) @ model_in_scene                                          # run.py:176-178
         relative = model_in_scene @ self.previous_transformation                                        # run.py:183-184
-        mesh_copy, cloud = self._project(model_in_scene, heat)                                          # run.py:179-193
+        mesh_copy, cloud = self._project(model_in_scene, heat, lap if timed else None)                  # run.py:179-193
         for earlier in self.intersection_pcds:                                                          # run.py:196-197
             earlier.transform(relative)
         if cloud is not None:

@@ -14,20 +14,19 @@ One STEP = one frame of the hot path with inputs resident in HBM:
 The two stages are independent (scene cloud vs mesh): each runs on its own context and HIP
 stream and they overlap on the device; a step ends when both have finished.
 
-N > 1, --mode replica (default): the path's independent units are FRAMES -- every rank processes its own whole
-frame, no data-path collective (weak scaling; value = frames of all ranks x rays / time).  A camera frame's ray stage
-is 0.05 ms and its registration is a chain of 21 dependent 33-us passes: neither pays for a collective, so
-splitting ONE such frame over GPUs cannot speed it up, and the job scales by frames.  The one-frame split is
-still built, tested (tests/test_compat_gpu.py, two ranks) and timed beside the headline ("frame_sharded"):
---mode shard (north_star) makes it the headline: ONE frame is split over the ranks --
-rays in contiguous blocks with an all-gather of the 8-byte hit records (RCCL over xGMI, issued by the
-library on its own stream); it is the right shape for BASELINE config 4 ("bench_1m": a million triangles, a dense
-full-frame heat map).  The frame's ONE registration is replicated on every rank for scenes below
-a million points (a pass is ~35 us: 21 all-reduces cost more than they save; every rank gets the identical
-pose without a collective); larger scenes are sharded with one 29-double all-reduce per pass, and that
-variant is timed beside it ("icp_scene_sharded").  The ICP lever across GPUs at these sizes is the pose
-batch (BASELINE config 3): "icp_batched" shards its 256 start poses over the ranks.  Total work is fixed: strong scaling;
-in shard mode the replica rate of the same ranks is measured too and reported under "replica".
+N > 1, --mode shard (default; SURVEY s8e, north_star): ONE frame is split over the ranks -- rays in contiguous blocks,
+triangle records replicated, an all-gather of the 8-byte hit records (RCCL over xGMI, issued on the library's stream).
+Strong scaling.  The workload of the N > 1 headline is the one the split is built for, BASELINE config 4: the
+1280x720 dense frame (921,600 rays) against the 1M-triangle mesh, `value` = its rays / the slowest rank's time per
+sharded cast (`config.workload` says so; the same cast on ONE GPU is timed in the same run, `one_gpu_same_workload`,
+so the line carries its own strong-scaling ratio -- the N = 1 line of this file stays on the metric's own 100k
+configuration, as the contract asks).  The camera-size frame split the same way is timed beside it ("frame_100k":
+a 0.05-ms ray stage and a chain of 21 dependent 33-us passes -- neither pays for a collective, the registration is
+replicated on every rank below a million scene points and every rank gets the identical pose; the scene-sharded
+registration with one 29-double all-reduce per pass is timed under "icp_scene_sharded"), the pose batch of BASELINE
+config 3 sharded over the ranks under "icp_batched", and the rate of the same ranks each on its own whole frame
+(no collective, weak scaling) under "replica".
+--mode replica makes that last one the headline instead (value = frames of all ranks x rays / time).
 
 Timed regions, each bracketed by barrier + synchronize, max over ranks:
     headline     K steps of the default path (triangle-driven ray stage, chunked ICP: one launch per pass)
@@ -77,7 +76,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="bench_100k")
-    ap.add_argument("--mode", choices=["shard", "replica"], default="replica")
+    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exhaustive / batched / 1M-triangle regions")
     return ap.parse_args()
@@ -299,6 +298,46 @@ def run(args):
     ray_variant, grid_status = _lib.raycast_last_variant(ray_ctx)   # which ray stage answered the timed casts
 
     extras = {}
+    # ---- N > 1, shard mode: the headline workload is BASELINE config 4 -- the 1280x720 dense frame against the 1M-triangle
+    # mesh, rays in contiguous blocks per rank + all-gather of the hit records; K timed casts after W warm-ups
+    big_headline = None
+    if mode == "shard" and args.config == "bench_100k":
+        big = synth.Frame("bench_1m")
+        bf = pdist.ShardedFrame(ray_be, big.verts_posed, big.tris, big.rays6)
+        for _ in range(max(args.warmup, 1)):
+            bf.cast()
+            ray_ctx.synchronize()
+        big_rows = []
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            bf.cast()
+            ray_ctx.synchronize()
+            big_rows.append(_lib.raycast_last_sweep_ms(ray_ctx))
+        barrier()
+        big_elapsed = max_over_ranks(time.perf_counter() - tb)
+        big_variant = _lib.raycast_last_variant(ray_ctx)
+        t_all, prim_all = bf.hits()                       # host arrays of the whole frame, from the gathered records
+        # the same cast whole on this rank's GPU (no split, no collective): the line's own one-GPU reference
+        whole = _lib.Mesh(ray_ctx, big.verts_posed, big.tris)
+        rays_w = ray_be.to_device(big.rays6)
+        t_w = torch.empty(big.n_rays, dtype=torch.float32, device=dev)
+        p_w = torch.empty(big.n_rays, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            whole.cast_rays_device(rays_w.data_ptr(), big.n_rays, t_w.data_ptr(), p_w.data_ptr())
+        ray_ctx.synchronize()
+        barrier()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            whole.cast_rays_device(rays_w.data_ptr(), big.n_rays, t_w.data_ptr(), p_w.data_ptr())
+            ray_ctx.synchronize()
+        one_gpu = max_over_ranks(time.perf_counter() - tw)
+        same = bool(np.array_equal(t_all.view(np.uint32), t_w.cpu().numpy().view(np.uint32))
+                    and np.array_equal(prim_all, p_w.cpu().numpy().view(np.uint32)))
+        big_headline = {"rays": big.n_rays, "tris": big.n_tris, "elapsed": big_elapsed, "sweep_ms": float(np.mean(big_rows)),
+                        "variant": big_variant, "one_gpu_elapsed": one_gpu, "equals_one_gpu": same,
+                        "width": big.width, "height": big.height}
+        del bf, big, whole, rays_w, t_w, p_w, t_all, prim_all
     if not args.no_extras:
         # ---- exhaustive region: the all-pairs path, same resident inputs, same sharding
         ex_steps = max(2, min(args.steps, 4))
@@ -428,7 +467,7 @@ def run(args):
             batch_s.append(max_over_ranks(time.perf_counter() - tb))
         extras["batched"] = (len(inits), min(batch_s))
         # ---- BASELINE config 4: 1M-triangle mesh, 1280x720 dense frame, rays sharded + all-gather
-        if args.config == "bench_100k":
+        if args.config == "bench_100k" and big_headline is None:
             big = synth.Frame("bench_1m")
             bf = pdist.ShardedFrame(ray_be, big.verts_posed, big.tris, big.rays6)
             for _ in range(2):
@@ -445,13 +484,17 @@ def run(args):
 
     if rank == 0:
         traffic = {}
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # PMC passes committed under profiles/
+        traffic_file = None
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # PMC passes committed under profiles/
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     traffic = json.load(fh)
+                traffic_file = "profiles/" + name
                 break
             except OSError:
                 pass
+        traffic_source = (f"{traffic_file}: separate rocprofv3 --pmc passes over tools/pmc_target.py, committed -- NOT measured in this "
+                          "run (the live figures of this line are the HIP-event kernel times)") if traffic_file else None
         trace_us = None     # the same kernel in the committed rocprofv3 kernel trace of this command
         import glob, re
         stats = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats_v*.csv"))
@@ -502,7 +545,8 @@ def run(args):
                          "achieved": sweep_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": sweep_tflops / PEAK_FP32_TFLOPS,
                          "traffic": traffic.get("icp_pass_kernel", {}).get("hbm_bytes_per_launch"),
-                         "mfma_util_pmc": traffic.get("icp_pass_kernel", {}).get("mfma_util"),
+                         "traffic_source": traffic_source,
+                         "mfma_util_pmc_committed_profile": traffic.get("icp_pass_kernel", {}).get("mfma_util"),
                          "kernel_ms": sweep_ms, "launches_per_step": passes,
                          "kernel_ms_x_launches": sweep_ms * passes, "region_ms_per_step": ms_per_step,
                          "kernel_us_committed_kernel_trace": trace_us,
@@ -539,14 +583,15 @@ def run(args):
                 "kernel": "nn_sweep_kernel<4,2> (all pairs)", "region": "exhaustive", "bound": "mfma",
                 "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
                 "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"),
-                "mfma_util_pmc": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
+                "traffic_source": traffic_source,
+                "mfma_util_pmc_committed_profile": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
                 "kernel_ms": ex_sweep_ms, "launches_per_step": ex_passes, "kernel_ms_x_launches": ex_sweep_ms * ex_passes,
                 "region_ms_per_step": ex_ms,
                 "note": f"{FLOP_PER_PAIR} flop x {int(n_scene * share)} scene x {n_model} model points per launch (SURVEY s8d)"}
             out["roofline_ray_sweep"] = {
                 "kernel": "ray_sweep_rpl_kernel<shared origin>", "region": "exhaustive", "bound": "valu_fp32",
                 "achieved": ray_exec, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ray_exec / PEAK_FP32_TFLOPS,
-                "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"),
+                "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
                 "kernel_ms": ex_ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ex_ray_ms,
                 "region_ms_per_step": ex_ms, "mrays_per_s": n_rays * share / (ex_ray_ms * 1e-3) / 1e6,
                 "algorithmic_46flop_tflops": ray_algo, "algorithmic_46flop_frac": ray_algo / PEAK_FP32_TFLOPS,
@@ -568,7 +613,7 @@ def run(args):
                           else f"ray stage, variant {ray_variant}", "region": "headline", "bound": "hbm",
                 "achieved": ray_bytes / (ray_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ray_bytes / (ray_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": None if not rast else rast.get("hbm_bytes_per_cast"),
+                "traffic": None if not rast else rast.get("hbm_bytes_per_cast"), "traffic_source": traffic_source,
                 "kernel_ms": ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ray_ms, "region_ms_per_step": ms_per_step,
                 "pmc": rast,
                 "note": "algorithmic bytes of one cast = 24 B per ray in + 48 B per triangle record in + 8 B per ray out "
@@ -641,6 +686,40 @@ def run(args):
             out["bench_1m"] = {"workload": f"{br} rays x {bt} triangles (BASELINE config 4), ray stage only",
                                "ms_per_frame": 1e3 * bsec, "mrays_per_s": br / bsec / 1e6, "sweep_ms_rank0": bsweep,
                                "parallelism": f"rays in {world} contiguous block(s)" + (" + all-gather" if world > 1 else "")}
+        if big_headline is not None:
+            # the N > 1 headline: BASELINE config 4's cast, sharded; what the 100k frame did in the same split moves aside
+            bh = big_headline
+            out["frame_100k"] = {k: out[k] for k in ("value", "ms_per_step", "ray_stage_ms", "ray_stage_mrays_per_s", "icp_ms",
+                                                      "icp_iters_per_s", "icp_passes", "icp_fitness", "pose_error_vs_gt", "ray_variant",
+                                                      "ray_grid_status", "roofline")}
+            out["frame_100k"]["workload"] = out["config"]["workload"]
+            out["frame_100k"]["note"] = ("the camera-size frame in the same split (rays in blocks + all-gather, the registration "
+                                         "replicated): a 0.05-ms ray stage does not pay for a collective")
+            for k in ("ray_stage_ms", "ray_stage_mrays_per_s", "icp_ms", "icp_iters_per_s", "icp_passes", "icp_pairs_swept_per_pass",
+                      "icp_fallback_points_per_pass", "icp_fitness", "icp_inlier_rmse", "pose_error_vs_gt"):
+                out.pop(k, None)
+            ms_big = 1e3 * bh["elapsed"] / args.steps
+            out["value"] = bh["rays"] * args.steps / bh["elapsed"] / 1e6
+            out["ms_per_step"] = ms_big
+            out["metric"] = "Mrays/s ray-mesh, 1280x720 dense frame vs 1M-tri mesh (BASELINE config 4), rays sharded + all-gather"
+            out["dtype"] = "f32"
+            out["config"]["workload"] = (f"bench_1m (BASELINE config 4): {bh['width']}x{bh['height']} dense frame, {bh['rays']} rays x "
+                                         f"{bh['tris']} triangles per step, ray stage (the split's workload; the 100k frame under frame_100k)")
+            out["ray_variant"], out["ray_grid_status"] = bh["variant"]
+            out["hits_equal_one_gpu_cast"] = bh["equals_one_gpu"]
+            out["one_gpu_same_workload"] = {"ms_per_step": 1e3 * bh["one_gpu_elapsed"] / args.steps,
+                                            "value_mrays_per_s": bh["rays"] * args.steps / bh["one_gpu_elapsed"] / 1e6,
+                                            "note": "the whole cast on one of these GPUs, no split, no collective, same run"}
+            out["strong_scaling_speedup"] = bh["one_gpu_elapsed"] / bh["elapsed"]
+            algo = 24.0 * bh["rays"] / world + 48.0 * bh["tris"] + 8.0 * bh["rays"] / world
+            gbs = algo / (bh["sweep_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "triangle-driven ray stage (rast_* kernels of one cast) on this rank's ray block", "region": "headline",
+                               "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                               "traffic": None, "kernel_ms": bh["sweep_ms"], "launches_per_step": 1, "kernel_ms_x_launches": bh["sweep_ms"],
+                               "region_ms_per_step": ms_big,
+                               "note": "algorithmic bytes of rank 0's share of a cast (24 B per ray in, 48 B per triangle record, 8 B per "
+                                       "ray out) / the HIP-event span of the cast's kernels on the ray stream; the rest of a step is the "
+                                       "all-gather of the hit records"}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(frame, depth)
         print(json.dumps(out), flush=True)

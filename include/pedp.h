@@ -77,15 +77,20 @@ int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N
  * (multiple of 8: chunk c is served by XCD c % 8) and sweep variant:
  *   0 auto (2 below 16,384 rays, else 4; 3 for a ray count whose last variant-4 cast had to be
  *     completed by the exhaustive sweep)
- *   1 ray-per-lane, every ray tested against every triangle
+ *   1 every ray against every triangle: rays of one origin on the matrix pipe (bf16 MFMA filter with a proven
+ *     slack, the exact test on the pairs that pass it), other rays on the packed fp32 loop of variant 5
  *   2 triangle-per-lane with a wavefront-wide min-t reduction
  *   3 ray-per-lane with conservative cluster culling when all rays share one origin
  *     (falls back to 1 on the device otherwise)
  *   4 triangle-driven: rays of one origin threaded into a grid of directions, every triangle
  *     tested against the rays in the cells its image covers (completed by 1 on the device when
  *     the rays do not share an origin, leave the grid's half space or crowd a cell).
+ *   5 every ray against every triangle on the vector pipe (ray per lane, packed fp32; round 3's exhaustive kernel)
  * All variants return identical bits. */
 int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
+/* Diagnostics of variant 1's matrix-pipe filter (tests): for N host rays of ONE origin, the filter's score of every (ray,
+ * triangle) pair -- >= 0: the pair goes to the exact test -- and the slack inside that score; N x F float32 each, host. */
+int pedp_debug_mfma_scores(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N, float *score, float *slack);
 
 /* Which variant the last pedp_raycast of this context ran and, for variant 4, whether the grid
  * answered the cast (grid_status 0) or the exhaustive sweep had to (bit 0 origins differ, 1 a ray

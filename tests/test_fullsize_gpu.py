@@ -26,7 +26,7 @@ def test_bench_100k_rays_bit_exact_all_variants(ctx, oracle, frame100k):
     ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
     assert np.isfinite(ref["t_hit"]).sum() == 35863            # hit count of this frame (oracle)
     mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
-    for variant in (4, 3, 1):                                    # triangle-driven grid (the default), cone-culled, exhaustive
+    for variant in (4, 3, 1, 5):                                 # triangle-driven grid (the default), cone-culled, exhaustive on the matrix pipe, exhaustive packed fp32
         _lib.raycast_configure(ctx, 0, variant)
         try:
             got = mesh.cast_rays(f.rays6)                        # natural ray order, with uv

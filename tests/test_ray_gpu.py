@@ -426,10 +426,9 @@ def _pinhole(rng, w, h, fov_scale, origin=None, tilt=None):
     return np.hstack([np.tile(o, (w * h, 1)), d]).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_grid_margin_on_triangle_soups(ctx, oracle, seed):
-    """The fuzz soups of the sweep test (sizes over four decades, slivers, triangles across the camera plane) at a
-    size the oracle can test pair by pair: every accepted pair is inside its rectangle with a factor >= 2 to spare."""
+def _soup_case(seed):
+    """A fuzz soup (sizes over four decades, slivers, triangles across the camera plane) at a size the oracle can test
+    pair by pair, and a pinhole camera's rays (every third one tilted, every second one off the origin)."""
     rng = np.random.default_rng(4000 + seed)
     n_tri = 700
     centre = rng.normal(0, 1, 3) * [150.0, 150.0, 0.0] + [0.0, 0.0, rng.uniform(300, 900)]
@@ -447,15 +446,23 @@ def test_grid_margin_on_triangle_soups(ctx, oracle, seed):
     if tilt is not None:
         verts = verts @ tilt.T
     rays = _pinhole(rng, 168, 110, rng.uniform(0.35, 1.6), origin, tilt)     # up to ~55 degrees off axis
-    worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts.astype(np.float32), tris, rays)
+    return verts.astype(np.float32), tris, rays
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grid_margin_on_triangle_soups(ctx, oracle, seed):
+    """The fuzz soups of the sweep test at a size the oracle can test pair by pair: every accepted pair is inside its
+    rectangle with a factor >= 2 to spare."""
+    verts, tris, rays = _soup_case(seed)
+    worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts, tris, rays)
     print(f"soup {seed}: {n_pairs} accepted pairs, {n_bounded} with a bounded image, largest used share of the margin {worst:.3f}")
     assert n_pairs > 300 and n_bounded > 0.3 * n_pairs    # (the triangles across the camera plane have no bounded image and meet many rays)
 
 
-def test_grid_margin_on_adversarial_triangles(ctx, oracle):
-    """What the margin's formula is about: triangles seen almost edge-on (the origin a hair off their plane), needles
-    whose sharp corner is NOT the record's first vertex, slivers of the size of the view, big triangles whose first
-    vertex is far away while the rays meet them close by, a wide-angle camera.  Every accepted pair inside with >= 2x."""
+def _adversarial_cases():
+    """Triangles seen almost edge-on (the origin a hair off their plane), needles whose sharp corner is NOT the record's
+    first vertex, slivers of the size of the view, big triangles whose first vertex is far away while the rays meet them
+    close by; three cameras, one wide-angle, one off the origin.  Yields (verts, tris, rays, fov)."""
     rng = np.random.default_rng(77)
     tri_list = []
 
@@ -488,10 +495,81 @@ def test_grid_margin_on_adversarial_triangles(ctx, oracle):
     verts = np.concatenate(tri_list).astype(np.float32)
     tris = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
     for fov, origin in ((0.9, None), (0.3, None), (0.45, rng.normal(0, 20, 3))):   # 0.3: +-59 degrees across
-        rays = _pinhole(rng, 168, 110, fov, origin)
+        yield verts, tris, _pinhole(rng, 168, 110, fov, origin), fov
+
+
+def test_grid_margin_on_adversarial_triangles(ctx, oracle):
+    """What the margin's formula is about (the sets of _adversarial_cases): every accepted pair inside with >= 2x."""
+    for verts, tris, rays, fov in _adversarial_cases():
         worst, n_pairs, n_bounded = _margin_slack(ctx, oracle, verts, tris, rays)
         print(f"adversarial, fov scale {fov}: {n_pairs} accepted pairs, {n_bounded} bounded, largest used share of the margin {worst:.3f}")
         assert n_pairs > 300
+
+
+def _filter_slack(ctx, oracle, verts, tris, rays):
+    """The exhaustive sweep's matrix-pipe filter (variant 1, shared origin) against EVERY pair the oracle accepts: the
+    pair's score is >= 0 (it reaches the exact test), and what the bf16 pipe made of the dot product alone lies less than
+    HALF the slack below zero.  Returns (largest used share of the slack, accepted pairs, pairs that pass the filter)."""
+    from pedp_hip import _lib
+
+    mesh = _lib.Mesh(ctx, verts, tris)
+    score, slack = _lib.debug_mfma_scores(ctx, mesh, rays)
+    pairs = oracle.accepted_pairs(verts, tris, rays)
+    s, sl = score[pairs[:, 0], pairs[:, 1]].astype(np.float64), slack[pairs[:, 0], pairs[:, 1]].astype(np.float64)
+    assert (s >= 0).all() and not np.signbit(s).any(), f"the filter rejects {int(np.signbit(s).sum())} pair(s) the oracle accepts"
+    real = np.isfinite(sl) & (sl < 1e20) & (sl > 0)                 # (records / rays sent straight to the exact test carry 1e30)
+    used = np.maximum(sl[real] - s[real], 0.0) / sl[real]
+    worst = float(used.max()) if real.any() else 0.0
+    assert worst <= 0.5, f"an accepted pair uses {worst:.3f} of the slack: less than a factor two is left"
+    return worst, len(pairs), int((~np.signbit(score)).sum())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mfma_filter_on_triangle_soups(ctx, oracle, seed):
+    """Variant 1's bf16 MFMA filter on the soups: no accepted pair is rejected, half the slack is never used, and the
+    pairs that pass are few (the exact test that follows them is the rare branch)."""
+    verts, tris, rays = _soup_case(seed)
+    if seed % 2:                                                    # (the filter serves rays of ONE origin: these soups' cameras sit off it)
+        rays[:, :3] = rays[0, :3]
+    worst, n_pairs, n_pass = _filter_slack(ctx, oracle, verts, tris, rays)
+    print(f"soup {seed}: {n_pairs} accepted pairs, {n_pass} pass the filter ({n_pass / max(n_pairs, 1):.3f}x), largest used share of the slack {worst:.4f}")
+    assert n_pairs > 300 and n_pass < 3 * n_pairs + 50000           # (triangles in a plane through the origin pass for every ray)
+
+
+def test_mfma_filter_on_adversarial_triangles(ctx, oracle):
+    for verts, tris, rays, fov in _adversarial_cases():
+        worst, n_pairs, n_pass = _filter_slack(ctx, oracle, verts, tris, rays)
+        print(f"adversarial, fov scale {fov}: {n_pairs} accepted pairs, {n_pass} pass the filter, largest used share of the slack {worst:.4f}")
+        assert n_pairs > 300
+
+
+def test_mfma_filter_sends_hostile_operands_to_the_exact_test(ctx, oracle):
+    """Rays without a finite direction, astronomically large triangles, zero-area triangles, triangles in a plane through
+    the origin: the pipe never sees operands whose products could overflow, the results are the oracle's."""
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("tiny")
+    verts = f.verts_posed.copy()
+    tris = f.tris.copy()
+    verts = np.vstack([verts, np.array([[1e20, 0, 1e3], [0, 1e20, 1e3], [-1e20, -1e20, 1e3],      # a triangle the size of a galaxy
+                                        [5, 5, 50], [5, 5, 50], [5, 5, 50],                        # zero area
+                                        [0, 0, 0], [10, 0, 100], [0, 10, 100]], np.float32)])      # in a plane through the origin
+    n0 = len(f.verts_posed)
+    tris = np.vstack([tris, np.array([[n0, n0 + 1, n0 + 2], [n0 + 3, n0 + 4, n0 + 5], [n0 + 6, n0 + 7, n0 + 8]], tris.dtype)])
+    rays = f.rays6.copy()
+    rays[5, 3:] = np.nan
+    rays[6, 3:] = (np.inf, 0, 1)
+    rays[7, 3:] = 0.0
+    rays[8, 3:] = (3e30, 1e30, 2e30)
+    mesh = _lib.Mesh(ctx, verts, tris)
+    _lib.raycast_configure(ctx, 0, 1)
+    try:
+        got = mesh.cast_rays(rays)
+    finally:
+        _lib.raycast_configure(ctx, 0, 0)
+    ref = oracle.raycast(verts, tris, rays)
+    assert np.array_equal(got["primitive_ids"], ref["primitive_ids"])
+    assert np.array_equal(got["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
 
 
 def test_grid_margin_degenerate_records_cost_nothing(ctx, oracle):
