@@ -343,7 +343,7 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
 //     triangles of one edge) streams: one coalesced 1-KB load per fragment from a per-call record buffer laid out in
 //     fragment order ([16-triangle group][edge][K quarter][triangle][8 bf16]);
 //   * a wave owns 128 rays (8 A fragments): per 16 triangles 24 MFMAs (16 cycles each) and, per three of them, four
-//     v_min3 and two v_max3 -- issued in the half of each MFMA's 16 cycles the vector pipe is free.
+//     v_or3 and two v_max3_i32 (the sign test below) -- issued in the half of each MFMA's 16 cycles the vector pipe is free.
 // Superset proof.  The oracle accepts only if fl(d . a') >= 0, fl(d . b') >= 0 and fl(d . c') + kappa |d|_1 >= 0
 // (pair_shared_kernel), fl = the three-rounding fma chain: |fl(d . x) - d . x| <= 4 u S, S = sum_c |d_c| |x_c| <= |d|_1 |x|_inf,
 // u = 2^-24.  The MFMA returns M = d . x + slack + delta: the pieces are exact, and its f32 accumulation of 29 terms --
@@ -354,9 +354,7 @@ __global__ __launch_bounds__(RPL_BLOCK) void ray_sweep_rpl_kernel(
 // error stays below a hundredth of the slack.  Non-finite or astronomically large operands (> 1e15: their products
 // could overflow inside the pipe) never reach it: such a ray or triangle gets zero pieces and a slack that always
 // passes, and the exact test decides.
-constexpr int MF_RG = 8;                   // ray groups (16 rays) per wave
-constexpr int MF_WAVES = 4;                // waves per workgroup
-constexpr int MF_RAYS = 16 * MF_RG * MF_WAVES;   // 512 rays per workgroup
+constexpr int MF_WAVES = 4;                // waves per workgroup; a wave owns MF_RG groups of 16 rays (template parameter)
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 union Frag { bf8 v; unsigned short h[8]; uint4 q; };
@@ -472,6 +470,7 @@ __device__ __forceinline__ void mfma_exact(const float *__restrict__ rays6, cons
     if (mt_accept(m)) atomicMin(&keys[ray], mt_key(m, tri));
 }
 
+template <int MF_RG>
 __global__ __launch_bounds__(64 * MF_WAVES) void ray_sweep_mfma_kernel(
     const uint4 *__restrict__ rec, const float *__restrict__ aos, int tgroups_total, int tgroups_per_chunk, int n_chunks,
     const float *__restrict__ rays6, int64_t N, unsigned long long *__restrict__ keys, const int *__restrict__ shared_flag) {
@@ -2022,11 +2021,20 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         } else {                     // exhaustive on the matrix pipe: bf16 filter, exact test on the rare branch
             hipLaunchKernelGGL(mfma_rec_kernel, dim3((unsigned)((mesh->F_padded + 255) / 256)), dim3(256), 0, c->stream, mesh->tri,
                                mesh->F_padded, d_rays, flag, mf_rec);
-            const int tg_total = (int)(mesh->F_padded / 16), tgpc = (tg_total + n_chunks - 1) / n_chunks;
-            const int64_t mf_grid = ((N + MF_RAYS - 1) / MF_RAYS) * n_chunks;
+            const int tg_total = (int)(mesh->F_padded / 16);
+            int mf_chunks = n_chunks;   // (its own count: the general-origin kernel behind keeps n_chunks / gpc / grid)
+            if (c->ray_tri_chunks == 0 && mf_chunks < 32 && tg_total / 32 >= 64) mf_chunks = 32;   // (measured: 4.35 ms against 4.54 with 8)
+            const int tgpc = (tg_total + mf_chunks - 1) / mf_chunks;
+            static const int mf_rg = getenv("PEDP_MF_RG") ? atoi(getenv("PEDP_MF_RG")) : 8;   // (experiments: 8 or 16 ray groups per wave)
+            const int64_t mf_rays = 16 * (mf_rg == 16 ? 16 : 8) * MF_WAVES;
+            const int64_t mf_grid = ((N + mf_rays - 1) / mf_rays) * mf_chunks;
             PEDP_REQUIRE(mf_grid < (int64_t)0x7FFFFFFF, "pedp_raycast: grid too large");
-            hipLaunchKernelGGL(ray_sweep_mfma_kernel, dim3((unsigned)mf_grid), dim3(64 * MF_WAVES), 0, c->stream, (const uint4 *)mf_rec,
-                               mesh->tri, tg_total, tgpc, n_chunks, d_rays, N, keys, flag);
+            if (mf_rg == 16)
+                hipLaunchKernelGGL(ray_sweep_mfma_kernel<16>, dim3((unsigned)mf_grid), dim3(64 * MF_WAVES), 0, c->stream, (const uint4 *)mf_rec,
+                                   mesh->tri, tg_total, tgpc, mf_chunks, d_rays, N, keys, flag);
+            else
+                hipLaunchKernelGGL(ray_sweep_mfma_kernel<8>, dim3((unsigned)mf_grid), dim3(64 * MF_WAVES), 0, c->stream, (const uint4 *)mf_rec,
+                                   mesh->tri, tg_total, tgpc, mf_chunks, d_rays, N, keys, flag);
         }
         hipLaunchKernelGGL(ray_sweep_rpl_kernel<false>, dim3((unsigned)grid), dim3(RPL_BLOCK), 0, c->stream,
                            (const f2 *)mesh->tri2, mesh->tri, groups_total, gpc, n_chunks, d_rays, N, keys, flag);

@@ -62,8 +62,9 @@ if ROOT not in sys.path:
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector == f32-MFMA dense peak
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TEST = 46        # Moeller-Trumbore with stored (v0, e1, e2)
-FLOP_PER_TEST_EXECUTED = 19  # shared-origin form (round 3): three dot products (5 flop each), one slack fma, one min3 per triangle
-FLOP_PER_TEST_EXECUTED_R02 = 21  # round 2's loop: three dot products + two products, an add, a subtract and a min3
+FLOP_PER_TEST_MFMA = 192     # matrix-pipe filter (round 4): 3 x v_mfma_f32_16x16x32_bf16 (16 x 16 x 32 x 2 flop) per 256 tests
+FLOP_PER_TEST_EXECUTED_R03 = 19  # round 3's packed fp32 loop (variant 5): three dot products (5 flop each), one slack fma, one min3
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
 FLOP_PER_PAIR = 8         # one K=4 fp32 MFMA dot per (scene, model) pair
 ICP_ITERS = 20
 TIMED_PASS = -3           # headline: ONE HIP-event pair around all 21 launches of the pass kernel: span / 21
@@ -350,6 +351,17 @@ def run(args):
             _lib.raycast_configure(ray_ctx, 0, 0)
             _lib.icp_configure(ctx, exhaustive=False, timed_pass=TIMED_PASS)
         extras["exhaustive"] = (ex_steps, ex_elapsed, ex_res, ex_rows, ex_passes, ex_pairs)
+        if mode != "shard":   # round 3's packed fp32 loop on the same rays, for the side field
+            _lib.raycast_configure(ray_ctx, 0, 5)
+            try:
+                v5 = []
+                for _ in range(3):
+                    cast_full()
+                    ray_ctx.synchronize()
+                    v5.append(_lib.raycast_last_sweep_ms(ray_ctx))
+                extras["sweep_variant5_ms"] = float(np.median(v5))
+            finally:
+                _lib.raycast_configure(ray_ctx, 0, 0)
         # ---- replica region (N > 1): every rank its own whole frame, no collective
         if mode == "shard":
             rp_elapsed, _, rp_rows = timed_region(step_whole, args.steps, 1)
@@ -567,7 +579,7 @@ def run(args):
             tests = float(n_rays) * n_tris * share                      # this rank's ray block x all triangles
             pairs = float(n_scene) * n_model * share                    # this rank's scene shard x all model points
             nn_tflops = FLOP_PER_PAIR * pairs / (ex_sweep_ms * 1e-3) / 1e12
-            ray_exec = FLOP_PER_TEST_EXECUTED * tests / (ex_ray_ms * 1e-3) / 1e12
+            ray_exec = FLOP_PER_TEST_MFMA * tests / (ex_ray_ms * 1e-3) / 1e12
             ray_algo = FLOP_PER_TEST * tests / (ex_ray_ms * 1e-3) / 1e12
             stream_bytes = -(-int(n_rays * share) // 64) * n_tris * 36.0
             hbm_frac = stream_bytes / (ex_ray_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
@@ -589,22 +601,26 @@ def run(args):
                 "region_ms_per_step": ex_ms,
                 "note": f"{FLOP_PER_PAIR} flop x {int(n_scene * share)} scene x {n_model} model points per launch (SURVEY s8d)"}
             out["roofline_ray_sweep"] = {
-                "kernel": "ray_sweep_rpl_kernel<shared origin>", "region": "exhaustive", "bound": "valu_fp32",
-                "achieved": ray_exec, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ray_exec / PEAK_FP32_TFLOPS,
-                "traffic": traffic.get("ray_sweep_rpl_kernel", {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
+                "kernel": "ray_sweep_mfma_kernel<8> (every ray x every triangle: bf16 MFMA filter, exact test on the pairs that pass)",
+                "region": "exhaustive", "bound": "mfma",
+                "achieved": ray_exec, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ray_exec / PEAK_BF16_TFLOPS,
+                "traffic": traffic.get("ray_sweep_mfma_kernel", {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
+                "mfma_busy_pmc_committed_profile": traffic.get("ray_sweep_mfma_kernel", {}).get("mfma_busy"),
                 "kernel_ms": ex_ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ex_ray_ms,
                 "region_ms_per_step": ex_ms, "mrays_per_s": n_rays * share / (ex_ray_ms * 1e-3) / 1e6,
-                "algorithmic_46flop_tflops": ray_algo, "algorithmic_46flop_frac": ray_algo / PEAK_FP32_TFLOPS,
-                "r02_accounting_21flop_frac": FLOP_PER_TEST_EXECUTED_R02 * tests / (ex_ray_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                "algorithmic_46flop_tflops": ray_algo, "algorithmic_46flop_frac_of_fp32_vector_peak": ray_algo / PEAK_FP32_TFLOPS,
+                "packed_fp32_loop_ms": extras.get("sweep_variant5_ms"),
+                "packed_fp32_loop_frac_of_fp32_vector_peak": (None if not extras.get("sweep_variant5_ms") else
+                    FLOP_PER_TEST_EXECUTED_R03 * tests / (extras["sweep_variant5_ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS),
                 "north_star_hbm_stream_gbs": stream_bytes / (ex_ray_ms * 1e-3) / 1e9, "north_star_hbm_stream_frac": hbm_frac,
                 "north_star_hbm_target_met": bool(hbm_frac >= 0.5),
-                "note": f"frac counts the {FLOP_PER_TEST_EXECUTED} flop per test the shared-origin kernel EXECUTES (oriented per-triangle "
-                        "records a', b', c', kappa: three packed dot products, one slack fma, one min3; 29 VALU instructions per "
-                        "four tests, 35 in round 2 -- r02_accounting_21flop_frac prices the same time with round 2's 21 flop for "
-                        f"comparison); the {FLOP_PER_TEST}-flop algorithmic figure of "
-                        "SURVEY s8d is the side field.  north_star's >= 50 % of the HBM roofline (triangle-stream "
-                        "accounting, ceil(N_r/64) x N_f x 36 B per launch) is NOT met: the records are L2-resident and "
-                        "the kernel is FP32-VALU-bound (SURVEY s0 D5)"}
+                "note": f"frac counts the {FLOP_PER_TEST_MFMA} bf16 flop per test the filter EXECUTES on the matrix pipe (three "
+                        "v_mfma_f32_16x16x32_bf16 per 16 rays x 16 triangles: the three edge scores as K = 32 contractions over exact "
+                        "three-way bf16 splits and a slack slot) against the dense bf16 MFMA peak; the exact Moeller-Trumbore test runs "
+                        f"on the pairs that pass (1.001x the accepted pairs).  The {FLOP_PER_TEST}-flop algorithmic figure of SURVEY s8d "
+                        "against the fp32 vector peak and round 3's packed fp32 loop (variant 5, timed in the same region) are side "
+                        "fields.  north_star's >= 50 % of the HBM roofline reads in its triangle-stream accounting "
+                        "(ceil(N_r/64) x N_f x 36 B per launch over 8 TB/s): north_star_hbm_stream_frac"}
         rast = traffic.get("ray_stage_rast")
         ray_bytes = 24.0 * n_rays + 48.0 * n_tris + 8.0 * n_rays       # rays in, triangle records in, (t, id) out
         if mode != "shard":
