@@ -1523,6 +1523,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
                  margin = st->margin;
     constexpr int PARTS = 32, TPARTS = NT / 32, PPT = PARTS / TPARTS;  // ranges; ranges in flight; ranges per thread
     static_assert(NT % 32 == 0 && PARTS % TPARTS == 0, "thread count");
+    if (tid == 0) L.do_rebuild = 0;
     if (tid == 0) PEDP_STAMP(2, 0, 0);
     if (tid == 0 && pass == 5) PEDP_STAMP(2, 3, 0);
     // what the solving thread needs of the state is requested now, ahead of the sums
@@ -1637,8 +1638,19 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
             unsigned c = tid < 16 ? __hip_atomic_load((g_u32 *)(uintptr_t)(f.idle + 32 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
             for (int off = 8; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-            if (__shfl(c, 0, 64) - st->idle_base >= (unsigned)f.n_idle || spins > (1u << 22)) break;  // (bounded: a lost workgroup must not hang the device)
+            if (__shfl(c, 0, 64) - st->idle_base >= (unsigned)f.n_idle) break;
+            if (spins > (1u << 22)) {  // bounded: a lost workgroup must not hang the device -- but the pass is NOT closed over
+                if (tid == 0) L.do_rebuild = -1;   // workgroups that may still read the old state: the registration fails loudly
+                break;
+            }
             __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (COHERENT && f.n_idle > 0) {
+        __syncthreads();
+        if (L.do_rebuild == -1) {  // (workgroup-uniform)
+            if (tid == 0) st->done = -1;   // icp_collect / the batch driver turn this into PEDP_ERR_HIP
+            return;
         }
     }
     if (tid == 0) {
@@ -2992,6 +3004,10 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
         PEDP_HIP_CHECK(hipMemcpyAsync(trace, w.trace, sizeof(double) * 18 * (size_t)(job.max_iter + 1), hipMemcpyDeviceToHost, x->stream));
     PEDP_HIP_CHECK(hipStreamSynchronize(x->stream));
     const IcpState *hp = (const IcpState *)x->pinned;
+    if (hp->done < 0) {
+        pedp_set_error("pedp_icp: a pass could not be closed (workgroups of its launch did not sign off in time)");
+        return PEDP_ERR_HIP;
+    }
     for (int k = 0; k < 16; ++k) T_out[k] = hp->T[k];
     // (scene slot, target point) pairs the MFMAs evaluated: fused pass counts 16 x 16 wave-tiles, the segmented path units x 128 slots
     x->icp_last_cand = job.w.fused ? hp->sum_tiles * 256 : hp->sum_tiles * (16 * job.qt) * (NN_SB * 16);
@@ -3143,6 +3159,11 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
             for (int k = 0; k < n; ++k) finished = finished && down[k].done;
         }
         PEDP_REQUIRE(finished, "pedp_icp_batched: a registration did not finish");
+        for (int k = 0; k < n; ++k)
+            if (down[k].done < 0) {
+                pedp_set_error("pedp_icp_batched: a pass of registration %d could not be closed (workgroups of its launch did not sign off in time)", b0 + k);
+                return PEDP_ERR_HIP;
+            }
         for (int k = 0; k < n; ++k) {
             const IcpState &h = down[k];
             for (int q = 0; q < 16; ++q) T_out[16 * (b0 + k) + q] = h.T[q];
