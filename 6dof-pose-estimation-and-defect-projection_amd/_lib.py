@@ -59,6 +59,10 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_rayset_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _P(C.c_void_p)]),
+    "pedp_rayset_destroy": (None, [C.c_void_p]),
+    "pedp_raycast_rayset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pedp_rayset_last_variant": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
     "pedp_debug_mfma_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pedp_mesh_posed_vertices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pedp_project_heatmap_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
@@ -335,6 +339,23 @@ class Mesh:
             out["primitive_uvs"] = uv
         return out
 
+    def cast_rayset(self, rayset, want_uv=True):
+        """Closest hits of a resident ray set (RaySet): host arrays like cast_rays."""
+        n = rayset.N
+        t = np.empty(n, np.float32)
+        ids = np.empty(n, np.uint32)
+        uv = np.empty((n, 2), np.float32) if want_uv else None
+        check(load().pedp_raycast_rayset(self.ctx._h, self._h, rayset._h, HOST, _ptr(t), _ptr(ids), _ptr(uv)), "pedp_raycast_rayset")
+        out = {"t_hit": t, "primitive_ids": ids}
+        if want_uv:
+            out["primitive_uvs"] = uv
+        return out
+
+    def cast_rayset_device(self, rayset, t_ptr, id_ptr, uv_ptr=None):
+        """The same into device memory (torch tensors' data_ptr()); asynchronous on the stream."""
+        check(load().pedp_raycast_rayset(self.ctx._h, self._h, rayset._h, DEVICE, C.c_void_p(t_ptr), C.c_void_p(id_ptr),
+                                         C.c_void_p(uv_ptr) if uv_ptr else None), "pedp_raycast_rayset")
+
     def cast_rays_device(self, rays_ptr, n, t_ptr, id_ptr, uv_ptr=None):
         """Device-pointer variant (torch tensors' data_ptr()); asynchronous on the stream."""
         check(load().pedp_raycast(self.ctx._h, self._h, C.c_void_p(rays_ptr), int(n), DEVICE, C.c_void_p(t_ptr),
@@ -343,6 +364,38 @@ class Mesh:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             load().pedp_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RaySet:
+    """A camera's rays as a resident object (pedp_rayset_*): the N x 6 float32 rows are copied once and the grid of the
+    triangle-driven ray stage is built once; casts against it are the triangle kernels and the result kernel only."""
+
+    def __init__(self, ctx, rays6=None, device_ptr=None, n=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if device_ptr is not None:
+            self.N = int(n)
+            check(load().pedp_rayset_create(ctx._h, C.c_void_p(device_ptr), self.N, DEVICE, C.byref(self._h)), "pedp_rayset_create")
+        else:
+            r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
+            self.N = len(r)
+            check(load().pedp_rayset_create(ctx._h, _ptr(r), self.N, HOST, C.byref(self._h)), "pedp_rayset_create")
+
+    def last_variant(self):
+        v, st = C.c_int(), C.c_int()
+        check(load().pedp_rayset_last_variant(self._h, C.byref(v), C.byref(st)), "pedp_rayset_last_variant")
+        return v.value, st.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().pedp_rayset_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(256) void ray_finalize_kernel(const float *__restri
                                     int64_t N, unsigned long long *__restrict__ keys,
                                     float *__restrict__ t_hit, uint32_t *__restrict__ prim_id,
                                     float *__restrict__ uv, const RastHdr *__restrict__ rast, RastHdr *__restrict__ rast_next,
-                                    int *__restrict__ rast_status, const f2 *__restrict__ pairs, int groups_total) {
+                                    int *__restrict__ rast_status, const f2 *__restrict__ pairs, int groups_total, int reset_keys = 0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && rast) {  // variant 4: how the cast went, for the host's choice next time; the other header gets its start values
         rast_status[1] = (int)(N & 0x7FFFFFFF);
@@ -1613,6 +1613,7 @@ __global__ __launch_bounds__(256) void ray_finalize_kernel(const float *__restri
     }
     if (i >= N) return;
     unsigned long long key = keys[i];
+    if (reset_keys) keys[i] = KEY_MISS;   // a ray set's keys start the next cast clean (nothing else clears them)
     unsigned id = (unsigned)(key & 0xFFFFFFFFull);
     if (key == KEY_MISS) {
         t_hit[i] = __uint_as_float(0x7F800000u);
@@ -2069,6 +2070,177 @@ int pedp_raycast(pedp_ctx_t c, pedp_mesh_t mesh, const float *rays6, int64_t N, 
         if (uv) { int dn_ = pedp_download(c, uv, d_uv, sizeof(float) * 2 * (size_t)N); if (dn_) return dn_; }
         PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return PEDP_OK;
+}
+
+// ---------------------------------------------------------------- resident ray sets (include/pedp.h)
+}  // extern "C"
+struct pedp_rayset_s {
+    pedp_ctx_t ctx = nullptr;
+    int device = 0;
+    int64_t N = 0;
+    char *buf = nullptr;        // one allocation: rays, keys, two headers, partial bounds, heads, nodes, items, full list
+    float *rays = nullptr;
+    unsigned long long *keys = nullptr;
+    RastHdr *hdr[2] = {nullptr, nullptr};
+    unsigned *head = nullptr;
+    float4 *nodes = nullptr;
+    RastItem *items = nullptr;
+    unsigned *full_list = nullptr;
+    int *status = nullptr;      // pinned: [0] why the grid failed in the last cast (0: it did not), [1] ray count
+    unsigned seq = 0;           // casts enqueued: picks one of the two headers
+    bool grid_ok = false;       // the build found the rays servable; cleared for good by a cast that was not answered by the grid
+    int last_variant = 0, last_status = 0;
+};
+extern "C" {
+
+int pedp_rayset_create(pedp_ctx_t c, const float *rays6, int64_t N, int mem, pedp_rayset_t *out) {
+    PEDP_REQUIRE(c && out, "pedp_rayset_create: null context/output");
+    *out = nullptr;
+    PEDP_REQUIRE(N > 0 && N < (int64_t)0x7FFFFFF0, "pedp_rayset_create: N out of range");
+    PEDP_REQUIRE(rays6, "pedp_rayset_create: null rays");
+    PEDP_REQUIRE(mem == PEDP_HOST || mem == PEDP_DEVICE, "pedp_rayset_create: bad mem flag %d", mem);
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    pedp_rayset_s *r = new (std::nothrow) pedp_rayset_s();
+    if (!r) { pedp_set_error("pedp_rayset_create: out of host memory"); return PEDP_ERR_ALLOC; }
+    r->ctx = c; r->device = c->device; r->N = N;
+    const size_t sz_rays = align256(sizeof(float) * 6 * (size_t)N), sz_keys = align256(sizeof(unsigned long long) * (size_t)N);
+    const size_t sz_part = align256(sizeof(uint4) * RAST_BBLOCKS), sz_head = align256(sizeof(unsigned) * (size_t)N);
+    const size_t sz_nodes = align256(sizeof(float4) * (size_t)N), sz_items = align256(sizeof(RastItem) * (size_t)RAST_ITEM_CAP);
+    const size_t total = sz_rays + sz_keys + 512 + sz_part + sz_head + sz_nodes + sz_items + sizeof(unsigned) * RAST_FULL_CAP;
+    hipError_t e = hipMalloc((void **)&r->buf, total);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&r->status, 64, hipHostMallocMapped);
+    if (e != hipSuccess) { pedp_set_error("pedp_rayset_create: %s", hipGetErrorString(e)); pedp_rayset_destroy(r); return PEDP_ERR_ALLOC; }
+    r->status[0] = 0; r->status[1] = -1;
+    char *b = r->buf;
+    r->rays = (float *)b; b += sz_rays;
+    r->keys = (unsigned long long *)b; b += sz_keys;
+    r->hdr[0] = (RastHdr *)b; r->hdr[1] = (RastHdr *)(b + 256); b += 512;
+    uint4 *part = (uint4 *)b; b += sz_part;
+    r->head = (unsigned *)b; b += sz_head;
+    r->nodes = (float4 *)b; b += sz_nodes;
+    r->items = (RastItem *)b; b += sz_items;
+    r->full_list = (unsigned *)b;
+    int rc = PEDP_OK;
+    if (mem == PEDP_HOST) rc = pedp_upload(c, r->rays, rays6, sizeof(float) * 6 * (size_t)N);
+    else e = hipMemcpyAsync(r->rays, rays6, sizeof(float) * 6 * (size_t)N, hipMemcpyDeviceToDevice, c->stream);
+    RastHdr h0;
+    memset(&h0, 0, sizeof(h0));
+    h0.ok = 1;
+    if (rc == PEDP_OK && e == hipSuccess) e = hipMemcpyAsync(r->hdr[0], &h0, sizeof(h0), hipMemcpyHostToDevice, c->stream);
+    if (rc == PEDP_OK && e == hipSuccess) {
+        // the frame, the bounds and the chains: what pedp_raycast's variant 4 builds per call (the bounds kernel also sets
+        // every key to "miss" and every head to "none")
+        hipLaunchKernelGGL(rast_bounds_kernel, dim3(RAST_BBLOCKS), dim3(256), 0, c->stream, (const float *)r->rays, N, r->hdr[0], r->keys, r->head, part);
+        hipLaunchKernelGGL(rast_insert_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const float *)r->rays, N, r->hdr[0],
+                           r->head, r->nodes, (const uint4 *)part);
+        e = hipGetLastError();
+    }
+    RastHdr hb;
+    if (rc == PEDP_OK && e == hipSuccess) e = hipMemcpyAsync(&hb, r->hdr[0], sizeof(hb), hipMemcpyDeviceToHost, c->stream);
+    if (rc == PEDP_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (also: the caller's array and h0 are free again)
+    if (rc != PEDP_OK || e != hipSuccess) {
+        if (rc == PEDP_OK) pedp_set_error("pedp_rayset_create: %s", hipGetErrorString(e));
+        pedp_rayset_destroy(r);
+        return rc != PEDP_OK ? rc : PEDP_ERR_HIP;
+    }
+    r->grid_ok = hb.ok != 0;
+    r->last_status = hb.ok ? 0 : hb.reason;
+    if (r->grid_ok) {  // the second header: the same frame and grid, its counters at their start values
+        e = hipMemcpyAsync(r->hdr[1], r->hdr[0], sizeof(RastHdr), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) { pedp_set_error("pedp_rayset_create: %s", hipGetErrorString(e)); pedp_rayset_destroy(r); return PEDP_ERR_HIP; }
+    }
+    *out = r;
+    return PEDP_OK;
+}
+
+void pedp_rayset_destroy(pedp_rayset_t r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->buf) (void)hipFree(r->buf);
+    if (r->status) (void)hipHostFree(r->status);
+    delete r;
+}
+
+int pedp_raycast_rayset(pedp_ctx_t c, pedp_mesh_t mesh, pedp_rayset_t r, int mem, float *t_hit, uint32_t *prim_id, float *uv) {
+    PEDP_REQUIRE(c && mesh && r, "pedp_raycast_rayset: null argument");
+    PEDP_REQUIRE(mesh->ctx == c && r->ctx == c, "pedp_raycast_rayset: mesh or ray set belongs to another context");
+    PEDP_REQUIRE(mem == PEDP_HOST || mem == PEDP_DEVICE, "pedp_raycast_rayset: bad mem flag %d", mem);
+    PEDP_REQUIRE(t_hit && prim_id, "pedp_raycast_rayset: null arrays");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t N = r->N;
+    // a cast the grid did not answer (its last kernel completed it exhaustively, correctly but slowly): from now on the
+    // other variants, from the resident copy
+    if (r->grid_ok && ((volatile int *)r->status)[1] == (int)(N & 0x7FFFFFFF) && ((volatile int *)r->status)[0] != 0) {
+        r->grid_ok = false;
+        r->last_status = ((volatile int *)r->status)[0];
+    }
+    if (!r->grid_ok || mesh->F >= (int64_t)0x7FFFFFF0) {
+        const int keep = c->ray_variant;
+        if (c->ray_variant == 0 || c->ray_variant == 4) c->ray_variant = 3;   // (differing origins: variant 3 takes the general sweep on the device)
+        int rc = PEDP_OK;
+        if (mem == PEDP_DEVICE) rc = pedp_raycast(c, mesh, r->rays, N, PEDP_DEVICE, t_hit, prim_id, uv);
+        else {
+            int st = c->ray_out.reserve(sizeof(float) * 4 * (size_t)N);
+            if (st) { c->ray_variant = keep; return st; }
+            float *d_t = (float *)c->ray_out.ptr;
+            uint32_t *d_id = (uint32_t *)(d_t + N);
+            float *d_uv = uv ? (float *)(d_id + N) : nullptr;
+            rc = pedp_raycast(c, mesh, r->rays, N, PEDP_DEVICE, d_t, d_id, d_uv);
+            if (!rc) rc = pedp_download(c, t_hit, d_t, sizeof(float) * (size_t)N);
+            if (!rc) rc = pedp_download(c, prim_id, d_id, sizeof(uint32_t) * (size_t)N);
+            if (!rc && uv) rc = pedp_download(c, uv, d_uv, sizeof(float) * 2 * (size_t)N);
+            if (!rc) PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        r->last_variant = c->ray_last_variant;
+        c->ray_variant = keep;
+        return rc;
+    }
+    float *d_t = t_hit, *d_uv = uv;
+    uint32_t *d_id = prim_id;
+    if (mem == PEDP_HOST) {
+        int st = c->ray_out.reserve(sizeof(float) * 4 * (size_t)N);
+        if (st) return st;
+        d_t = (float *)c->ray_out.ptr;
+        d_id = (uint32_t *)(d_t + N);
+        d_uv = uv ? (float *)(d_id + N) : nullptr;
+    }
+    int *d_status = nullptr;
+    PEDP_HIP_CHECK(hipHostGetDevicePointer((void **)&d_status, r->status, 0));
+    RastHdr *h = r->hdr[r->seq & 1], *h_next = r->hdr[(r->seq + 1) & 1];
+    PEDP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    if (mesh->F > 0)
+        hipLaunchKernelGGL(rast_tri_kernel, dim3((unsigned)((mesh->F + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, mesh->F, h,
+                           (const unsigned *)r->head, (const float4 *)r->nodes, r->items, r->keys, r->full_list);
+    hipLaunchKernelGGL(rast_item_kernel, dim3(RAST_ITEM_WAVES / 4), dim3(256), 0, c->stream, mesh->tri, h, (const unsigned *)r->head,
+                       (const float4 *)r->nodes, (const RastItem *)r->items, r->keys);
+    hipLaunchKernelGGL(rast_full_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, (const float *)r->rays, N,
+                       (const RastHdr *)h, (const unsigned *)r->full_list, r->keys);
+    PEDP_HIP_CHECK(hipGetLastError());
+    PEDP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    c->ray_timed = true;
+    hipLaunchKernelGGL(ray_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, mesh->tri, (const float *)r->rays, N,
+                       r->keys, d_t, d_id, d_uv, (const RastHdr *)h, h_next, d_status, (const f2 *)mesh->tri2,
+                       (int)(mesh->F_padded / (2 * RPL_PAIRS)), 1);
+    PEDP_HIP_CHECK(hipGetLastError());
+    r->seq += 1;
+    r->last_variant = 4;
+    c->ray_last_variant = 4;
+    if (mem == PEDP_HOST) {
+        { int dn_ = pedp_download(c, t_hit, d_t, sizeof(float) * (size_t)N); if (dn_) return dn_; }
+        { int dn_ = pedp_download(c, prim_id, d_id, sizeof(uint32_t) * (size_t)N); if (dn_) return dn_; }
+        if (uv) { int dn_ = pedp_download(c, uv, d_uv, sizeof(float) * 2 * (size_t)N); if (dn_) return dn_; }
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return PEDP_OK;
+}
+
+int pedp_rayset_last_variant(pedp_rayset_t r, int *variant, int *grid_status) {
+    PEDP_REQUIRE(r && variant && grid_status, "pedp_rayset_last_variant: null argument");
+    PEDP_HIP_CHECK(hipSetDevice(r->device));
+    PEDP_HIP_CHECK(hipStreamSynchronize(r->ctx->stream));
+    *variant = r->last_variant;
+    *grid_status = r->last_variant == 4 ? ((volatile int *)r->status)[0] : r->last_status;
     return PEDP_OK;
 }
 

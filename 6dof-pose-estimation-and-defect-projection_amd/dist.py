@@ -333,6 +333,11 @@ class ShardedFrame:
             self.rays = torch.from_numpy(block).to(dev)
             self.rec = torch.empty((2, self.width), dtype=torch.int32, device=dev)
             self.gathered = torch.empty((self.world, 2, self.width), dtype=torch.int32, device=dev)
+        # the rank's ray block as a resident ray set (the product backend: grid chains built once, four launches per cast)
+        self.rayset = None
+        if hasattr(backend, "ctx") and self.hi > self.lo:
+            with backend.ordered():
+                self.rayset = _lib.RaySet(backend.ctx, device_ptr=self.rays.data_ptr(), n=self.hi - self.lo)
         self.n_scene = 0
         if scene is not None:
             self.n_scene = len(scene)
@@ -343,7 +348,9 @@ class ShardedFrame:
     def cast(self, gather=True):
         """Enqueue the sweep of this rank's block and the all-gather of the records."""
         n = self.hi - self.lo
-        if n > 0:
+        if n > 0 and self.rayset is not None:
+            self.mesh.cast_rayset_device(self.rayset, self.rec[0].data_ptr(), self.rec[1].data_ptr())
+        elif n > 0:
             self.mesh.cast_rays_device(self.rays.data_ptr(), n, self.rec[0].data_ptr(), self.rec[1].data_ptr())
         if gather and self.world > 1:
             self.be.all_gather_device(self.rec, self.gathered, self.group)

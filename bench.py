@@ -211,8 +211,16 @@ def run(args):
     t_hit = torch.empty(n_rays, dtype=torch.float32, device=dev)
     prim = torch.empty(n_rays, dtype=torch.int32, device=dev)
 
+    # the camera's rays are a resident ray set (pedp_rayset_*): the grid of the triangle-driven ray stage is built once,
+    # a cast is the triangle kernels and the result kernel.  PEDP_BENCH_PLAIN_CAST=1: pedp_raycast on the ray array per call
+    rayset = None if os.environ.get("PEDP_BENCH_PLAIN_CAST") == "1" else _lib.RaySet(ray_ctx, device_ptr=rays.data_ptr(), n=n_rays)
+    plain_cast = [False]
+
     def cast_full():
-        mesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
+        if rayset is not None and not plain_cast[0]:
+            mesh.cast_rayset_device(rayset, t_hit.data_ptr(), prim.data_ptr())
+        else:
+            mesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
 
     cast_full()
     ray_ctx.synchronize()
@@ -296,7 +304,8 @@ def run(args):
     elapsed, res, rows = timed_region(step, args.steps, args.warmup)
     passes, pairs_swept, fb_points = _lib.icp_last_stats(ctx)
     ms_per_step = 1e3 * elapsed / args.steps
-    ray_variant, grid_status = _lib.raycast_last_variant(ray_ctx)   # which ray stage answered the timed casts
+    # which ray stage answered the timed casts
+    ray_variant, grid_status = rayset.last_variant() if (rayset is not None and mode != "shard") else _lib.raycast_last_variant(ray_ctx)
 
     extras = {}
     # ---- N > 1, shard mode: the headline workload is BASELINE config 4 -- the 1280x720 dense frame against the 1M-triangle
@@ -342,6 +351,7 @@ def run(args):
     if not args.no_extras:
         # ---- exhaustive region: the all-pairs path, same resident inputs, same sharding
         ex_steps = max(2, min(args.steps, 4))
+        plain_cast[0] = True                      # (the exhaustive variants are pedp_raycast's)
         _lib.raycast_configure(ray_ctx, 0, 1)
         _lib.icp_configure(ctx, exhaustive=True, timed_pass=TIMED_PASS_EX)
         try:
@@ -362,6 +372,14 @@ def run(args):
                 extras["sweep_variant5_ms"] = float(np.median(v5))
             finally:
                 _lib.raycast_configure(ray_ctx, 0, 0)
+        if mode != "shard":   # the per-call form of the headline's ray stage (pedp_raycast: rays read twice, chains rebuilt), for the side field
+            pc = []
+            for _ in range(5):
+                cast_full()
+                ray_ctx.synchronize()
+                pc.append(_lib.raycast_last_sweep_ms(ray_ctx))
+            extras["plain_cast_ms"] = float(np.median(pc[1:]))
+        plain_cast[0] = False
         # ---- replica region (N > 1): every rank its own whole frame, no collective
         if mode == "shard":
             rp_elapsed, _, rp_rows = timed_region(step_whole, args.steps, 1)
@@ -391,7 +409,10 @@ def run(args):
                 pts = base_dev + noise_dev[k % 4]                 # the frame's new points (torch's stream) ...
                 torch.cuda.current_stream().synchronize()         # ... are complete before the library reads them
                 pmesh.set_pose(poses[k % 4])                      # records rebuilt on the device (ray stream)
-                pmesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
+                if rayset is not None:
+                    pmesh.cast_rayset_device(rayset, t_hit.data_ptr(), prim.data_ptr())
+                else:
+                    pmesh.cast_rays_device(rays.data_ptr(), n_rays, t_hit.data_ptr(), prim.data_ptr())
                 b = time.perf_counter()
                 s_k = _lib.Cloud.from_device(ctx, pts.data_ptr(), len(pts))   # copy, box, then (inside pedp_icp) order + spheres
                 r_k = _lib.icp(ctx, s_k, tgt, radius, init, **icp_kw)
@@ -552,6 +573,9 @@ def run(args):
             "pose_error_vs_gt": float(np.abs(np.linalg.inv(res["T"]) - frame.T_gt).max()),
             # dominant kernel of the HEADLINE step as it runs there (rank 0's share in shard mode)
             "ray_variant": ray_variant, "ray_grid_status": grid_status,
+            "ray_stage_form": "resident ray set (pedp_raycast_rayset: grid chains built once; 4 launches per cast)" if rayset is not None
+                              else "pedp_raycast per call (rays read twice, chains rebuilt; 6 launches)",
+            "ray_stage_ms_per_call_form": extras.get("plain_cast_ms"),
             "roofline": {"kernel": "icp_pass_kernel (one launch per pass: per-chunk transform, culling, MFMA sweep, selection, partial "
                                    "sums; the last workgroup sums, solves and updates the pose)", "region": "headline", "bound": "mfma",
                          "achieved": sweep_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

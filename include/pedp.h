@@ -42,6 +42,7 @@ enum { PEDP_POINT_TO_PLANE = 0, PEDP_POINT_TO_POINT = 1 };
 
 typedef struct pedp_ctx_s *pedp_ctx_t;
 typedef struct pedp_mesh_s *pedp_mesh_t;
+typedef struct pedp_rayset_s *pedp_rayset_t;
 typedef struct pedp_cloud_s *pedp_cloud_t;
 
 int pedp_version(void);
@@ -88,6 +89,21 @@ int pedp_raycast(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N
  *   5 every ray against every triangle on the vector pipe (ray per lane, packed fp32; round 3's exhaustive kernel)
  * All variants return identical bits. */
 int pedp_raycast_configure(pedp_ctx_t ctx, int tri_chunks, int variant);
+/* A camera's rays as a resident object.  A camera sends the same rays every frame (the reference generates them from the
+ * pixel grid in the camera's frame and moves the MESH, src/defect_projection.py:196-223, :549-550): a ray set copies
+ * the N x 6 float32 [origin | direction] rows once and builds, once, what the triangle-driven ray stage (variant 4)
+ * derives from the rays alone -- the frame, the grid over the mapped directions, the cells' chains.  A cast against a
+ * ray set is then the triangle kernels and the result kernel only: four launches, the rays never re-read
+ * (pedp_raycast reads them twice and rebuilds the chains per call).  Results are those of pedp_raycast, bit for bit;
+ * rays the grid cannot serve (origins that differ, directions outside the frame's half space, crowded cells) are cast
+ * by pedp_raycast's other variants from the resident copy.  mem: where rays6 / the outputs live. */
+int pedp_rayset_create(pedp_ctx_t ctx, const float *rays6, int64_t N, int mem, pedp_rayset_t *out);
+void pedp_rayset_destroy(pedp_rayset_t rays);
+int pedp_raycast_rayset(pedp_ctx_t ctx, pedp_mesh_t mesh, pedp_rayset_t rays, int mem, float *t_hit, uint32_t *prim_id, float *uv);
+/* how the last cast against the set was answered: *variant 4 (the grid) with *grid_status 0, or the variant
+ * pedp_raycast fell back to with the reason the grid gave (bits as in pedp_raycast_last_variant) */
+int pedp_rayset_last_variant(pedp_rayset_t rays, int *variant, int *grid_status);
+
 /* Diagnostics of variant 1's matrix-pipe filter (tests): for N host rays of ONE origin, the filter's score of every (ray,
  * triangle) pair -- >= 0: the pair goes to the exact test -- and the slack inside that score; N x F float32 each, host. */
 int pedp_debug_mfma_scores(pedp_ctx_t ctx, pedp_mesh_t mesh, const float *rays6, int64_t N, float *score, float *slack);

@@ -586,3 +586,56 @@ def test_grid_margin_degenerate_records_cost_nothing(ctx, oracle):
     assert status == 0 and (tri[len(f.tris):, 0] == 0).all()
     got = _grid_cast(ctx, mesh, f.rays6, 0)
     _same(got, oracle.raycast(v, tris, f.rays6, bvh=True))
+
+
+def test_resident_ray_set_equals_the_per_call_cast(ctx, oracle):
+    """pedp_rayset_*: a camera's rays resident, the grid's chains built once -- every cast against the set returns the
+    oracle's bits, cast after cast (the keys are re-armed by the result kernel), against different meshes and poses,
+    with and without uv, into host and device memory; rays the grid cannot serve are cast by the other variants."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import _lib, synth
+
+    f = synth.Frame("parity")
+    rs = _lib.RaySet(ctx, f.rays6)
+    mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+    ref = oracle.raycast(f.verts_posed, f.tris, f.rays6, bvh=True)
+    for rep in range(3):
+        got = mesh.cast_rayset(rs, want_uv=(rep != 1))
+        assert rs.last_variant() == (4, 0)
+        assert np.array_equal(got["primitive_ids"], ref["primitive_ids"]) and np.array_equal(got["t_hit"].view(np.uint32), ref["t_hit"].view(np.uint32))
+        if rep != 1:
+            assert np.array_equal(got["primitive_uvs"].view(np.uint32), ref["primitive_uvs"].view(np.uint32))
+    # another mesh (moved: other hits, other misses), then the first one again
+    moved = (f.verts_posed + np.array([12.0, -7.0, 25.0], np.float32)).astype(np.float32)
+    mesh2 = _lib.Mesh(ctx, moved, f.tris)
+    ref2 = oracle.raycast(moved, f.tris, f.rays6, bvh=True)
+    got2 = mesh2.cast_rayset(rs)
+    assert np.array_equal(got2["primitive_ids"], ref2["primitive_ids"]) and np.array_equal(got2["t_hit"].view(np.uint32), ref2["t_hit"].view(np.uint32))
+    got = mesh.cast_rayset(rs)
+    assert np.array_equal(got["primitive_ids"], ref["primitive_ids"]) and (got2["primitive_ids"] != got["primitive_ids"]).any()
+    # device in, device out
+    d_rays = torch.from_numpy(f.rays6).cuda()
+    rs_dev = _lib.RaySet(ctx, device_ptr=d_rays.data_ptr(), n=len(f.rays6))
+    del d_rays                                               # (the set owns its copy)
+    t = torch.empty(len(f.rays6), dtype=torch.float32, device="cuda")
+    ids = torch.empty(len(f.rays6), dtype=torch.int32, device="cuda")
+    mesh.cast_rayset_device(rs_dev, t.data_ptr(), ids.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), ref["t_hit"].view(np.uint32)) and np.array_equal(ids.cpu().numpy().view(np.uint32), ref["primitive_ids"])
+    # rays the grid cannot serve: origins that differ -- still the oracle's bits, by another variant
+    mixed = f.rays6.copy()
+    mixed[::3, :3] += np.array([5.0, -3.0, 2.0], np.float32)
+    rs_mixed = _lib.RaySet(ctx, mixed)
+    refm = oracle.raycast(f.verts_posed, f.tris, mixed, bvh=True)
+    gotm = mesh.cast_rayset(rs_mixed)
+    assert rs_mixed.last_variant()[0] != 4
+    assert np.array_equal(gotm["primitive_ids"], refm["primitive_ids"]) and np.array_equal(gotm["t_hit"].view(np.uint32), refm["t_hit"].view(np.uint32))
+    # a posable mesh under changing poses, the set unchanged
+    pm = _lib.Mesh(ctx, f.model_points, f.tris, posable=True)
+    for k in range(3):
+        T = f.T_gt.copy()
+        T[:3, 3] += (3.0 * k, -2.0 * k, 5.0 * k)
+        pm.set_pose(T)
+        refp = oracle.raycast(oracle.pose_vertices(T, f.model_points), f.tris, f.rays6, bvh=True)
+        gotp = pm.cast_rayset(rs, want_uv=False)
+        assert np.array_equal(gotp["primitive_ids"], refp["primitive_ids"]) and np.array_equal(gotp["t_hit"].view(np.uint32), refp["t_hit"].view(np.uint32))

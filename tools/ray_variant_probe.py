@@ -25,3 +25,14 @@ for config in sys.argv[1:] or ["bench_100k", "bench_1m"]:
         print(config, "variant", variant, "last", _lib.raycast_last_variant(ctx), f"{dt * 1e3:.3f} ms per cast, sweep stage",
               f"{_lib.raycast_last_sweep_ms(ctx):.3f} ms, hits {int(torch.isfinite(t).sum())}", flush=True)
     _lib.raycast_configure(ctx, 0, 0)
+    rs = _lib.RaySet(ctx, device_ptr=rays.data_ptr(), n=f.n_rays)          # the rays resident: chains built once
+    for rep in range(3):
+        m.cast_rayset_device(rs, t.data_ptr(), ids.data_ptr())
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(20):
+        m.cast_rayset_device(rs, t.data_ptr(), ids.data_ptr())
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    print(config, "resident ray set, last", rs.last_variant(), f"{dt * 1e3:.3f} ms per cast, sweep stage",
+          f"{_lib.raycast_last_sweep_ms(ctx):.3f} ms, hits {int(torch.isfinite(t).sum())}", flush=True)
