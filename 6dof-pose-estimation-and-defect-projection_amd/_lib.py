@@ -59,6 +59,8 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
+    "pedp_host_free": (None, [C.c_void_p]),
     "pedp_rayset_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _P(C.c_void_p)]),
     "pedp_rayset_destroy": (None, [C.c_void_p]),
     "pedp_raycast_rayset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -168,6 +170,53 @@ def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
 
 
+class _Lease:
+    """A page-locked block on loan from the pool: numpy arrays over it keep it alive through `.base`; when the last of them
+    is gone the block goes back to the pool."""
+
+    def __init__(self, ptr, cap):
+        self.ptr, self.cap = ptr, cap
+        self.__array_interface__ = {"shape": (cap,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _host_pool_give(self.ptr, self.cap)
+        except Exception:
+            pass
+
+
+_HOST_POOL = {}        # capacity (a power of two) -> page-locked blocks at rest
+_HOST_POOL_KEEP = 6    # blocks kept per capacity; the rest are freed
+
+
+def _host_pool_give(ptr, cap):
+    lst = _HOST_POOL.setdefault(cap, [])
+    if len(lst) < _HOST_POOL_KEEP:
+        lst.append(ptr)
+    else:
+        load().pedp_host_free(C.c_void_p(ptr))
+
+
+def host_array(shape, dtype):
+    """A result array in page-locked memory from a pool (pedp_host_alloc): downloads reach it without a staging copy, and
+    its pages do not fault in anew every frame the way a fresh np.empty's do.  An ordinary (writeable) numpy array to its
+    holder; the block returns to the pool when the array and every view of it are gone."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    if n < (64 << 10):                       # small results: the allocator's own free lists serve these without faults
+        return np.empty(shape, dtype)
+    cap = 1 << (n - 1).bit_length()
+    lst = _HOST_POOL.get(cap)
+    if lst:
+        ptr = lst.pop()
+    else:
+        p = C.c_void_p()
+        check(load().pedp_host_alloc(cap, C.byref(p)), "pedp_host_alloc")
+        ptr = p.value
+    raw = np.asarray(_Lease(ptr, cap))
+    return raw[:n].view(dtype).reshape(shape)
+
+
 def device_count():
     n = C.c_int(0)
     check(load().pedp_device_count(C.byref(n)), "pedp_device_count")
@@ -260,7 +309,7 @@ class Mesh:
         if not self.posable:
             raise PedpError("posed_vertices needs a posable mesh")
         M = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
-        out = np.empty((self.V, 3), np.float64)
+        out = host_array((self.V, 3), np.float64)
         check(load().pedp_mesh_posed_vertices(self._h, _ptr(M), HOST, _ptr(out)), "pedp_mesh_posed_vertices")
         return out
 
@@ -294,14 +343,14 @@ class Mesh:
         cap = self._hit_cap if self._hit_cap > 0 else max(shape[0] * shape[1], 1)   # room for the hits: every pixel the first
         # time, then the last call's count and a margin, grown on demand
         while True:
-            pts = np.empty((cap, 3), np.float64)
-            inten = np.empty(cap, np.float64)
-            pix = np.empty((cap, 2), np.int32)
-            prim = np.empty(cap, np.uint32)
+            pts = host_array((cap, 3), np.float64)
+            inten = host_array((cap,), np.float64)
+            pix = host_array((cap, 2), np.int32)
+            prim = host_array((cap,), np.uint32)
             cols = None
             if jet_lut is not None:
                 lut = np.ascontiguousarray(jet_lut, dtype=np.float64).reshape(256, 3)
-                cols = np.empty((cap, 3), np.float64)
+                cols = host_array((cap, 3), np.float64)
                 opts.jet_lut, opts.colors = lut.ctypes.data, cols.ctypes.data
                 keep.append(lut)
             if post is not None:

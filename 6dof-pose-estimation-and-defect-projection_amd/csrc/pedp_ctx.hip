@@ -152,6 +152,16 @@ int pedp_download_parts(pedp_ctx_s *c, const void *src, size_t span, int n, cons
             if (dst[i]) { int rc = pedp_download(c, dst[i], (const char *)src + off[i], bytes[i]); if (rc) return rc; }
         return PEDP_OK;
     }
+    bool all_pinned = true;   // page-locked destinations (pedp_host_alloc, a pinned torch tensor): straight there, one wait
+    for (int i = 0; i < n && all_pinned; ++i)
+        if (dst[i] && bytes[i] && !host_is_pinned(dst[i])) all_pinned = false;
+    if (all_pinned) {
+        for (int i = 0; i < n; ++i)
+            if (dst[i] && bytes[i]) PEDP_HIP_CHECK(hipMemcpyAsync(dst[i], (const char *)src + off[i], bytes[i], hipMemcpyDeviceToHost, c->stream));
+        PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->stage_busy = false;
+        return PEDP_OK;
+    }
     int rc = stage_reserve(c, 1, span);
     if (rc) return rc;
     PEDP_HIP_CHECK(hipMemcpyAsync(c->stage[1], src, span, hipMemcpyDeviceToHost, c->stream));
@@ -269,6 +279,17 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int pedp_host_alloc(size_t bytes, void **out) {
+    PEDP_REQUIRE(out, "pedp_host_alloc: null output");
+    *out = nullptr;
+    PEDP_HIP_CHECK(hipHostMalloc(out, bytes > 0 ? bytes : 1, hipHostMallocDefault));
+    return PEDP_OK;
+}
+
+void pedp_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int pedp_ctx_synchronize(pedp_ctx_t c) {

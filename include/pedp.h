@@ -461,6 +461,14 @@ int pedp_comm_allreduce_f64(pedp_ctx_t ctx, double *buf, int64_t n);
 int pedp_cluster_poses(float angle_diff_deg, float dist_diff, const float *poses, int n,
                        const float *syms, int s, int32_t *keep_idx, int *n_keep);
 
+/* ---------------------------------------------------------------- page-locked host memory
+ * Result arrays a caller allocates anew for every frame are paid for twice: the pages of a fresh allocation fault in one
+ * by one while the result is copied into them (0.15 ms per megabyte measured inside the frame chain), and a pageable
+ * destination goes through the library's staging buffer.  pedp_host_alloc hands out page-locked memory (hipHostMalloc)
+ * that downloads reach directly; pedp_hip keeps a pool of such blocks under its result arrays (_lib.host_array). */
+int pedp_host_alloc(size_t bytes, void **out);
+void pedp_host_free(void *p);
+
 /* ---------------------------------------------------------------- rigid transform of host arrays
  * What o3d.geometry.PointCloud.transform / TriangleMesh.transform do to the holders' float64 arrays on the path
  * (src/pose_estimation.py:406-409 transform_object, :815-816; run.py:118, :197, :200): out_i = R in_i + t with
