@@ -645,11 +645,12 @@ def run(args):
                         "against the fp32 vector peak and round 3's packed fp32 loop (variant 5, timed in the same region) are side "
                         "fields.  north_star's >= 50 % of the HBM roofline reads in its triangle-stream accounting "
                         "(ceil(N_r/64) x N_f x 36 B per launch over 8 TB/s): north_star_hbm_stream_frac"}
-        rast = traffic.get("ray_stage_rast")
+        rast = traffic.get("ray_stage_rayset" if rayset is not None else "ray_stage_rast")
         ray_bytes = 24.0 * n_rays + 48.0 * n_tris + 8.0 * n_rays       # rays in, triangle records in, (t, id) out
         if mode != "shard":
             out["roofline_ray_stage"] = {
-                "kernel": "triangle-driven ray stage (rast_bounds / rast_insert / rast_tri / rast_item / ray_finalize)" if ray_variant == 4
+                "kernel": ("triangle-driven ray stage against the resident ray set (rast_tri / rast_item / rast_full / ray_finalize)" if rayset is not None
+                           else "triangle-driven ray stage (rast_bounds / rast_insert / rast_tri / rast_item / rast_full / ray_finalize)") if ray_variant == 4
                           else f"ray stage, variant {ray_variant}", "region": "headline", "bound": "hbm",
                 "achieved": ray_bytes / (ray_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ray_bytes / (ray_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
@@ -657,7 +658,8 @@ def run(args):
                 "kernel_ms": ray_ms, "launches_per_step": 1, "kernel_ms_x_launches": ray_ms, "region_ms_per_step": ms_per_step,
                 "pmc": rast,
                 "note": "algorithmic bytes of one cast = 24 B per ray in + 48 B per triangle record in + 8 B per ray out "
-                        f"= {ray_bytes / 1e6:.1f} MB, over the HIP-event span of the cast's kernels.  Five short launches: the "
+                        f"= {ray_bytes / 1e6:.1f} MB (the per-call accounting, kept for comparison: against a resident ray set the rays are "
+                        "not read at all), over the HIP-event span of the cast's kernels.  A few short launches: the "
                         "stage is bound by launch boundaries and by the chains of dependent accesses inside them (cell "
                         "heads -> nodes -> atomicMin keys), not by HBM; see DESIGN s4.1 for the PMC reading"}
         if "fresh_frame" in extras:

@@ -7,7 +7,7 @@ as measured (width uncalibrated) and flagged.  WRITE_SIZE is taken as is."""
 import collections, csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def load(name):
@@ -21,6 +21,7 @@ def load(name):
 
 
 f, w, sq = load(f"{RND}_pmc_fetch_size.csv"), load(f"{RND}_pmc_write_size.csv"), load(f"{RND}_pmc_sq.csv")
+sq2 = load(f"{RND}_pmc_sq2.csv")
 
 
 def pick(d, key, counter):
@@ -35,6 +36,7 @@ KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector 
     ("nn_sweep_kernel<1", "nn_sweep_kernel_culled", True),
     ("icp_pass_kernel", "icp_pass_kernel", True),
     ("icp_finish_kernel", "icp_finish_kernel", True),
+    ("ray_sweep_mfma_kernel", "ray_sweep_mfma_kernel", True),
     ("ray_sweep_rpl_kernel<true>", "ray_sweep_rpl_kernel", False),
     ("ray_sweep_seg_kernel", "ray_sweep_seg_kernel", False),
     ("ray_cull_mask_kernel", "ray_cull_mask_kernel", True),
@@ -69,6 +71,13 @@ for key, name, stream in KERNELS:
         # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
         rec["mfma_util"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         rec["mfma_flop"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
+        rec["mfma_busy"] = rec["mfma_util"]
+    for c in ("SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_MFMA", "SQ_WAIT_INST_ANY", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
+        v = pick(sq2, key, c)
+        if v is not None:
+            rec[c] = v
+    if rec.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+        rec["mfma_flop_bf16"] = rec["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0
     out[name] = rec
 # the triangle-driven ray stage as a whole: its kernels of one cast summed (ray_finalize_kernel is shared with the other
 # variants: its mean over all casts is taken)
@@ -85,5 +94,13 @@ if parts:
     agg["per_kernel_wait_share"] = {k: out[k]["SQ_WAIT_ANY"] / out[k]["SQ_WAVE_CYCLES"] for k in out
                                     if k.startswith("rast_") and out[k].get("SQ_WAVE_CYCLES")}
     out["ray_stage_rast"] = agg
+# the same stage against a resident ray set: only the triangle kernels and the result kernel run per cast
+parts = [out[k] for k in ("rast_tri_kernel", "rast_item_kernel", "rast_full_kernel", "ray_finalize_kernel") if k in out]
+if parts:
+    out["ray_stage_rayset"] = {"hbm_bytes_per_cast": sum(p["hbm_bytes_per_launch"] for p in parts),
+                               "fetch_bytes_corrected": sum(p["fetch_bytes_corrected"] for p in parts),
+                               "write_bytes": sum(p["write_bytes"] for p in parts), "launches_per_cast": 4,
+                               "note": "rast_tri + rast_item + rast_full + ray_finalize (the per-launch means of the PMC passes, which "
+                                       "hold per-call and ray-set casts of the same frame: the same work in these four kernels)"}
 json.dump(out, open(os.path.join(P, f"{RND}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
