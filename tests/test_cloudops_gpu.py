@@ -392,6 +392,19 @@ def test_preprocess_source_in_one_call_equals_the_steps(ctx, oracle):
     assert status == 0 and rep["inliers"] == len(inl_ref) and np.abs(rep["plane_model"] - plane_ref).max() < 1e-12
     _, coarse = oracle.voxel_down_sample(down, 10, oracle.estimate_normals(down, 2.0, 5))
     assert np.abs(rep["mean_normal"] - coarse.mean(axis=0)).max() < 1e-9
+    # the average normal's other ways: a far outlier makes the input's box too large for dense cells (the sort-based grid
+    # answers), a clump of more than 512 down-sampled points in one 10-unit voxel overflows a cell's list (likewise)
+    far = np.vstack([scene, [[4.0e4, -3.0e4, 9.0e4]]])
+    _, _, _, st_far, rep_far = cloud_ops.preprocess_source_fused(far, 4, 2.0, 200, first_frame=True, ctx=ctx, report=True)
+    down_far, _ = oracle.voxel_down_sample(far, 4)
+    _, coarse_far = oracle.voxel_down_sample(down_far, 10, oracle.estimate_normals(down_far, 2.0, 5))
+    assert st_far == 0 and np.abs(rep_far["mean_normal"] - coarse_far.mean(axis=0)).max() < 1e-9
+    clump = np.vstack([scene, np.random.default_rng(3).uniform([20, 20, 300], [29, 29, 309], (4000, 3))])
+    _, _, _, st_c, rep_c = cloud_ops.preprocess_source_fused(clump, 0.5, 2.0, 200, first_frame=True, ctx=ctx, report=True)
+    down_c, _ = oracle.voxel_down_sample(clump, 0.5)
+    _, coarse_c = oracle.voxel_down_sample(down_c, 10, oracle.estimate_normals(down_c, 2.0, 5))
+    assert st_c == 0 and np.abs(rep_c["mean_normal"] - coarse_c.mean(axis=0)).max() < 1e-9
+    assert np.unique(np.floor((down_c - (down_c.min(0) - 5.0)) / 10.0), axis=0, return_counts=True)[1].max() > 512
     # the counters of the stages, and the statuses
     voxel = 4 if True else 0
     p, n, counts, status = cloud_ops.preprocess_source_fused(scene, voxel, 2.0, 200, first_frame=True, ctx=ctx)
