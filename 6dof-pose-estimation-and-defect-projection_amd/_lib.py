@@ -59,6 +59,8 @@ PROTOTYPES = {
     "pedp_project_heatmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64),
                                        _P(C.c_int64)]),
+    "pedp_depth_to_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      _P(C.c_int64)]),
     "pedp_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     "pedp_host_free": (None, [C.c_void_p]),
     "pedp_rayset_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _P(C.c_void_p)]),
@@ -266,6 +268,13 @@ def default_context(device=0):
 class Pinhole(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class DepthEntryParams(C.Structure):
+    """pedp_depth_entry_params (include/pedp.h)."""
+    _fields_ = [("erode_radius", C.c_int32), ("erode_diff", C.c_float), ("erode_ratio", C.c_float), ("erode_zfar", C.c_float),
+                ("bilateral_radius", C.c_int32), ("bilateral_zfar", C.c_float), ("sigmaD", C.c_float), ("sigmaR", C.c_float),
+                ("K", C.c_float * 9), ("xyz_zfar", C.c_float), ("z_min", C.c_float), ("scale", C.c_double)]
 
 
 class ProjectOpts(C.Structure):

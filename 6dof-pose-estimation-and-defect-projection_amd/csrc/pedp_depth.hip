@@ -469,6 +469,70 @@ __global__ __launch_bounds__(256) void xyzmap_batch_kernel(const float *__restri
     o[0] = X; o[1] = Y; o[2] = Z;
 }
 
+// ---- the valid points of a back-projected image, in row-major order, as float64 scaled (metres -> millimetres): what
+// run.py's loop hands to preprocess_source.  Count per 2,048-pixel block, one single-workgroup scan of the block totals,
+// scatter with the block-local scan redone in LDS (the pattern of pedp_project.hip's compactions).
+constexpr int SC_THREADS = 256, SC_PER = 8, SC_BLOCK = SC_THREADS * SC_PER;
+__device__ __forceinline__ int sc_block_scan(int v, int *lds, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + inc - v;
+}
+__global__ __launch_bounds__(SC_THREADS) void scene_count_kernel(const float *__restrict__ xyz, int64_t n, float z_min, int *__restrict__ block_tot) {
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SC_BLOCK + (int64_t)threadIdx.x * SC_PER;
+    int cnt = 0;
+    for (int k = 0; k < SC_PER; ++k)
+        if (base + k < n && xyz[3 * (base + k) + 2] >= z_min) ++cnt;
+    int total;
+    (void)sc_block_scan(cnt, lds, &total);
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void scene_scan_kernel(int *__restrict__ block_tot, int n_blocks, int *__restrict__ out_total) {
+    __shared__ int part[1024];
+    const int per = (n_blocks + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n_blocks);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_tot[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        *out_total = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = block_tot[i]; block_tot[i] = run; run += v; }
+}
+__global__ __launch_bounds__(SC_THREADS) void scene_scatter_kernel(const float *__restrict__ xyz, int64_t n, float z_min, double scale,
+                                                                   const int *__restrict__ block_off, double *__restrict__ pts) {
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SC_BLOCK + (int64_t)threadIdx.x * SC_PER;
+    unsigned flags = 0;
+    for (int k = 0; k < SC_PER; ++k)
+        if (base + k < n && xyz[3 * (base + k) + 2] >= z_min) flags |= 1u << k;
+    int64_t pos = block_off[blockIdx.x] + sc_block_scan(__popc(flags), lds, nullptr);
+    for (int k = 0; k < SC_PER; ++k) {
+        if (!(flags >> k & 1u)) continue;
+        const float *q = xyz + 3 * (base + k);
+        pts[3 * pos] = __dmul_rn((double)q[0], scale);
+        pts[3 * pos + 1] = __dmul_rn((double)q[1], scale);
+        pts[3 * pos + 2] = __dmul_rn((double)q[2], scale);
+        ++pos;
+    }
+}
+
 int stage_in(pedp_ctx_t c, const float *src, size_t n_in, size_t n_out, int mem, const float **d_in, float **d_out,
              float *out) {
     *d_in = src;
@@ -594,6 +658,56 @@ int pedp_depth2xyzmap_batch(pedp_ctx_t c, const float *depths, int B, int H, int
     hipLaunchKernelGGL(xyzmap_batch_kernel, dim3((unsigned)((hw + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, d_in,
                        (int64_t)hw, W, (const float *)c->proj.ptr, zfar, d_out);
     return stage_out(c, xyz, d_out, 3 * n, mem);
+}
+
+int pedp_depth_to_scene(pedp_ctx_t c, const float *depth, int H, int W, int depth_mem, const pedp_depth_entry_params *prm,
+                        float *d_filtered, float *d_xyz, double *d_points, int64_t *n_points) {
+    PEDP_REQUIRE(c && prm && d_points && n_points, "pedp_depth_to_scene: null argument");
+    PEDP_REQUIRE(depth_mem == PEDP_HOST || depth_mem == PEDP_DEVICE, "pedp_depth_to_scene: bad mem flag %d", depth_mem);
+    PEDP_REQUIRE(H >= 0 && W >= 0 && (int64_t)H * W < (int64_t)1 << 30, "pedp_depth_to_scene: image size out of range");
+    *n_points = 0;
+    const size_t n = (size_t)H * W;
+    if (n == 0) return PEDP_OK;
+    PEDP_REQUIRE(depth, "pedp_depth_to_scene: null depth image");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    // scratch: [raw image (host input)][eroded][filtered (if the caller wants none)][xyz (likewise)][block offsets][counter][K]
+    const int n_blocks = (int)((n + SC_BLOCK - 1) / SC_BLOCK);
+    auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t s_img = a256(sizeof(float) * n), s_xyz = a256(sizeof(float) * 3 * n), s_off = a256(sizeof(int) * ((size_t)n_blocks + 1));
+    int st = c->ray_in.reserve(3 * s_img + s_xyz + s_off + 512);
+    if (st) return st;
+    char *b = (char *)c->ray_in.ptr;
+    const float *d_raw = depth;
+    if (depth_mem == PEDP_HOST) {
+        { int up_ = pedp_upload(c, b, depth, sizeof(float) * n); if (up_) return up_; }
+        d_raw = (const float *)b;
+    }
+    float *d_er = (float *)(b + s_img);
+    float *d_fl = d_filtered ? d_filtered : (float *)(b + 2 * s_img);
+    float *d_x = d_xyz ? d_xyz : (float *)(b + 3 * s_img);
+    int *boff = (int *)(b + 3 * s_img + s_xyz);
+    int *counter = boff + n_blocks;
+    float *d_K = (float *)(b + 3 * s_img + s_xyz + s_off);
+    int rc = pedp_erode_depth(c, d_raw, H, W, prm->erode_radius, prm->erode_diff, prm->erode_ratio, prm->erode_zfar, PEDP_DEVICE, d_er);
+    if (rc) return rc;
+    rc = pedp_bilateral_filter_depth(c, d_er, H, W, prm->bilateral_radius, prm->bilateral_zfar, prm->sigmaD, prm->sigmaR, PEDP_DEVICE, d_fl);
+    if (rc) return rc;
+    float *h_K = (float *)((char *)c->pinned + 12288);
+    for (int k = 0; k < 9; ++k) h_K[k] = prm->K[k];   // (every earlier user of this pinned block has waited for its copy)
+    PEDP_HIP_CHECK(hipMemcpyAsync(d_K, h_K, sizeof(float) * 9, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(xyzmap_batch_kernel, dim3((unsigned)((n + 255) / 256), 1u), dim3(256), 0, c->stream, (const float *)d_fl, (int64_t)n, W,
+                       (const float *)d_K, prm->xyz_zfar, d_x);
+    hipLaunchKernelGGL(scene_count_kernel, dim3((unsigned)n_blocks), dim3(SC_THREADS), 0, c->stream, (const float *)d_x, (int64_t)n, prm->z_min, boff);
+    hipLaunchKernelGGL(scene_scan_kernel, dim3(1), dim3(1024), 0, c->stream, boff, n_blocks, counter);
+    hipLaunchKernelGGL(scene_scatter_kernel, dim3((unsigned)n_blocks), dim3(SC_THREADS), 0, c->stream, (const float *)d_x, (int64_t)n, prm->z_min,
+                       prm->scale, (const int *)boff, d_points);
+    PEDP_HIP_CHECK(hipGetLastError());
+    int *h_n = (int *)((char *)c->pinned + 8192);
+    PEDP_HIP_CHECK(hipMemcpyAsync(h_n, counter, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->stage_busy = false;
+    *n_points = *h_n;
+    return PEDP_OK;
 }
 
 }  // extern "C"

@@ -118,3 +118,45 @@ def depth2xyzmap_batch(depths, Ks, zfar, ctx=None):
             raise _lib.PedpError("Ks must hold one 3 x 3 matrix per image")
         return lib.pedp_depth2xyzmap_batch(h, src, B, H, W, _lib._ptr(Kf), float(zfar), mem, dst)
     return _run("pedp_depth2xyzmap_batch", depths, (3,), call, ctx)
+
+
+def depth_to_scene(depth, K, erode_radius=2, bilateral_radius=2, depth_diff_thres=0.001, ratio_thres=0.8, erode_zfar=100,
+                   bilateral_zfar=100, sigmaD=2, sigmaR=100000, xyz_zfar=np.inf, z_min=0.001, scale=1000.0, buffers=None, ctx=None):
+    """A frame's depth entry in ONE library call (pedp_depth_to_scene): erode_depth -> bilateral_filter_depth ->
+    depth2xyzmap_batch -> the points with z >= z_min as float64, scaled (estimater.py:255-259 and the scene cloud of run.py's
+    loop; what `xyz[xyz[..., 2] >= z_min].double() * scale` gives after the three calls, bit for bit).  depth: H x W float32
+    metres, a numpy array (uploaded by the library through its pinned staging) or a CUDA tensor.  Returns torch CUDA tensors
+    (filtered depth H x W, xyz map H x W x 3, points n x 3 float64); `buffers` (a dict, optional) keeps them across frames."""
+    import torch
+
+    ctx = ctx or _lib.default_context()
+    dev = torch.device(f"cuda:{ctx.device}")
+    if _is_torch(depth):
+        d_in = depth.to(dev, torch.float32).contiguous()
+        torch.cuda.current_stream(dev).synchronize()            # the library reads it on its own stream
+        H, W = _hw(d_in.shape)
+        src, mem, keep = C.c_void_p(d_in.data_ptr()), _lib.DEVICE, d_in
+    else:
+        d_in = np.ascontiguousarray(depth, dtype=np.float32)
+        H, W = _hw(d_in.shape)
+        src, mem, keep = _lib._ptr(d_in), _lib.HOST, d_in
+    buffers = {} if buffers is None else buffers
+    if buffers.get("shape") != (H, W):
+        buffers["shape"] = (H, W)
+        buffers["depth"] = torch.empty((H, W), dtype=torch.float32, device=dev)
+        buffers["xyz"] = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        buffers["points"] = [torch.empty((H * W, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+        buffers["turn"] = 0
+        torch.cuda.current_stream(dev).synchronize()
+    buffers["turn"] ^= 1                                          # two point buffers in turn: a frame's cloud outlives the next call
+    pts = buffers["points"][buffers["turn"]]
+    Kf = np.asarray(K.detach().cpu().numpy() if _is_torch(K) else K, dtype=np.float32).reshape(9)
+    prm = _lib.DepthEntryParams(int(erode_radius), float(depth_diff_thres), float(ratio_thres), float(erode_zfar), int(bilateral_radius),
+                                float(bilateral_zfar), float(sigmaD), float(sigmaR), (C.c_float * 9)(*Kf.tolist()), float(xyz_zfar),
+                                float(z_min), float(scale))
+    n = C.c_int64()
+    _lib.check(_lib.load().pedp_depth_to_scene(ctx._h, src, H, W, mem, C.byref(prm), C.c_void_p(buffers["depth"].data_ptr()),
+                                               C.c_void_p(buffers["xyz"].data_ptr()), C.c_void_p(pts.data_ptr()), C.byref(n)),
+               "pedp_depth_to_scene")
+    del keep
+    return buffers["depth"], buffers["xyz"], pts[: n.value]

@@ -25,7 +25,7 @@ import time
 
 import numpy as np
 
-from . import compat
+from . import compat, depth_filters
 from .compat import PointCloud
 from .ray_projection import FrameProjector
 
@@ -43,6 +43,8 @@ class FrameChain:
         self.color_to_depth = np.asarray(color_to_depth, np.float64)
         self.proj = FrameProjector(self.mesh, intrinsic, self.color_to_depth)
         self.K32 = torch.as_tensor(np.asarray(K32, np.float32), device="cuda")[None]
+        self.K32_host = np.asarray(K32, np.float32).reshape(3, 3)
+        self._depth_buffers = {}
         self.heat_threshold = heat_threshold
         self.host_pts = [None, None]  # pinned, live across frames: a pageable destination makes the runtime pin and unpin
         self.frame_no = 0             # 9 MB per frame, which holds up the next submissions by 20-30 ms (DESIGN s6); TWO of
@@ -73,13 +75,11 @@ class FrameChain:
     def _scene(self, depth_m, device_scene, lap):
         """estimater.py:255-259 and reader.get_source: filtered depth, back-projection, the valid points in mm."""
         torch = self.torch
-        d = depth_m if torch.is_tensor(depth_m) else torch.from_numpy(depth_m)
-        d = d.cuda()
-        d = compat.erode_depth(d, radius=2, device="cuda")
-        d = compat.bilateral_filter_depth(d, radius=2, device="cuda")
-        xyz = compat.depth2xyzmap_batch(d[None], self.K32, zfar=np.inf)[0]
+        # erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch -> the valid points in mm, as ONE library call
+        # (pedp_depth_to_scene: one upload of the image, no trip to the host between the kernels; bit for bit what the three
+        # calls and torch's `xyz[xyz[..., 2] >= 0.001].double() * 1000.0` give -- tests/test_depth_gpu.py)
+        d, xyz, dev_pts = depth_filters.depth_to_scene(depth_m, self.K32_host, buffers=self._depth_buffers)
         lap("depth filters + back-projection")
-        dev_pts = xyz[xyz[..., 2] >= 0.001].double() * 1000.0                  # scene cloud in mm (run.py works in mm)
         if device_scene:
             source, pts = PointCloud(dev_pts), None
         else:

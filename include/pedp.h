@@ -216,6 +216,27 @@ int pedp_depth2xyzmap(pedp_ctx_t ctx, const float *depth, int H, int W, const do
 int pedp_depth2xyzmap_batch(pedp_ctx_t ctx, const float *depths, int B, int H, int W, const float *Ks, float zfar,
                             int mem, float *xyz);
 
+/* The depth entry of a camera frame in ONE call (estimater.py:255-259 and the scene cloud run.py's loop works on):
+ *     erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch (one image, float32) -> the pixels with z >= z_min in
+ *     row-major order as float64 points scaled by `scale` (metres -> millimetres: 1000)
+ * -- the kernels of the three calls above back to back on the context's stream, one upload of the image (depth_mem =
+ * PEDP_HOST), no trip to the host between them, one 4-byte read-back (the count).  d_filtered (H x W float32) and d_xyz
+ * (H x W x 3 float32) are DEVICE memory, nullable (library scratch is used instead); d_points: DEVICE memory for
+ * H x W x 3 float64, the first n_points rows are written (what torch's `xyz[xyz[..., 2] >= z_min].double() * scale`
+ * gives).  Results are those of the single calls bit for bit. */
+typedef struct {
+    int32_t erode_radius;
+    float erode_diff, erode_ratio, erode_zfar;      /* erode_depth(radius, depth_diff_thres, ratio_thres, zfar) */
+    int32_t bilateral_radius;
+    float bilateral_zfar, sigmaD, sigmaR;            /* bilateral_filter_depth(radius, zfar, sigmaD, sigmaR) */
+    float K[9];                                      /* intrinsics of depth2xyzmap_batch (float32, row-major) */
+    float xyz_zfar;                                  /* its zfar (inf: none) */
+    float z_min;                                     /* validity of a back-projected point: 0.001 */
+    double scale;
+} pedp_depth_entry_params;
+int pedp_depth_to_scene(pedp_ctx_t ctx, const float *depth, int H, int W, int depth_mem, const pedp_depth_entry_params *prm,
+                        float *d_filtered, float *d_xyz, double *d_points, int64_t *n_points);
+
 /* ---------------------------------------------------------------- point-cloud operations
  * the Open3D calls preprocess_source chains (src/pose_estimation.py:186-268),
  * restated from the published open3d==0.18.0 algorithms.  Host arrays only (N x 3 float64); the

@@ -132,3 +132,29 @@ def test_depth2xyzmap_with_pixel_list(ctx, oracle):
     ref[vs, us] = pts
     ref[d < 0.001] = 0
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_depth_to_scene_in_one_call_equals_the_three_calls(ctx, oracle):
+    """pedp_depth_to_scene (a frame's depth entry: erode -> bilateral -> depth2xyzmap_batch -> the valid points in mm) against
+    the single calls and torch's mask expression: the filtered image, the xyz map and the float64 points in every bit, from
+    a host image and from a CUDA tensor, frame after frame (the point buffers are taken in turn), odd sizes, no valid pixel."""
+    torch = pytest.importorskip("torch")
+    from pedp_hip import compat, depth_filters, synth
+
+    K = np.array([[504.0, 0, 319.5], [0, 504.0, 287.5], [0, 0, 1]], np.float32)
+    buffers = {}
+    keep = []
+    for k, (h, w) in enumerate([(576, 640), (576, 640), (61, 83), (576, 640)]):
+        depth = synth.depth_image(h, w, seed=10 + k, nan=False).astype(np.float32)
+        src = torch.from_numpy(depth).cuda() if k == 1 else depth
+        d, xyz, pts = depth_filters.depth_to_scene(src, K, buffers=buffers)
+        e = compat.erode_depth(torch.from_numpy(depth).cuda(), radius=2, device="cuda")
+        b = compat.bilateral_filter_depth(e, radius=2, device="cuda")
+        x = compat.depth2xyzmap_batch(b[None], torch.from_numpy(K).cuda()[None], zfar=np.inf)[0]
+        ref = x[x[..., 2] >= 0.001].double() * 1000.0
+        assert torch.equal(d, b) and torch.equal(xyz, x)
+        assert pts.dtype == torch.float64 and pts.shape == ref.shape and torch.equal(pts, ref) and len(pts) > 100
+        keep.append((pts, ref.clone()))
+    assert torch.equal(keep[2][0], keep[2][1])          # the cloud of the frame before the last is intact (two buffers in turn)
+    d, xyz, pts = depth_filters.depth_to_scene(np.zeros((40, 48), np.float32), K, buffers=buffers)
+    assert len(pts) == 0 and not xyz.any()
