@@ -114,6 +114,7 @@ PROTOTYPES = {
     "pedp_nn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "pedp_icp_last_planned_passes": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
     "pedp_icp_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pedp_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -597,6 +598,13 @@ def icp_last_stats(ctx):
     a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     check(load().pedp_icp_last_stats(ctx._h, C.byref(a), C.byref(b), C.byref(c)), "pedp_icp_last_stats")
     return a.value, b.value, c.value
+
+
+def icp_last_planned_passes(ctx):
+    """Passes of the last single icp() that ran under a visit plan (more live chunks than CUs; scheduling only)."""
+    a = C.c_int64(0)
+    check(load().pedp_icp_last_planned_passes(ctx._h, C.byref(a)), "pedp_icp_last_planned_passes")
+    return a.value
 
 
 def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,

@@ -37,6 +37,7 @@
 //                        caller's hook), pivoted LDLT 6x6 / Jacobi SVD 3x3, T <- U * T,
 //                        fitness / rmse / convergence.
 #include "pedp_internal.h"
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -65,14 +66,14 @@ extern "C" int pedp_debug_icp_stamps(long long *out) {
 __device__ long long g_icp_rt[32][512][8];
 // per wave of the pass kernel (last pass that ran): [0] start [1] slots ready [2] culled+swept [3] selected [4] sums done (s_memtime),
 // [5] words << 32 | batches << 16 | wide << 8 | slots, [6] tiles
-__device__ long long g_icp_wave[512][8][12];
+__device__ long long g_icp_wave[512][8][16];
 #define PEDP_WV(slot, val)                                                                         \
     do {                                                                                           \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 512 && blockIdx.y == 0)                        \
             g_icp_wave[blockIdx.x][threadIdx.x >> 6][slot] = (long long)(val);                     \
     } while (0)
 extern "C" int pedp_debug_icp_wave(long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_wave), sizeof(long long) * 512 * 8 * 12) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_wave), sizeof(long long) * 512 * 8 * 16) == hipSuccess ? 0 : -3;
 }
 #define PEDP_RT(pass, slot)                                                                     \
     do {                                                                                        \
@@ -139,6 +140,8 @@ struct IcpState {
     // tickets and sign-offs are counted on from launch to launch (nothing to reset at the end of a pass): what the
     // counters read when this launch began
     unsigned ticket_base, idle_base;
+    int n_planned;             // passes of this registration that ran under a visit plan (statistics)
+    int nonce;                 // of this registration (<< 16 in the tags of the visit plan: entries of an earlier registration never match)
     double T_init[16];         // the start transformation: slot 0 of the update history (arrives with the state, no copy of its own)
 };
 
@@ -1417,6 +1420,29 @@ __device__ __forceinline__ void xform(const double *__restrict__ M, double &x, d
     x = nx; y = ny; z = nz;
 }
 
+// Pointers that reach a kernel through the argument block parked in LDS have no address space the compiler
+// could infer: every access through them came out as a FLAT operation, which counts on the LDS counter as
+// well as on the memory counter -- each LDS read of a list entry then waited for the loads still in flight
+// (`s_waitcnt vmcnt(0) lgkmcnt(0)` in front of the sweep's MFMAs), so nothing was prefetched at all.  The
+// pass kernel states the address space where it dereferences them.
+#define PEDP_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ PEDP_GLOBAL T *as_global(T *p) {
+    return (PEDP_GLOBAL T *)(uintptr_t)p;
+}
+__device__ __forceinline__ float4 gload4(const float4 *p) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = *(const PEDP_GLOBAL v4 *)(uintptr_t)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <typename P>
+__device__ __forceinline__ void xform_g(P M, double &x, double &y, double &z) {  // xform through a global pointer
+    const double nx = dadd(dadd(dadd(dmul(M[0], x), dmul(M[1], y)), dmul(M[2], z)), M[3]);
+    const double ny = dadd(dadd(dadd(dmul(M[4], x), dmul(M[5], y)), dmul(M[6], z)), M[7]);
+    const double nz = dadd(dadd(dadd(dmul(M[8], x), dmul(M[9], y)), dmul(M[10], z)), M[11]);
+    x = nx; y = ny; z = nz;
+}
+
 struct PassArgs {
     // scene
     const double *src;          // N x 3 source points
@@ -1454,6 +1480,15 @@ struct PassArgs {
                                 // 512 atomics on the state's line held up every wave's reads of the state
     double *packet, *trace;
     double bc[3];               // centre of the target's box (motion bound)
+    // Which workgroup visits which live chunk (single registration only).  With more live chunks than CUs the
+    // dispatcher puts workgroups n_cu + k and k on one CU, and two workgroups on a CU run a third slower than one
+    // alone: the pass ended with the pairs.  The workgroup that is through FIRST (ticket 0; it has ten microseconds
+    // to spare) ranks the chunks by the durations the pass before measured and hands the lightest 2 (n_live - n_cu)
+    // of them to the positions that share a CU, the lightest with the heaviest of those.  Only who works on a chunk
+    // changes -- partial sums stay indexed by live rank, so no result bit does.
+    int4 *visit;                // [2][visit_cap]: (live rank, chunk, pass + 1 it is meant for, n_live) for workgroup b of pass p at [p & 1][b]
+    int2 *dur;                  // [2][visit_cap]: (cycles, pass + 1 that measured them) by live rank, at [p & 1][rank]
+    int visit_cap, n_cu;
 };
 
 template <typename T>
@@ -1483,6 +1518,9 @@ struct FinishArgs {
     // the state is rewritten only once all n_idle of them have
     unsigned *idle = nullptr;
     int n_idle = 0, n_busy = 0;
+    // in-launch finish: what the closing workgroup read of the state when the launch began (pass, rebuild flag, live
+    // count do not change inside a pass) -- no second, dependent read in front of the partial sums' loads
+    int known = 0, k_pass = 0, k_rebuild = 0, k_n_live = 0;
 };
 template <int NT, int LCAP>
 struct FinishLds {
@@ -1518,7 +1556,7 @@ __device__ __forceinline__ unsigned long long load_live(unsigned long long *p) {
 
 template <int NT, int LCAP, bool COHERENT>
 __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &f, FinishLds<NT, LCAP> &L, const int tid) {
-    const int pass = st->pass, max_iter = st->max_iter;
+    const int pass = f.known ? f.k_pass : st->pass, max_iter = st->max_iter;
     const double n_source = st->n_source, rel_fitness = st->rel_fitness, rel_rmse = st->rel_rmse, reachE = st->reachE,
                  margin = st->margin;
     constexpr int PARTS = 32, TPARTS = NT / 32, PPT = PARTS / TPARTS;  // ranges; ranges in flight; ranges per thread
@@ -1539,8 +1577,8 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
     if (f.phase != 2) {
         // Partial sums are indexed by chunk id in a rebuild pass and by live rank otherwise; either
         // way they are summed in ascending chunk order.
-        const bool listing = st->rebuild != 0;
-        int n_live = st->n_live;
+        const bool listing = f.known ? f.k_rebuild != 0 : st->rebuild != 0;
+        int n_live = f.known ? f.k_n_live : st->n_live;
         bool listed = true;
         if (listing) {
             // the new live list, ascending: thread t owns a contiguous range of mask words
@@ -1570,7 +1608,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
                     const int chunk = wi * 64 + __builtin_ctzll(word);
                     word &= word - 1ull;
                     if (listed) L.lst[at] = chunk;
-                    f.live_list[at] = chunk;
+                    as_global(f.live_list)[at] = chunk;
                     ++at;
                 }
             }
@@ -1615,7 +1653,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
             double t = 0.0;
             for (int q = 0; q < PARTS; ++q) t += L.slice[q][tid];
             L.pk[tid] = t;
-            if (tid < PACKET) f.packet[tid] = t;
+            if (tid < PACKET) as_global(f.packet)[tid] = t;
         }
         __syncthreads();
         if (tid == 0 && f.phase == 1) {  // (phase 0 writes these further down, with the rest of the state)
@@ -1630,7 +1668,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         }
         if (f.phase == 1) return;
     } else {
-        if (tid < PACKET) L.pk[tid] = f.packet[tid];
+        if (tid < PACKET) L.pk[tid] = as_global(f.packet)[tid];
         __syncthreads();
     }
     if (COHERENT && f.n_idle > 0 && tid < 64) {  // normally true at the first look
@@ -1672,7 +1710,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         st->fitness = fit;
         st->rmse = rmse;
         if (f.trace) {
-            double *tr = f.trace + 18 * pass;
+            PEDP_GLOBAL double *tr = as_global(f.trace) + 18 * pass;
             tr[0] = fit; tr[1] = rmse;
             for (int k = 0; k < 16; ++k) tr[2 + k] = T0[k];
         }
@@ -1722,7 +1760,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
             }
             PEDP_STAMP(2, 0, 2);
             if (pass == 5) PEDP_STAMP(2, 3, 5);
-            for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; f.hist[16 * (pass + 1) + k] = upd[k]; }
+            for (int k = 0; k < 16; ++k) { st->upd[k] = upd[k]; as_global(f.hist)[16 * (pass + 1) + k] = upd[k]; }
             {
                 double Tn[16];
                 mat4_mul_dev(upd, T0, Tn);
@@ -1759,7 +1797,7 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
     }
     __syncthreads();
     if (L.do_rebuild)  // the next pass lists the live chunks anew; it resets what the old ones leave behind
-        for (int wi = tid; wi < f.n_lw; wi += NT) { f.live[f.n_lw + wi] = load_live<COHERENT>(&f.live[wi]); f.live[wi] = 0ull; }
+        for (int wi = tid; wi < f.n_lw; wi += NT) { as_global(f.live)[f.n_lw + wi] = load_live<COHERENT>(&f.live[wi]); as_global(f.live)[wi] = 0ull; }
 }
 
 constexpr int FIN_THREADS = 1024;
@@ -1797,7 +1835,7 @@ __device__ __forceinline__ void scan_near_tiles(unsigned long long near, int uni
         }
         const int64_t row = (int64_t)unit * 16 + (lane & 15);
         if (unit >= 0 && row < a.Nt)
-            lexmin(bd, bj, dist2(qx, qy, qz, a.tgt_s[6 * row], a.tgt_s[6 * row + 1], a.tgt_s[6 * row + 2]), a.tperm[row]);
+            lexmin(bd, bj, dist2(qx, qy, qz, as_global(a.tgt_s)[6 * row], as_global(a.tgt_s)[6 * row + 1], as_global(a.tgt_s)[6 * row + 2]), as_global(a.tperm)[row]);
     }
 }
 
@@ -1822,9 +1860,12 @@ __device__ __forceinline__ double row_sum_step(double v) { return v + row_partne
 // The MFMA loop of one wave over the n tiles of its LDS list against ITS sub-block (B operand b):
 // per lane -- slot lane & 15, target rows 4 (lane >> 4) .. + 3 of every tile -- the two best tiles
 // (value, tile) and the third-best value.  One MFMA per tile; the A fragments of the next SW_G tiles
-// are requested before this group's MFMAs are issued.  Pad tiles (rows that never win) follow the
-// list's last entry.
-__device__ __forceinline__ void sweep_sub_block(const unsigned *__restrict__ list, int n, const float *__restrict__ tgtf,
+// are requested before this group's MFMAs are issued (as GLOBAL loads: while they were flat, every LDS
+// read of a list entry waited for them).  SW_PAD pad tiles (rows that never win) follow the
+// list's last entry.  (Three groups in flight with the winners kept as list positions measured slower:
+// 0.738 against 0.714 ms per registration, round 4.)
+constexpr int SW_PAD = 2 * SW_G;
+__device__ __forceinline__ void sweep_sub_block(const unsigned *__restrict__ list, int n, const PEDP_GLOBAL float *__restrict__ tgtf,
                                                 int frag, float b, float &b1, int &t1, float &b2, int &t2, float &b3) {
     if (n <= 0) return;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1879,7 +1920,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     __shared__ double wp[W][3][16], accsh[W][PSTRIDE];
     __shared__ float wcs[W][3][16], weps[W][16], wS[W][16], wrho[W][16];
     __shared__ int wpi[W][16], wkk[W][16], misc[8];
-    __shared__ unsigned wtl[W][WTL + 2 * SW_G];
+    __shared__ unsigned wtl[W][WTL + SW_PAD];
     __shared__ float4 wnode[W][16], wsph0[64];
     __shared__ double rbs[16];  // rebuild passes: the pose so far (3 x 4), its norm bound, the reach
     __shared__ float wnode_r[W][16];
@@ -1898,12 +1939,22 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     // the first unit's live-list entry is requested together with the state (the list has one entry
     // per chunk, so the index is always inside it; the value is used only when it is valid)
     int chunk_next = pose_ptr(a0.live_list, pose_off)[blockIdx.x < (unsigned)a0.n_chunks ? blockIdx.x : 0];
+    // both parities of this workgroup's entry of the visit plan, requested before the pass number is known
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i vis0 = {0, 0, 0, 0}, vis1 = {0, 0, 0, 0};
+    if (!BATCH && a0.visit && blockIdx.x < (unsigned)a0.visit_cap) {
+        vis0 = ((const v4i *)a0.visit)[blockIdx.x];
+        vis1 = ((const v4i *)a0.visit)[(size_t)a0.visit_cap + blockIdx.x];
+    }
     // word spheres do not depend on the chunk: the first 64 are requested before anything else and parked in LDS
     if (threadIdx.x < 64) wsph0[threadIdx.x] = a0.word_sph[(int)threadIdx.x < a0.n_words ? threadIdx.x : 0];
     if (st->done) return;
     const bool rebuild = st->rebuild != 0;
     const int n_live = st->n_live, pass = st->pass;
     const unsigned ticket_base = st->ticket_base;
+    const v4i vis = (pass & 1) ? vis1 : vis0;
+    const int tag_now = st->nonce + pass + 1;  // (a registration runs well under 65,535 passes; beyond that no plan is made)
+    const bool planned = !BATCH && !rebuild && vis[2] == tag_now && vis[3] == n_live;  // (all workgroups agree: the plan is written whole)
     // Workgroups with chunks take a ticket when they are through; the one that draws the last closes the
     // pass.  The others leave at once -- but sign off first (a counter of sixteen, each on a line of its own:
     // hundreds of atomics on one word in the first microsecond held up everybody's loads), and the closing
@@ -1963,8 +2014,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
         const unsigned long long lt = (1ull << lane) - 1ull;
         // a rebuild pass visits chunks (unit = chunk id), other passes the live list (unit = rank);
         // `unit` also indexes the chunk's partial sums (see icp_finish_body)
-        const double *Pk_in = a.Pk + (size_t)(pass & 1) * a.pp_stride, *Tp_in = a.Tprev + (size_t)(pass & 1) * a.pp_stride;
-        double *Pk_out = a.Pk + (size_t)((pass + 1) & 1) * a.pp_stride, *Tp_out = a.Tprev + (size_t)((pass + 1) & 1) * a.pp_stride;
+        const PEDP_GLOBAL double *Pk_in = as_global(a.Pk) + (size_t)(pass & 1) * a.pp_stride, *Tp_in = as_global(a.Tprev) + (size_t)(pass & 1) * a.pp_stride;
+        PEDP_GLOBAL double *Pk_out = as_global(a.Pk) + (size_t)((pass + 1) & 1) * a.pp_stride, *Tp_out = as_global(a.Tprev) + (size_t)((pass + 1) & 1) * a.pp_stride;
         int chunk, unit;
         if (rebuild) {
             bool more = true;
@@ -1978,10 +2029,10 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
 #pragma unroll
                     for (int k = 0; k < 12; ++k) Rs[k] = rbs[k];
                     const double rscale = rbs[12], reach = rbs[13];
-                    const bool was_live = (a.live[a.n_lw + (u >> 6)] >> (u & 63)) & 1ull;
+                    const bool was_live = (as_global(a.live)[a.n_lw + (u >> 6)] >> (u & 63)) & 1ull;
 #pragma unroll 2
                     for (int sb = 0; sb < 8; ++sb) {
-                        const double *sp8 = a.chunk_sph + (size_t)(8 * u + sb) * 4;
+                        const PEDP_GLOBAL double *sp8 = as_global(a.chunk_sph) + (size_t)(8 * u + sb) * 4;
                         const double cx = sp8[0], cy = sp8[1], cz = sp8[2], cr = sp8[3];
                         const double tx = Rs[0] * cx + Rs[1] * cy + Rs[2] * cz + Rs[3], ty = Rs[4] * cx + Rs[5] * cy + Rs[6] * cz + Rs[7],
                                      tz = Rs[8] * cx + Rs[9] * cy + Rs[10] * cz + Rs[11];
@@ -1998,7 +2049,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                     const int i = __builtin_ctzll(wd);
                     wd &= wd - 1ull;
                     const int64_t k = ((int64_t)blockIdx.x + (int64_t)(todo_base + i) * gridDim.x) * CH + tid;
-                    if (tid < CH && k < a.N) a.idx_out[a.perm[k]] = -1;
+                    if (tid < CH && k < a.N) as_global(a.idx_out)[as_global(a.perm)[k]] = -1;
                 }
             }
             if (!more) break;
@@ -2010,10 +2061,16 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             unit = (int)(blockIdx.x + (unsigned)it * gridDim.x);
             ++it;
             if (unit >= n_live) break;
-            chunk = unit == (int)blockIdx.x ? chunk_next : a.live_list[unit];
+            if (planned && it == 1) { unit = vis[0]; chunk = vis[1]; }
+            else chunk = unit == (int)blockIdx.x ? chunk_next : as_global(a.live_list)[unit];
         }
+        long long t_chunk0 = 0;
+        if (!BATCH && !rebuild) t_chunk0 = (long long)__builtin_amdgcn_s_memtime();
         if (tid == 0) PEDP_STAMP(1, blockIdx.x, 0);
         PEDP_WV(0, __builtin_amdgcn_s_memtime());
+        PEDP_WV(9, pass);
+        PEDP_WV(10, __builtin_amdgcn_s_memrealtime());
+        PEDP_WV(12, ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492));  // XCC_ID, HW_ID
         // ---- 1. every wave transforms the 64 points of its half (the four waves of a half do the same
         // arithmetic and get the same ballots; quarter 0 stores), box test, compaction of the candidates:
         // the half's candidates in ascending position take the half's slots 0.., the wave keeps those
@@ -2026,14 +2083,14 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             const int64_t k = (int64_t)chunk * CH + half * 64 + lane;
             const bool valid = k < a.N;
             if (valid) {
-                pi = a.perm[k];
+                pi = as_global(a.perm)[k];
                 if (rebuild) {
-                    x = a.src[3 * (int64_t)pi]; y = a.src[3 * (int64_t)pi + 1]; z = a.src[3 * (int64_t)pi + 2];
+                    x = as_global(a.src)[3 * (int64_t)pi]; y = as_global(a.src)[3 * (int64_t)pi + 1]; z = as_global(a.src)[3 * (int64_t)pi + 2];
                     xform(st->T_init, x, y, z);
-                    for (int q = 1; q <= pass; ++q) xform(a.hist + 16 * q, x, y, z);
+                    for (int q = 1; q <= pass; ++q) xform_g(as_global(a.hist) + 16 * q, x, y, z);
                     // a chunk that was live in the pass before has that pass's neighbours (every point of a live
                     // chunk gets one, or NaN): the search radii need not start from r again
-                    if ((a.live[a.n_lw + (chunk >> 6)] >> (chunk & 63)) & 1ull)
+                    if ((as_global(a.live)[a.n_lw + (chunk >> 6)] >> (chunk & 63)) & 1ull)
                         dprev = sqrt(dist2(x, y, z, Tp_in[3 * k], Tp_in[3 * k + 1], Tp_in[3 * k + 2]));
                 } else {
                     x = Pk_in[3 * k]; y = Pk_in[3 * k + 1]; z = Pk_in[3 * k + 2];
@@ -2055,7 +2112,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             if (q4 == 0) {  // (the other copy: a wave of this half that comes late still reads this pass's inputs)
                 if (lane == 0) misc[half] = mn != 0ull;
                 if (valid) {  // (a rebuild pass stores every visited chunk's coordinates; only the live ones are read again)
-                    if (!cand) { a.idx_out[pi] = -1; Tp_out[3 * k] = dnan; }
+                    if (!cand) { as_global(a.idx_out)[pi] = -1; Tp_out[3 * k] = dnan; }
                     Pk_out[3 * k] = x; Pk_out[3 * k + 1] = y; Pk_out[3 * k + 2] = z;
                 }
             }
@@ -2181,7 +2238,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             int n = 0;
             for (int R = 0; R * 64 < a.n_words; ++R) {
                 const int wi = R * 64 + lane;
-                const float4 wsR = R == 0 ? wsph0[lane] : a.word_sph[wi < a.n_words ? wi : 0];
+                const float4 wsR = R == 0 ? wsph0[lane] : gload4(a.word_sph + (wi < a.n_words ? wi : 0));
                 unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_sb(wsR));
 #if PEDP_ICP_STAMPS
                 dbg_words += __builtin_popcountll(km);
@@ -2191,9 +2248,9 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                     ++dbg_batches;
 #endif
                     if (n + L2_WORDS * 64 > WTL) {  // rare: a dense neighbourhood
-                        if (lane < 2 * SW_G) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
+                        if (lane < SW_PAD) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
                         __builtin_amdgcn_s_waitcnt(0xC07F);
-                        sweep_sub_block(wtl[wv], n, a.tgtf, frag, bfrag, b1, t1, b2, t2, b3);
+                        sweep_sub_block(wtl[wv], n, as_global(a.tgtf), frag, bfrag, b1, t1, b2, t2, b3);
                         ntl_w += n;
                         n = 0;
                     }
@@ -2207,13 +2264,34 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                             km &= km - 1ull;
                         }
                         const int tile = word[u] * 64 + lane;
-                        ts[u] = a.tile_sph[(word[u] >= 0 && tile < a.n_tiles) ? tile : 0];
+                        ts[u] = gload4(a.tile_sph + ((word[u] >= 0 && tile < a.n_tiles) ? tile : 0));
+                    }
+                    // the batch's spheres against the cover, node by node: a node is read from LDS once per
+                    // batch (the next one requested before this one's tests), not once per sphere -- a wide
+                    // sub-block's four or five nodes used to cost a dependent LDS round trip per (sphere, node)
+                    unsigned nearbits = 0u;
+                    {
+                        float4 nd = node0;
+                        float nd_r = node0_r;
+                        for (int i = 0; i < nn; ++i) {  // wave-uniform
+                            float4 ndn = nd;
+                            float ndn_r = nd_r;
+                            if (i + 1 < nn) { ndn = wnode[wv][i + 1]; ndn_r = wnode_r[wv][i + 1]; }
+#pragma unroll
+                            for (int u = 0; u < L2_WORDS; ++u) {
+                                const float ex = ts[u].x - nd.x, ey = ts[u].y - nd.y, ez = ts[u].z - nd.z;
+                                const float li = nd_r + nd.w + ts[u].w;
+                                if (!((ex * ex + ey * ey + ez * ez) > li * li * 1.00001f + 1e-6f)) nearbits |= 1u << u;
+                            }
+                            nd = ndn;
+                            nd_r = ndn_r;
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < L2_WORDS; ++u) {
                         if (word[u] < 0) continue;
                         const int tile = word[u] * 64 + lane;
-                        const bool keep = tile < a.n_tiles && near_sb(ts[u]);
+                        const bool keep = tile < a.n_tiles && (nearbits >> u & 1u) != 0u && ts[u].w >= 0.f;
                         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
                         if (keep) wtl[wv][n + __builtin_popcountll(m & lt)] = (unsigned)tile;
                         n += __builtin_popcountll(m);
@@ -2221,9 +2299,9 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 }
             }
             PEDP_WV(8, __builtin_amdgcn_s_memtime());
-            if (lane < 2 * SW_G) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
+            if (lane < SW_PAD) wtl[wv][n + lane] = (unsigned)a.n_tiles;  // pad tiles: rows that never win
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            sweep_sub_block(wtl[wv], n, a.tgtf, frag, bfrag, b1, t1, b2, t2, b3);
+            sweep_sub_block(wtl[wv], n, as_global(a.tgtf), frag, bfrag, b1, t1, b2, t2, b3);
             ntl_w += n;
             if (tid == 0) PEDP_STAMP(1, blockIdx.x, 2);
             PEDP_WV(2, __builtin_amdgcn_s_memtime());
@@ -2236,13 +2314,18 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             // the window sends the slot to the exact search.
             auto load_rows = [&](int tile, double (&rw)[4][6], int (&ri)[4]) {
                 const int64_t row0 = (int64_t)tile * 16 + 4 * g;  // this lane's rows of the tile
+                // four rows of 48 B lie one behind the other, 16-B aligned: twelve 16-B loads (the sorted rows are
+                // allocated and zero-filled up to the pad tiles, so rows beyond Nt are readable; they are not scored)
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const PEDP_GLOBAL v2d *rows = (const PEDP_GLOBAL v2d *)(uintptr_t)(a.tgt_s + 6 * row0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + r < a.Nt ? row0 + r : 0;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) rw[r][c] = a.tgt_s[6 * row + c];
-                    ri[r] = a.tperm[row];
+                for (int q = 0; q < 12; ++q) {
+                    const v2d t = rows[q];
+                    rw[q / 3][2 * (q % 3)] = t[0];
+                    rw[q / 3][2 * (q % 3) + 1] = t[1];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ri[r] = as_global(a.tperm)[row0 + r < a.Nt ? row0 + r : 0];
             };
             const float e = real ? weps[wv][j] : 0.f, Si = real ? wS[wv][j] : 3e38f;
             const double qx = wp[wv][0][j], qy = wp[wv][1][j], qz = wp[wv][2][j];
@@ -2328,13 +2411,13 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 int xj = 0x7FFFFFFF;
                 for (int R = 0; R * 64 < a.n_words; ++R) {
                     const int wi = R * 64 + lane;
-                    const float4 wsR = R == 0 ? wsph0[lane] : a.word_sph[wi < a.n_words ? wi : 0];
+                    const float4 wsR = R == 0 ? wsph0[lane] : gload4(a.word_sph + (wi < a.n_words ? wi : 0));
                     unsigned long long km = __builtin_amdgcn_ballot_w64(wi < a.n_words && near_pt(wsR));
                     while (km != 0ull) {
                         const int word = R * 64 + __builtin_ctzll(km);
                         km &= km - 1ull;
                         const int tile = word * 64 + lane;
-                        const float4 ts = a.tile_sph[tile < a.n_tiles ? tile : 0];
+                        const float4 ts = gload4(a.tile_sph + (tile < a.n_tiles ? tile : 0));
                         const bool keep = tile < a.n_tiles && near_pt(ts);
                         scan_near_tiles(__builtin_amdgcn_ballot_w64(keep), tile, a, sx64, sy64, sz64, lane, xd, xj);
                     }
@@ -2368,16 +2451,16 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
                 if (jn >= 0 && !(dd < st->r2)) jn = -1;  // strict, as SearchHybrid's lower_bound
                 const int64_t kp = (int64_t)chunk * CH + wkk[wv][j];
                 if (g == 0) {
-                    a.idx_out[i] = jn;
+                    as_global(a.idx_out)[i] = jn;
                     if (jn < 0) Tp_out[3 * kp] = dnan;
                 }
                 if (jn >= 0) {
                     const double sx = wp[wv][0][j], sy = wp[wv][1][j], sz = wp[wv][2][j];
                     double tx = wt[0], ty = wt[1], tz = wt[2], nx = wn[0], ny = wn[1], nz = wn[2];
                     if (!have_tn) {  // rare: the exact search returns an index
-                        tx = a.tgt[3 * (int64_t)jn]; ty = a.tgt[3 * (int64_t)jn + 1]; tz = a.tgt[3 * (int64_t)jn + 2];
+                        tx = as_global(a.tgt)[3 * (int64_t)jn]; ty = as_global(a.tgt)[3 * (int64_t)jn + 1]; tz = as_global(a.tgt)[3 * (int64_t)jn + 2];
                         if (a.estimator == PEDP_POINT_TO_PLANE) {
-                            nx = a.nrm[3 * (int64_t)jn]; ny = a.nrm[3 * (int64_t)jn + 1]; nz = a.nrm[3 * (int64_t)jn + 2];
+                            nx = as_global(a.nrm)[3 * (int64_t)jn]; ny = as_global(a.nrm)[3 * (int64_t)jn + 1]; nz = as_global(a.nrm)[3 * (int64_t)jn + 2];
                         }
                     }
                     if (g == 0) { Tp_out[3 * kp] = tx; Tp_out[3 * kp + 1] = ty; Tp_out[3 * kp + 2] = tz; }
@@ -2423,6 +2506,7 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             if (lane == 0) { accsh[wv][PACKET] = (double)ntl_w; accsh[wv][PACKET + 1] = (double)nfb_w; }
         }
         PEDP_WV(4, __builtin_amdgcn_s_memtime());
+        PEDP_WV(11, __builtin_amdgcn_s_memrealtime());
         __syncthreads();
         if (tid < PSTRIDE) {
             double v = 0.0;
@@ -2430,7 +2514,16 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
             for (int w = 0; w < W; ++w) v += accsh[w][tid];
             double *dst = &a.partials[(size_t)unit * PSTRIDE + tid];
             if (a.fuse) store_sc1(dst, v);
-            else *dst = v;
+            else *as_global(dst) = v;
+        }
+        if (!BATCH && !rebuild && tid == 0 && a.dur && unit < a.visit_cap) {
+            // what this chunk cost, for the plan after next; a workgroup that shared its CU ran about a third slower
+            long long d = (long long)__builtin_amdgcn_s_memtime() - t_chunk0;
+            const int extra = n_live - a.n_cu;
+            if (extra > 0 && ((int)blockIdx.x < extra || (int)blockIdx.x >= a.n_cu)) d = d * 3 / 4;
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i e = {(int)(d < 0x7FFFFFFF ? d : 0x7FFFFFFF), tag_now};
+            ((PEDP_GLOBAL v2i *)(uintptr_t)a.dur)[(size_t)(pass & 1) * a.visit_cap + unit] = e;
         }
         if (tid == 0) PEDP_STAMP(1, blockIdx.x, 5);
 #if PEDP_ICP_STAMPS
@@ -2446,9 +2539,43 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add((g_u32 *)(uintptr_t)a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         misc[4] = prev - ticket_base == (unsigned)(n_wg - 1);
+        misc[5] = prev == ticket_base;
     }
     __syncthreads();
     PEDP_RT(pass, 3);
+    if (!BATCH && misc[5] && !misc[4] && a.visit) {
+        // ---- the first workgroup through writes the next pass's visit plan: all of it, valid or not
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const int tid = threadIdx.x, n_cu = a.n_cu, extra = n_live - n_cu;
+        PEDP_GLOBAL v4i *plan = (PEDP_GLOBAL v4i *)(uintptr_t)a.visit + (size_t)((pass + 1) & 1) * a.visit_cap;
+        const bool want = !rebuild && pass < 65000 && extra > 0 && n_live <= 2 * n_cu && n_live <= (int)gridDim.x && n_live <= W * 64 && n_live <= a.visit_cap;
+        int d = 0x7FFFFFFF, mine_ok = 1;
+        if (want && tid < n_live) {
+            const v2i e = ((const PEDP_GLOBAL v2i *)(uintptr_t)a.dur)[(size_t)((pass + 1) & 1) * a.visit_cap + tid];  // pass - 1 wrote this copy
+            mine_ok = e[1] == tag_now - 1;
+            d = e[0];
+        }
+        const int chunk_of_rank = (want && tid < n_live) ? as_global(a.live_list)[tid] : 0;
+        if (__syncthreads_and(mine_ok) && want) {
+            fin.scan[tid] = d;
+            __syncthreads();
+            if (tid < n_live) {
+                int r = 0;  // rank of this chunk by (duration, live rank)
+                for (int q = 0; q < n_live; ++q) {
+                    const int dq = fin.scan[q];
+                    r += (dq < d || (dq == d && q < tid)) ? 1 : 0;
+                }
+                const int pos = r < extra ? r : (r < 2 * extra ? n_cu + (2 * extra - 1 - r) : r - extra);
+                const v4i e = {tid, chunk_of_rank, tag_now + 1, n_live};
+                plan[pos] = e;
+            }
+        } else {
+            const v4i none = {0, 0, 0, 0};
+            const int n = (int)gridDim.x < a.visit_cap ? (int)gridDim.x : a.visit_cap;
+            for (int i = tid; i < n; i += W * 64) plan[i] = none;
+        }
+        return;
+    }
     if (!misc[4]) return;
 
     if (threadIdx.x == 0) PEDP_STAMP(1, blockIdx.x, 6);
@@ -2458,6 +2585,8 @@ __global__ __launch_bounds__(W * 64, 4) void icp_pass_kernel(IcpState *st0, cons
     f.idle = a.ticket + 32;
     f.n_idle = (int)gridDim.x - n_wg;
     f.n_busy = n_wg;
+    if (!BATCH && planned && threadIdx.x == 0) st->n_planned += 1;
+    f.known = 1; f.k_pass = pass; f.k_rebuild = rebuild ? 1 : 0; f.k_n_live = n_live;
     icp_finish_body<W * 64, 2048, true>(st, f, fin, threadIdx.x);
     PEDP_RT(pass, 4);
 }
@@ -2494,6 +2623,9 @@ struct IcpWorkspace {
     unsigned *ticket;
     unsigned long long *live;
     int32_t *live_list;
+    int4 *visit;   // visit plan and chunk durations (single registration; see PassArgs)
+    int2 *dur;
+    int visit_cap;
     int n_lw, n_chunks;
     const float4 *word_sph;
     const double *tgt_s;
@@ -2558,7 +2690,8 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     size_t o_b1 = take(sizeof(float) * tr);
     size_t o_t1 = take(sizeof(int32_t) * tr);
     size_t o_b2 = take(sizeof(float) * tr);
-    size_t o_Pk = 0, o_hist = 0, o_cpart = 0, o_live = 0, o_llist = 0, o_tprev = 0, o_ticket = 0;
+    size_t o_Pk = 0, o_hist = 0, o_cpart = 0, o_live = 0, o_llist = 0, o_tprev = 0, o_ticket = 0, o_visit = 0;
+    w.visit_cap = 0;
     if (fused) {
         o_Pk = take(sizeof(double) * 3 * (size_t)w.Ns_pad * 2);     // read from [pass & 1], written to the other: no wave
         o_tprev = take(sizeof(double) * 3 * (size_t)w.Ns_pad * 2);  // ever reads what a faster wave of the same pass has rewritten
@@ -2567,6 +2700,10 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
         o_ticket = take(17 * 128);  // the ticket and the sixteen sign-off counters, a line each; the live masks right behind (one memset)
         o_live = take(sizeof(unsigned long long) * 2 * (size_t)w.n_lw);  // live mask + the mask before the last rebuild
         o_llist = take(sizeof(int32_t) * (size_t)w.blocks_cap);
+        if (poses <= 1) {  // a batch fills every CU several times over anyway
+            w.visit_cap = (int)(w.blocks_cap < 2 * c->num_cus ? w.blocks_cap : 2 * c->num_cus);
+            o_visit = take((sizeof(int4) + sizeof(int2)) * 2 * (size_t)w.visit_cap);
+        }
     }
     off = align_up(off, 4096);
     w.pose_stride = off;  // a batch lays `poses` such blocks one behind the other
@@ -2602,6 +2739,8 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
     w.live = (unsigned long long *)(b + o_live);
     w.live_list = (int32_t *)(b + o_llist);
     w.ticket = (unsigned *)(b + o_ticket);
+    w.visit = w.visit_cap ? (int4 *)(b + o_visit) : nullptr;
+    w.dur = w.visit_cap ? (int2 *)(b + o_visit + sizeof(int4) * 2 * (size_t)w.visit_cap) : nullptr;
     // the per-block survivor counters start at zero (the segment kernel re-zeroes them per pass)
     if (!fused) PEDP_HIP_CHECK(hipMemsetAsync(w.blk_cnt, 0, sizeof(int32_t) * (size_t)w.blocks_cap, c->stream));
     return PEDP_OK;
@@ -2672,6 +2811,10 @@ inline bool unfused_finish() {
     static const bool m = getenv("PEDP_ICP_UNFUSED_FINISH") && atoi(getenv("PEDP_ICP_UNFUSED_FINISH")) != 0;
     return m;
 }
+inline bool no_visit_plan() {  // PEDP_ICP_NO_VISIT_PLAN=1: every workgroup takes the live chunk of its own index (tests compare the two)
+    static const bool m = getenv("PEDP_ICP_NO_VISIT_PLAN") && atoi(getenv("PEDP_ICP_NO_VISIT_PLAN")) != 0;
+    return m;
+}
 // Enqueue the kernel of a fused pass.  fuse: the workgroup that finishes last closes the pass
 // (sum, solve, update); otherwise icp_finish_kernel launches follow (exchange step in between).
 int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int estimator,
@@ -2689,6 +2832,8 @@ int enqueue_fused_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pe
     pa.estimator = estimator; pa.idx_out = w.idx; pa.partials = w.cpart;
     pa.pose_stride = poses > 1 ? w.pose_stride : 0;
     pa.fuse = fuse && !unfused_finish() ? 1 : 0; pa.n_lw = w.n_lw; pa.packet = w.packet; pa.trace = trace; pa.ticket = w.ticket;
+    const bool plan = poses <= 1 && !no_visit_plan();
+    pa.visit = plan ? w.visit : nullptr; pa.dur = plan ? w.dur : nullptr; pa.visit_cap = w.visit_cap; pa.n_cu = c->num_cus;
     // grid-stride loop over the live chunks: any grid is correct; two workgroups per CU are resident
     int64_t g = w.n_chunks;
     if (g > 2 * c->num_cus) g = 2 * c->num_cus;
@@ -2865,6 +3010,8 @@ int icp_job_setup(pedp_ctx_t x, pedp_cloud_t source, pedp_cloud_t target, const 
 // icp_enqueue; the same block receives the final state)
 void icp_fill_state(IcpState *dst, const TargetPrep &tp, const double init[16], const pedp_icp_params *prm, int64_t Ns) {
     IcpState h{};
+    static std::atomic<int> registration_counter{0};
+    h.nonce = ((registration_counter.fetch_add(1, std::memory_order_relaxed) & 0x3FFF) + 1) << 16;
     for (int k = 0; k < 16; ++k) { h.T[k] = init[k]; h.upd[k] = init[k]; h.T_init[k] = init[k]; }
     for (int k = 0; k < 3; ++k) h.centroid[k] = tp.c[k];
     h.rebuild = 1;  // fused pass: pass 0 builds the live chunk set from the whole scene
@@ -3013,6 +3160,7 @@ int icp_collect(pedp_ctx_t x, const IcpJob &job, double T_out[16], double *fitne
     x->icp_last_cand = job.w.fused ? hp->sum_tiles * 256 : hp->sum_tiles * (16 * job.qt) * (NN_SB * 16);
     x->icp_last_fb = hp->sum_fb;
     x->icp_last_passes = hp->iters + 1;
+    x->icp_last_planned = hp->n_planned;
     x->icp_last_nt = job.Nt;
     if (fitness) *fitness = hp->fitness;
     if (inlier_rmse) *inlier_rmse = hp->rmse;
@@ -3388,6 +3536,12 @@ int pedp_icp_last_stats(pedp_ctx_t c, int64_t *passes, int64_t *pairs_swept, int
     if (passes) *passes = c->icp_last_passes;
     if (pairs_swept) *pairs_swept = c->icp_last_cand;
     if (fallback_points) *fallback_points = c->icp_last_fb;
+    return PEDP_OK;
+}
+
+int pedp_icp_last_planned_passes(pedp_ctx_t c, int64_t *planned) {
+    PEDP_REQUIRE(c && planned, "pedp_icp_last_planned_passes: null argument");
+    *planned = c->icp_last_planned;
     return PEDP_OK;
 }
 

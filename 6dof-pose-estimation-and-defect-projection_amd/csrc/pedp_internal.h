@@ -128,7 +128,7 @@ struct pedp_ctx_s {
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
     int icp_timed_pass = -1;      // pedp_icp_configure: HIP events around the sweep kernel of this pass
-    long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0;  // last pedp_icp
+    long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0, icp_last_planned = 0;  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
     pedp_icp_graph_key icp_graph_key;

@@ -458,6 +458,13 @@ int pedp_icp_configure(pedp_ctx_t ctx, int exhaustive, int timed_pass);
  * ambiguous and went through the exact float64 brute-force kernel. */
 int pedp_icp_last_stats(pedp_ctx_t ctx, int64_t *passes, int64_t *pairs_swept, int64_t *fallback_points);
 
+/* Passes of the last single pedp_icp on this context that ran under a visit plan: with more live scene chunks than
+ * CUs (and at most twice as many) the workgroup that is through first ranks the chunks by the time the pass before
+ * spent on them and hands the lightest ones to the workgroup positions that share a CU.  Scheduling only -- partial
+ * sums stay indexed by live rank, results do not change in any bit (PEDP_ICP_NO_VISIT_PLAN=1 switches it off;
+ * tests/test_icp_gpu.py compares).  No counterpart in the reference (src/pose_estimation.py:447-453 calls Open3D). */
+int pedp_icp_last_planned_passes(pedp_ctx_t ctx, int64_t *planned);
+
 /* ---------------------------------------------------------------- multi-GPU collectives
  * One process per GPU.  The reference has no distributed path; these entry points
  * exist so that the two exchange steps of the sharded path run inside the library, on

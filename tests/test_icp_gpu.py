@@ -395,3 +395,46 @@ def test_in_launch_finish_equals_the_finish_kernel(tmp_path):
         outs.append(np.load(out))
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+_PLAN_PROBE = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+from pedp_hip import _lib, synth
+ctx = _lib.Context(0)
+f = synth.Frame("bench_100k")
+mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+scene = f.scene(mesh.cast_rays(f.rays6, want_uv=False)["t_hit"])
+src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+out = {}
+for name, init in (("a", f.icp_init()), ("b", np.linalg.inv(synth.batched_start_poses(3)[2]))):
+    r = _lib.icp(ctx, src, tgt, 10.0, init, max_iteration=20, relative_fitness=-1, relative_rmse=-1, want_corr=True, want_trace=True)
+    out[name + "T"], out[name + "trace"], out[name + "corr"] = r["T"], r["trace"], r["corr"]
+    out[name + "planned"] = np.int64(_lib.icp_last_planned_passes(ctx))
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_visit_plan_changes_no_bit(tmp_path):
+    """With more live chunks than CUs (the bench frame: 281 on 256) the first workgroup through a pass hands the
+    lightest chunks to the workgroup positions that share a CU.  Scheduling only: the transformation, every pass of
+    the trace and every correspondence agree bit for bit with PEDP_ICP_NO_VISIT_PLAN=1 -- and the plan was in force."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"plan{flag}.npz")
+        env = dict(os.environ, PEDP_ICP_NO_VISIT_PLAN=flag)
+        p = subprocess.run([sys.executable, "-c", _PLAN_PROBE, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        if not k.endswith("planned"):
+            assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert int(outs[1]["aplanned"]) == 0 and int(outs[1]["bplanned"]) == 0
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:   # 281 live chunks: a plan from the fourth steady pass on
+        assert int(outs[0]["aplanned"]) >= 10, int(outs[0]["aplanned"])

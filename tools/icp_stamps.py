@@ -79,11 +79,11 @@ if hasattr(lib, "pedp_debug_icp_rt") and lib.pedp_debug_icp_rt(C.c_void_p(rt.cty
         prev_close = last
         print(line)
 # per-wave view of the last pass
-wvb = np.zeros((512, 8, 12), np.int64)
+wvb = np.zeros((512, 8, 16), np.int64)
 if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wvb.ctypes.data)) == 0:
-    w = wvb.reshape(-1, 12)
-    w = w[(w[:, 4] > 0) & (w[:, 2] > 0)]
-    w = w[w[:, 0] > w[:, 0].max() - 60 * mhz]
+    w = wvb.reshape(-1, 16)
+    last_pass = int(w[:, 9].max())
+    w = w[(w[:, 4] > 0) & (w[:, 2] > 0) & (w[:, 9] == last_pass)]   # s_memtime is per XCD: select by pass, not by time
     ph = np.diff(w[:, :5], axis=1) * tick
     words, batches, wide, slots, tiles = w[:, 5] >> 32, (w[:, 5] >> 16) & 0xFFFF, ((w[:, 5] >> 8) & 0xFF) - 1, w[:, 5] & 0xFF, w[:, 6]
     print(f"waves with slots in the last pass: {len(w)}; wide {int(wide.sum())}")
@@ -100,7 +100,7 @@ if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wv
         print(f"   slowest cull+sweep {cs[i]:6.2f}: words {words[i]} batches {batches[i]} tiles {tiles[i]} wide {wide[i]} slots {slots[i]}")
     # per workgroup: how much of its time is the spread of the sweep between its waves
     g = wvb.copy()
-    ok = (g[:, :, 4] > 0) & (g[:, :, 2] > 0) & (g[:, :, 0] > g[:, :, 0].max() - 60 * mhz)
+    ok = (g[:, :, 4] > 0) & (g[:, :, 2] > 0) & (g[:, :, 9] == last_pass)
     rows = []
     for b in range(g.shape[0]):
         m = ok[b]
@@ -118,3 +118,43 @@ if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wv
         print(f"   sweep: slowest wave median {np.median(r[:,2]):.2f} max {r[:,2].max():.2f} | mean median {np.median(r[:,3]):.2f} max {r[:,3].max():.2f}")
         print(f"   if the sweep were shared evenly inside a workgroup: slowest wave median {np.median(r[:,4]):.2f} max {r[:,4].max():.2f}")
         print(f"   cover + lists: slowest wave median {np.median(r[:,5]):.2f} max {r[:,5].max():.2f} | mean median {np.median(r[:,6]):.2f}")
+
+    # the slowest workgroups of the last pass on the device-wide clock: where their slowest wave spent its time
+    t0 = g[:, :, 10][ok].min()
+    done = np.where(ok, g[:, :, 11], 0).max(axis=1)
+    order = np.argsort(-done)[:10]
+    print("slowest workgroups (us after the first wave's start on the 100-MHz clock; phases of the wave that finished last):")
+    for b in order:
+        if done[b] == 0:
+            continue
+        m = ok[b]
+        t = g[b][m]
+        k = int(np.argmax(t[:, 11]))
+        q = t[k]
+        info = q[5]
+        print(f"   wg {b:3d}: done {(done[b]-t0)/100:6.2f}, started {(t[:,10].min()-t0)/100:5.2f}; its last wave: slots ready {(q[1]-q[0])*tick:5.2f} cover {(q[7]-q[1])*tick:5.2f} "
+              f"lists {(q[8]-q[7])*tick:5.2f} sweep {(q[2]-q[8])*tick:5.2f} select {(q[3]-q[2])*tick:5.2f} sums {(q[4]-q[3])*tick:5.2f} | words {info>>32} batches {(info>>16)&0xFFFF} "
+              f"tiles {q[6]} slots {info&0xFF}; waves' ends spread {(t[:,11].max()-t[:,11].min())/100:5.2f}")
+    ends = (done[done > 0] - t0) / 100
+    print(f"   workgroup end times: median {np.median(ends):.2f} p90 {np.percentile(ends,90):.2f} p99 {np.percentile(ends,99):.2f} max {ends.max():.2f}")
+    tl = (g[:, :, 6][ok])
+    print(f"   tiles per wave: median {np.median(tl)} p90 {np.percentile(tl,90)} p99 {np.percentile(tl,99)} max {tl.max()}")
+
+    # which workgroups shared a CU (HW_ID bits 15:8 = CU / SH / SE, XCC_ID): times of lone and of co-resident workgroups
+    hw = g[:, 0, 12]
+    cu_key = ((hw >> 32) & 0xF) * 256 + ((hw & 0xFFFFFFFF) >> 8 & 0xFF)
+    live = ok.any(axis=1)
+    import collections
+    groups = collections.defaultdict(list)
+    for b in np.nonzero(live)[0]:
+        groups[int(cu_key[b])].append(int(b))
+    dur = np.where(ok, g[:, :, 11] - g[:, :, 10], 0).max(axis=1) / 100.0
+    lone = [dur[v[0]] for v in groups.values() if len(v) == 1]
+    shared = [dur[b] for v in groups.values() if len(v) > 1 for b in v]
+    print(f"CUs in use {len(groups)}; workgroups alone on a CU {len(lone)}: duration median {np.median(lone):.2f} p90 {np.percentile(lone,90):.2f} max {np.max(lone):.2f} us")
+    if shared:
+        print(f"   workgroups sharing a CU {len(shared)} (on {sum(1 for v in groups.values() if len(v) > 1)} CUs, up to {max(len(v) for v in groups.values())} each): duration median {np.median(shared):.2f} p90 {np.percentile(shared,90):.2f} max {np.max(shared):.2f} us")
+    pairs = sorted(tuple(v) for v in groups.values() if len(v) > 1)
+    print("   co-resident workgroups:", pairs[:40])
+    xcc = ((hw >> 32) & 0xF)
+    print("   XCC of workgroups 0..15:", [int(x) for x in xcc[:16]], " CU field of 0..7:", [int((h & 0xFFFFFFFF) >> 8 & 0xFF) for h in hw[:8]], " of 256..263:", [int((h & 0xFFFFFFFF) >> 8 & 0xFF) for h in hw[256:264]])
