@@ -1622,6 +1622,36 @@ __device__ __forceinline__ void icp_finish_body(IcpState *st, const FinishArgs &
         const int k = tid & 31;
         const int lper = (n_live + PARTS - 1) / PARTS;
         auto sum_ranges = [&](auto position) {
+            if constexpr (PPT == 2) {
+                // 512 threads, 32 ranges x 32 entries: a thread takes TWO ENTRIES OF ONE range (not one entry of two
+                // ranges, one range after the other): every load of the pass's sum is requested in one go -- one round
+                // trip past the L2 instead of two -- with the registers the two-range form used (ten loads per entry and
+                // round: a range is 9 chunks at the bench frame's 281 live chunks; each entry's additions in the same order)
+                constexpr int BW = 10;
+                const int part = tid >> 4, k0 = (tid & 15) * 2, k1 = k0 + 1;
+                const bool has1 = k1 < PACKET + 2;
+                const int l_lo = part * lper < n_live ? part * lper : n_live, l_hi = l_lo + lper < n_live ? l_lo + lper : n_live;
+                double v0 = 0.0, v1 = 0.0;
+                for (int q = l_lo; q < l_hi; q += BW) {
+                    int at[BW];
+                    double x0[BW], x1[BW];
+#pragma unroll
+                    for (int u = 0; u < BW; ++u) at[u] = position(q + u < l_hi ? q + u : l_hi - 1);
+#pragma unroll
+                    for (int u = 0; u < BW; ++u) {
+                        x0[u] = load_partial<COHERENT>(&f.partials[(size_t)at[u] * PSTRIDE + k0]);
+                        x1[u] = has1 ? load_partial<COHERENT>(&f.partials[(size_t)at[u] * PSTRIDE + k1]) : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < BW; ++u) {
+                        v0 = q + u < l_hi ? v0 + x0[u] : v0;
+                        v1 = q + u < l_hi ? v1 + x1[u] : v1;
+                    }
+                }
+                L.slice[part][k0] = v0;
+                L.slice[part][k1] = v1;
+                return;
+            }
 #pragma unroll
             for (int pp = 0; pp < PPT; ++pp) {
                 const int part = (tid >> 5) + pp * TPARTS;

@@ -16,4 +16,4 @@ pr = cProfile.Profile(); pr.enable()
 for k in range(40):
     chain.process(depth_m, init_pose(), heat, seed=0)
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue())
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70); print(s.getvalue())
