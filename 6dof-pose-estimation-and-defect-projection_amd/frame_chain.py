@@ -21,6 +21,7 @@ caller's business, bench.py and the tests set it):
 The FoundationPose networks that supply the start pose are out of scope: the caller passes one.
 Used by tests/test_stream_gpu.py (every stage against the oracle's chain), by bench.py's `frame_chain` and
 `tracking_frame` regions (the driver's clock) and by tools/stream_latency.py (stage times)."""
+import gc
 import time
 
 import numpy as np
@@ -32,7 +33,7 @@ from .ray_projection import FrameProjector
 
 class FrameChain:
     def __init__(self, model_points, model_normals, triangles, intrinsic, K32, color_to_depth, params, heat_threshold=0.75,
-                 background=None):
+                 background=None, freeze_gc=True):
         import torch
 
         self.torch = torch
@@ -50,6 +51,14 @@ class FrameChain:
         self.frame_no = 0             # 9 MB per frame, which holds up the next submissions by 20-30 ms (DESIGN s6); TWO of
         self.stage_ms = {}            # them in turn, so a frame's scene cloud stays valid while the next one is written
         self.reset()
+        if freeze_gc:
+            # A frame allocates a few thousand containers (dicts, tuples, holders); after a few dozen frames the collector
+            # runs a FULL collection, and with torch and numpy imported that walks every object of the process: 43 ms
+            # measured (tools/frame_gc_probe.py) -- ten frames' time, on one frame.  Everything alive now (modules,
+            # the model, the mesh) is long-lived: gc.freeze() takes it out of the collector's walks for good; full
+            # collections then see only what the loop itself made (< 0.1 ms).  Reference counting frees as before.
+            gc.collect()
+            gc.freeze()
 
     def reset(self):
         """The state run.py's loop carries from frame to frame (run.py:61, :104-107, :129)."""

@@ -23,6 +23,27 @@ def attach_queues(data_q, capture_q=None):
     data_queue, capture_queue = data_q, capture_q
 
 
+class LatestQueue:
+    """A data queue whose consumer keeps up: it holds the newest message only, like the Dash callback that drains
+    `data_queue` on every tick and draws the last message it found (web_vis.py's interval callback).  What bench.py,
+    the tools and the tests attach -- an ordinary queue.Queue that nobody reads keeps every frame's posed mesh alive,
+    and with it the page-locked block its vertices were downloaded into (one hipHostMalloc per frame, 0.75 ms)."""
+
+    def __init__(self):
+        self.last, self.count = None, 0
+
+    def put(self, item, *args, **kwargs):
+        self.last = item
+        self.count += 1
+
+    def get(self, *args, **kwargs):
+        item, self.last = self.last, None
+        return item
+
+    def empty(self):
+        return self.last is None
+
+
 def dash_payload(intersection_pcds, target_mesh):
     """The message of update_dash_data, built without sending it."""
     pcd_data = []

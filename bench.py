@@ -431,11 +431,10 @@ def run(args):
             # (run.py:99-101, :154-156) and the root logger at INFO in the reference's format (run.py:252, :260;
             # Utils.py:94-99) -- the lines are formatted and written like the reference's, to a null sink
             import logging
-            import queue as _queue
             from pedp_hip import viewer_wire
             from pedp_hip.frame_chain import bench_frame_setup
             chain, depth_m, heat, init_pose = bench_frame_setup(frame, depth)
-            viewer_wire.attach_queues(_queue.Queue())
+            viewer_wire.attach_queues(viewer_wire.LatestQueue())   # a consumer that keeps up (an unread queue.Queue would keep every frame's mesh alive)
             root_log = logging.getLogger()
             log_level, log_sink = root_log.level, logging.StreamHandler(open(os.devnull, "w"))
             log_sink.setFormatter(logging.Formatter("[%(funcName)s()] %(message)s"))
@@ -445,13 +444,18 @@ def run(args):
             depth_k = [(depth_m + drng.normal(0.0, 2e-4, depth_m.shape)).astype(np.float32) for _ in range(4)]
             n_done = [0]
 
+            frame_wall = []
+
             def step_chain():
+                a = time.perf_counter()
                 out_k = chain.process(depth_k[n_done[0] % 4], init_pose(), heat, seed=n_done[0])
+                frame_wall.append(1e3 * (time.perf_counter() - a))
                 n_done[0] += 1
                 return {"T": out_k["icp"].transformation, "fitness": out_k["icp"].fitness, "n_hits": len(out_k["cloud"].points)}
 
             fc_steps = max(3, min(args.steps, 10))
             fc_elapsed, fc_res, _ = timed_region(step_chain, fc_steps, 2)
+            fc_wall = list(frame_wall[-fc_steps:])
             chain.process(depth_k[0], init_pose(), heat, seed=0, timed=True)     # stage times, outside the timed region
             stage_ms = dict(chain.stage_ms)
             n_done[0] = 0                                                         # the same frames, the scene cloud never on the host
@@ -475,15 +479,18 @@ def run(args):
 
             def step_tracking():
                 del chain.intersection_pcds[1:]
+                a = time.perf_counter()
                 out_k = chain.process_tracking(depth_k[n_done[0] % 4], tracker_pose.copy(), heat_t, i=n_done[0], seed=n_done[0])
+                frame_wall.append(1e3 * (time.perf_counter() - a))
                 n_done[0] += 1
                 return {"T": out_k["icp"].transformation, "fitness": out_k["icp"].fitness, "n_hits": len(out_k["cloud"].points),
                         "n_processed": len(out_k["source_processed"].points)}
 
             tf_elapsed, tf_res, _ = timed_region(step_tracking, fc_steps, 2)
+            tf_wall = list(frame_wall[-fc_steps:])
             chain.process_tracking(depth_k[0], tracker_pose.copy(), heat_t, i=n_done[0], seed=0, timed=True)
-            extras["frame_chain"] = (fc_steps, fc_elapsed, fc_res, stage_ms, fd_elapsed)
-            extras["tracking_frame"] = (fc_steps, tf_elapsed, tf_res, dict(chain.stage_ms))
+            extras["frame_chain"] = (fc_steps, fc_elapsed, fc_res, stage_ms, fd_elapsed, fc_wall)
+            extras["tracking_frame"] = (fc_steps, tf_elapsed, tf_res, dict(chain.stage_ms), tf_wall)
             viewer_wire.attach_queues(None)
             root_log.removeHandler(log_sink)
             root_log.setLevel(log_level)
@@ -674,9 +681,10 @@ def run(args):
                         "spatial order + chunk spheres of the new handle, pedp_mesh_set_pose with a new pose (records rebuilt), "
                         f"{ICP_ITERS}-iteration registration, full-frame cast; the handle's buffers go back to the pool"}
         if "frame_chain" in extras:
-            fc_steps, fc_elapsed, fc_res, fc_stage, fd_elapsed = extras["frame_chain"]
+            fc_steps, fc_elapsed, fc_res, fc_stage, fd_elapsed, fc_wall = extras["frame_chain"]
             out["frame_chain"] = {
                 "frames": fc_steps, "ms_per_frame": 1e3 * fc_elapsed / fc_steps, "frames_per_s": fc_steps / fc_elapsed,
+                "ms_slowest_frame": max(fc_wall),   # FrameChain freezes the collector's old generations: no 40-ms full collection lands on a frame (DESIGN s6)
                 "ms_per_frame_device_scene": 1e3 * fd_elapsed / fc_steps,   # PointCloud over the CUDA tensor: no 9 MB down and up again
                 "stage_ms": fc_stage, "icp_fitness": fc_res["fitness"], "projected_hits": fc_res["n_hits"],
                 "pose_error_vs_gt": float(np.abs(np.linalg.inv(fc_res["T"]) - frame.T_gt).max()),
@@ -686,9 +694,10 @@ def run(args):
                         "-> preprocess_source -> z search -> randomised ICP restarts -> posed mesh -> heat-map projection -> "
                         "viewer message.  stage_ms from one extra, synchronised frame outside the timed region"}
         if "tracking_frame" in extras:
-            tf_steps, tf_elapsed, tf_res, tf_stage = extras["tracking_frame"]
+            tf_steps, tf_elapsed, tf_res, tf_stage, tf_wall = extras["tracking_frame"]
             out["tracking_frame"] = {
                 "frames": tf_steps, "ms_per_frame": 1e3 * tf_elapsed / tf_steps, "frames_per_s": tf_steps / tf_elapsed,
+                "ms_slowest_frame": max(tf_wall),
                 "stage_ms": tf_stage, "icp_fitness": tf_res["fitness"], "projected_hits": tf_res["n_hits"],
                 "processed_points": tf_res["n_processed"],
                 "pose_error_vs_gt": float(np.abs(np.linalg.inv(tf_res["T"]) - frame.T_gt).max()),

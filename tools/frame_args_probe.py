@@ -12,7 +12,7 @@ import queue
 f = synth.Frame("bench_100k")
 m = _lib.Mesh(_lib.default_context(), f.verts_posed, f.tris)
 t_hit = m.cast_rays(f.rays6, want_uv=False)["t_hit"]
-viewer_wire.attach_queues(queue.Queue())
+viewer_wire.attach_queues(viewer_wire.LatestQueue())
 root = logging.getLogger()
 sink = logging.StreamHandler(open(os.devnull, "w"))
 sink.setFormatter(logging.Formatter("[%(funcName)s()] %(message)s"))

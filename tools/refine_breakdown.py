@@ -13,7 +13,7 @@ t_hit = m.cast_rays(f.rays6, want_uv=False)["t_hit"]
 chain, depth_m, heat, init_pose = bench_frame_setup(f, t_hit)
 import queue
 from pedp_hip import viewer_wire
-viewer_wire.attach_queues(queue.Queue())
+viewer_wire.attach_queues(viewer_wire.LatestQueue())
 acc, calls = collections.defaultdict(float), collections.defaultdict(list)
 
 def timed(mod, name, label=None, describe=None):
