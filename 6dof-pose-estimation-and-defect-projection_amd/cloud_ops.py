@@ -89,8 +89,8 @@ def preprocess_source_fused(points, voxel_size, plane_distance, plane_iterations
     # the result is a small fraction of the frame: room for a tenth (at least 64 k points), the whole cloud if that is short
     for cap in (max(n // 10, 65536), n):
         cap = min(cap, max(n, 1))
-        out = np.empty((cap, 3), np.float64)
-        outn = np.empty((cap, 3), np.float64) if first_frame else None
+        out = _lib.host_array((cap, 3), np.float64)            # page-locked, pooled: the download needs no staging copy
+        outn = _lib.host_array((cap, 3), np.float64) if first_frame else None
         m, status = C.c_int64(), C.c_int()
         counts = (C.c_int64 * 4)()
         rc = _lib.load().pedp_preprocess_source_ex(ctx._h, ptr, n, on_dev, C.byref(prm), _lib._ptr(out), _lib._ptr(outn), cap,

@@ -98,7 +98,8 @@ class FrameChain:
                 self.host_pts[k] = torch.empty((max(len(dev_pts), d.numel()), 3), dtype=torch.float64, pin_memory=True)
             self.host_pts[k][: len(dev_pts)].copy_(dev_pts)
             pts = self.host_pts[k][: len(dev_pts)].numpy()   # the pinned array itself (no second 9-MB copy): valid until
-            source = PointCloud.borrowed(pts)                # the frame after next is processed (no copy, no kept device copy)
+            source = PointCloud.borrowed(pts, device=dev_pts)   # the frame after next is processed (no copy; the device twin
+                                                                # spares preprocess_source the upload of the bytes just downloaded)
         lap("scene cloud")
         return d, xyz, pts, int(len(dev_pts)), source
 

@@ -99,13 +99,19 @@ class PointCloud:
         return cls(points, normals, colors, _adopt=True)
 
     @classmethod
-    def borrowed(cls, points):
+    def borrowed(cls, points, device=None):
         """A holder over an array the caller keeps and may rewrite after the holder has served (a frame's scene cloud in a
-        pinned buffer): no copy, no kept device copy."""
+        pinned buffer): no copy, no kept device copy.  `device`: the float64 N x 3 CUDA tensor the array was downloaded
+        from, if the caller still has it -- the GPU operations then read it instead of uploading the same bytes again
+        (valid as long as the holder's points are not assigned or transformed, which drop it)."""
         out = cls()
         a = np.asarray(points, dtype=np.float64)
         out._points = a.reshape(-1, 3) if a.size else np.zeros((0, 3))
         out._borrowed = True
+        if device is not None:
+            if not _on_device(device) or device.numel() != out._points.size:
+                raise ValueError("PointCloud.borrowed: `device` must be the CUDA tensor the points were downloaded from")
+            out._dev_points = device.reshape(-1, 3)
         return out
 
     @classmethod
@@ -227,7 +233,7 @@ class PointCloud:
     def voxel_down_sample(self, voxel_size):
         from . import cloud_ops
 
-        if self._dev_points is not None and self._points is None and not self.has_normals():      # device-resident scene: the grid is built from it
+        if self._dev_points is not None and not self.has_normals():      # device-resident scene (or its twin on the device): the grid is built from it
             pts, nrm = cloud_ops.voxel_down_sample(self._dev_points, voxel_size)
         else:
             pts, nrm = cloud_ops.voxel_down_sample(self.points, voxel_size, self.normals if self.has_normals() else None)

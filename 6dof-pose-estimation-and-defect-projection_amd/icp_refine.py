@@ -207,7 +207,7 @@ def preprocess_source(pcd, background, param, i=0):
     if not param.get("mesh") and not param.get("debug_vis") and not _FORCE_STEPS:
         from . import cloud_ops
 
-        src_pts = pcd._dev_points if getattr(pcd, "_points", 0) is None and pcd._dev_points is not None else points_of(pcd)
+        src_pts = pcd._dev_points if getattr(pcd, "_dev_points", None) is not None else points_of(pcd)   # (a holder's device twin, if it has one)
         plane = params["plane_removal"]
         res = cloud_ops.preprocess_source_fused(src_pts, params["down_sample"], plane["distance_threshold"], plane["num_iterations"],
                                                 first_frame=(i == 0), box=box, report=(info or box))
