@@ -115,6 +115,8 @@ PROTOTYPES = {
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "pedp_icp_last_planned_passes": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "pedp_icp_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_int]),
+    "pedp_icp_end": (C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_void_p, C.c_void_p]),
     "pedp_icp_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pedp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pedp_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -641,6 +643,45 @@ def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_
     trace = np.zeros((max_iteration + 1, 18), np.float64) if want_trace else None
     check(load().pedp_icp(ctx._h, source._h, target._h, C.byref(prm), _ptr(T0), _ptr(T), C.byref(fit),
                           C.byref(rmse), C.byref(it), _ptr(corr), _ptr(trace)), "pedp_icp")
+    out = {"T": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iters": it.value}
+    if want_corr:
+        out["corr"] = corr
+    if want_trace:
+        out["trace"] = trace[: it.value + 1]
+    return out
+
+
+def icp_begin(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,
+              relative_fitness=1e-6, relative_rmse=1e-6, want_trace=False, n_source_global=0, use_comm=False):
+    """pedp_icp_begin: every pass of the registration is enqueued, the call returns at once; `icp_end(ctx, ...)` waits and
+    returns pedp_icp's result.  The context is the registration's until then."""
+    prm = IcpParams()
+    prm.max_correspondence_distance = float(max_correspondence_distance)
+    prm.estimator = int(estimator)
+    prm.max_iteration = int(max_iteration)
+    prm.relative_fitness = float(relative_fitness)
+    prm.relative_rmse = float(relative_rmse)
+    prm.allreduce = C.cast(None, ALLREDUCE_FN)
+    prm.allreduce_user = None
+    prm.n_source_global = int(n_source_global)
+    prm.use_comm = int(bool(use_comm))
+    T0 = np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+    check(load().pedp_icp_begin(ctx._h, source._h, target._h, C.byref(prm), _ptr(T0), 1 if want_trace else 0), "pedp_icp_begin")
+    ctx._icp_pending = (source, target, int(max_iteration), bool(want_trace))   # (the handles stay alive until the end)
+
+
+def icp_end(ctx, want_corr=False):
+    """pedp_icp_end: dict(T, fitness, inlier_rmse, iters[, corr, trace]) of the registration icp_begin started."""
+    pending = getattr(ctx, "_icp_pending", None)
+    if pending is None:
+        raise PedpError("icp_end: no registration is pending on this context")
+    source, _, max_iteration, want_trace = pending
+    ctx._icp_pending = None
+    T = np.empty((4, 4), np.float64)
+    fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+    corr = np.empty(source.N, np.int32) if want_corr else None
+    trace = np.zeros((max_iteration + 1, 18), np.float64) if want_trace else None
+    check(load().pedp_icp_end(ctx._h, _ptr(T), C.byref(fit), C.byref(rmse), C.byref(it), _ptr(corr), _ptr(trace)), "pedp_icp_end")
     out = {"T": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iters": it.value}
     if want_corr:
         out["corr"] = corr

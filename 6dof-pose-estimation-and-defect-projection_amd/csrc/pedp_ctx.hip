@@ -247,6 +247,7 @@ void pedp_ctx_destroy(pedp_ctx_t c) {
         if (c->sub[k]) pedp_ctx_destroy(c->sub[k]);
         c->sub[k] = nullptr;
     }
+    pedp_icp_drop_pending(c);   // (a pedp_icp_begin nobody ended: the stream has been waited for above)
     if (c->icp_graph) (void)hipGraphExecDestroy(c->icp_graph);
     for (hipGraphExec_t g : c->icp_bgraph)
         if (g) (void)hipGraphExecDestroy(g);

@@ -3378,12 +3378,20 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
 
 }  // namespace
 
+void pedp_icp_drop_pending(pedp_ctx_t c) {
+    if (c && c->icp_pending) {
+        delete (IcpJob *)c->icp_pending;
+        c->icp_pending = nullptr;
+    }
+}
+
 extern "C" {
 
 int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm,
              const double init[16], double T_out[16], double *fitness, double *inlier_rmse,
              int32_t *n_iter_done, int32_t *corr, double *trace) {
     PEDP_REQUIRE(c && source && target && prm && init && T_out, "pedp_icp: null argument");
+    PEDP_REQUIRE(!c->icp_pending, "pedp_icp: a registration is pending on this context (pedp_icp_end first)");
     int rc = icp_check_args(c, source, target, prm);
     if (rc) return rc;
     PEDP_HIP_CHECK(hipSetDevice(c->device));
@@ -3399,11 +3407,45 @@ int pedp_icp(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_
     return icp_collect(c, job, T_out, fitness, inlier_rmse, n_iter_done, corr, trace);
 }
 
+int pedp_icp_begin(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prm, const double init[16],
+                   int want_trace) {
+    PEDP_REQUIRE(c && source && target && prm && init, "pedp_icp_begin: null argument");
+    PEDP_REQUIRE(!c->icp_pending, "pedp_icp_begin: a registration is pending on this context (pedp_icp_end first)");
+    int rc = icp_check_args(c, source, target, prm);
+    if (rc) return rc;
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    TargetPrep tp;
+    rc = icp_prepare(c, source, target, tp);
+    if (rc) return rc;
+    IcpJob *job = new (std::nothrow) IcpJob;
+    PEDP_REQUIRE(job, "pedp_icp_begin: out of memory");
+    rc = icp_job_setup(c, source, target, prm, *job);
+    if (!rc) {
+        icp_fill_state((IcpState *)c->pinned, tp, init, prm, source->N);
+        rc = icp_enqueue(c, source, target, tp, prm, want_trace != 0, false, *job);
+    }
+    if (rc) { delete job; return rc; }
+    c->icp_pending = job;
+    return PEDP_OK;
+}
+
+int pedp_icp_end(pedp_ctx_t c, double T_out[16], double *fitness, double *inlier_rmse, int32_t *n_iter_done, int32_t *corr,
+                 double *trace) {
+    PEDP_REQUIRE(c && T_out, "pedp_icp_end: null argument");
+    PEDP_REQUIRE(c->icp_pending, "pedp_icp_end: no registration is pending on this context");
+    IcpJob *job = (IcpJob *)c->icp_pending;
+    c->icp_pending = nullptr;
+    const int rc = icp_collect(c, *job, T_out, fitness, inlier_rmse, n_iter_done, corr, trace);
+    delete job;
+    return rc;
+}
+
 // Hypotheses are independent: up to PEDP_MAX_SUB registrations are in flight at once, each on
 // its own stream and workspace (sub-contexts of c), sharing the clouds' cached preparation.
 int pedp_icp_batched_ex(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *prms,
                         const double *inits, int B, double *T_out, double *fitness, double *inlier_rmse, int32_t *n_iter_done) {
     PEDP_REQUIRE(c && source && target && prms && inits && T_out, "pedp_icp_batched: null argument");
+    PEDP_REQUIRE(!c->icp_pending, "pedp_icp_batched: a registration is pending on this context (pedp_icp_end first)");
     PEDP_REQUIRE(B >= 0, "pedp_icp_batched: negative batch");
     if (B == 0) return PEDP_OK;
     bool uniform = true;

@@ -128,7 +128,8 @@ struct pedp_ctx_s {
     pedp_scratch proj, proj_out;  // fused heat-map projection: selection, rays, hit records / compacted outputs
     bool icp_exhaustive = false;  // pedp_icp_configure: no culling (all-pairs sweep every pass)
     int icp_timed_pass = -1;      // pedp_icp_configure: HIP events around the sweep kernel of this pass
-    long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0, icp_last_planned = 0;  // last pedp_icp
+    long long icp_last_cand = 0, icp_last_fb = 0, icp_last_passes = 0, icp_last_nt = 0, icp_last_planned = 0;
+    void *icp_pending = nullptr;   // pedp_icp_begin's job until pedp_icp_end collects it (an IcpJob of pedp_icp.hip)  // last pedp_icp
     pedp_ctx_s *sub[PEDP_MAX_SUB] = {};  // sub-contexts (own stream + workspace) for batched registrations
     hipGraphExec_t icp_graph = nullptr;  // sub-contexts: one whole registration, replayed per start pose
     pedp_icp_graph_key icp_graph_key;
@@ -197,3 +198,6 @@ struct pedp_cloud_s {
     void *tgt_s = nullptr;      // sorted rows as float64 x 3 (exact re-scoring)
     int64_t tgt4_pad = 0;
 };
+
+// pedp_icp.hip: frees the job of a pedp_icp_begin that was never ended (called by pedp_ctx_destroy)
+void pedp_icp_drop_pending(pedp_ctx_t c);

@@ -253,10 +253,11 @@ def run(args):
 
     def step_whole():
         """Whole frame on this rank (N = 1, and the replica region)."""
-        cast_full()                                # enqueued on the ray stream, returns at once
         a = time.perf_counter()
-        res = _lib.icp(ctx, src, tgt, radius, init, **icp_kw)   # returns after its stream has finished
-        icp_wall[0] = 1e3 * (time.perf_counter() - a)
+        _lib.icp_begin(ctx, src, tgt, radius, init, **icp_kw)   # every pass enqueued on the ICP stream, returns at once
+        cast_full()                                # enqueued on the ray stream while the first passes run
+        res = _lib.icp_end(ctx)                    # returns after the ICP stream has finished
+        icp_wall[0] = 1e3 * (time.perf_counter() - a)   # (the registration's wall time, the cast's enqueue inside it)
         ray_ctx.synchronize()                      # the step ends when both stages have finished
         return res
 

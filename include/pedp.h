@@ -393,6 +393,20 @@ int pedp_icp(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
              double *fitness, double *inlier_rmse, int32_t *n_iter_done, int32_t *corr,
              double *trace);
 
+/* pedp_icp in two halves.  pedp_icp_begin enqueues every pass of the registration on the context's stream and returns at
+ * once (passes after convergence are no-ops on the device: the host does not look at the criteria in between);
+ * pedp_icp_end waits for them and hands the result over -- the same bits as pedp_icp's.  What the host does in between
+ * (enqueueing a frame's ray stage on ANOTHER context, bench.py's step) overlaps with the registration instead of waiting in
+ * front of it.  Between the two calls this context must not be used for anything else (its workspace and its page-locked
+ * state block belong to the pending registration): a second pedp_icp_begin, pedp_icp or pedp_icp_batched returns
+ * PEDP_ERR_ARG; destroying the context or either cloud with a registration pending is an error of the caller.  want_trace:
+ * pedp_icp_end's `trace` may be non-null.  The reference has no counterpart (registration_icp is one blocking call,
+ * src/pose_estimation.py:447-453). */
+int pedp_icp_begin(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *params,
+                   const double init[16], int want_trace);
+int pedp_icp_end(pedp_ctx_t ctx, double T_out[16], double *fitness, double *inlier_rmse, int32_t *n_iter_done,
+                 int32_t *corr, double *trace);
+
 /* Batched refine (FoundationPose hypothesis sizing, estimater.py:104-122): B start
  * poses share one source and one target; no early exit across the batch.  Up to 8 registrations
  * are in flight on internal streams (each replaying one captured hipGraph per pose); the call

@@ -438,3 +438,22 @@ def test_visit_plan_changes_no_bit(tmp_path):
     import torch
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:   # 281 live chunks: a plan from the fourth steady pass on
         assert int(outs[0]["aplanned"]) >= 10, int(outs[0]["aplanned"])
+
+
+def test_begin_end_equals_the_blocking_call(ctx, oracle):
+    """pedp_icp_begin / pedp_icp_end: the registration enqueued whole, collected later -- the same bits as pedp_icp, with
+    and without the early exit; a second registration on the context in between is refused."""
+    from pedp_hip import _lib
+
+    f, scene = _frame_scene(oracle, "parity")
+    src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+    for kw in (dict(max_iteration=12, relative_fitness=-1, relative_rmse=-1), dict(max_iteration=30)):
+        one = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), want_corr=True, want_trace=True, **kw)
+        _lib.icp_begin(ctx, src, tgt, 10.0, f.icp_init(), want_trace=True, **kw)
+        with pytest.raises(_lib.PedpError):
+            _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), **kw)
+        two = _lib.icp_end(ctx, want_corr=True)
+        assert np.array_equal(one["T"], two["T"]) and one["fitness"] == two["fitness"] and one["inlier_rmse"] == two["inlier_rmse"]
+        assert one["iters"] == two["iters"] and np.array_equal(one["corr"], two["corr"]) and np.array_equal(one["trace"], two["trace"])
+    with pytest.raises(_lib.PedpError):
+        _lib.icp_end(ctx)
