@@ -1,3 +1,4 @@
+"""Build libpedp_hip.so and the diagnostic libpedp_hip_stamps.so (-DPEDP_ICP_STAMPS=1, for tools/icp_stamps.py): python tools/build_libs.py"""
 import importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "6dof-pose-estimation-and-defect-projection_amd")
