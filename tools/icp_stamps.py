@@ -158,3 +158,15 @@ if hasattr(lib, "pedp_debug_icp_wave") and lib.pedp_debug_icp_wave(C.c_void_p(wv
     print("   co-resident workgroups:", pairs[:40])
     xcc = ((hw >> 32) & 0xF)
     print("   XCC of workgroups 0..15:", [int(x) for x in xcc[:16]], " CU field of 0..7:", [int((h & 0xFFFFFFFF) >> 8 & 0xFF) for h in hw[:8]], " of 256..263:", [int((h & 0xFFFFFFFF) >> 8 & 0xFF) for h in hw[256:264]])
+    # work of lone and of sharing workgroups: slots and swept tiles per workgroup
+    slots_wg = np.where(ok, g[:, :, 5] & 0xFF, 0).sum(axis=1)
+    tiles_wg = np.where(ok, g[:, :, 6], 0).sum(axis=1)
+    lone_b = [v[0] for v in groups.values() if len(v) == 1]
+    shared_b = [b for v in groups.values() if len(v) > 1 for b in v]
+    for name, bs in (("alone", lone_b), ("sharing", shared_b)):
+        if bs:
+            bs = np.array(bs)
+            print(f"   {name:8s}: slots per workgroup median {np.median(slots_wg[bs]):.0f} (min {slots_wg[bs].min()}, max {slots_wg[bs].max()}); tiles swept median {np.median(tiles_wg[bs]):.0f} (max {tiles_wg[bs].max()}); duration median {np.median(dur[bs]):.2f}")
+    order_d = np.argsort(dur[np.array(lone_b)])
+    lb = np.array(lone_b)[order_d]
+    print("   lone workgroups by duration, deciles of (duration, slots, tiles):", [(round(float(dur[b]), 1), int(slots_wg[b]), int(tiles_wg[b])) for b in lb[:: max(len(lb) // 10, 1)]])
