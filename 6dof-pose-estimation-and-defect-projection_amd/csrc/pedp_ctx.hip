@@ -559,6 +559,7 @@ void pedp_cloud_destroy(pedp_cloud_t cl) {
     if (cl->tile_sph4) (void)hipFree(cl->tile_sph4);
     if (cl->tile_sphw) (void)hipFree(cl->tile_sphw);
     if (cl->tgt_s) (void)hipFree(cl->tgt_s);
+    if (cl->tgt_bf) (void)hipFree(cl->tgt_bf);
     delete cl;
 }
 

@@ -353,14 +353,17 @@ __device__ __forceinline__ PackPoint pack_one(const IcpState *__restrict__ st, i
     return o;
 }
 __device__ __forceinline__ void pack_store(const PackPoint &p, int slot, float4 *__restrict__ B, float *__restrict__ eps,
-                                           float *__restrict__ S, int32_t *__restrict__ list, float Tn, float T2, float r1) {
+                                           float *__restrict__ S, int32_t *__restrict__ list, float Tn, float T2, float r1,
+                                           float mi_factor) {
     B[slot] = make_float4(-2.0f * p.sx, -2.0f * p.sy, -2.0f * p.sz, 1.0f);
     // Error bound of the fp32 surrogate relative to the float64 distance, for points whose
     // nearest neighbour is closer than r1 (see DESIGN.md "NN filter bound"):
     //   eps = 2^-23 * (5 * (2*|s'|_1*Tn + T2) + 2*min(r1, |s'|_1 + Tn)*(Tn + |s'|_1))
     float s1 = fabsf(p.sx) + fabsf(p.sy) + fabsf(p.sz);
     float Mi = 2.0f * s1 * Tn + T2;
-    eps[slot] = 1.1920929e-7f * (5.0f * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
+    // (mi_factor: 5 for the fp32 MFMA's four rounded products and three sums; 34 for the bf16 form's thirty exact products
+    // and up to thirty-one fp32 additions inside the matrix pipe, each charged a full ulp of the largest partial sum)
+    eps[slot] = 1.1920929e-7f * (mi_factor * Mi + 2.0f * fminf(r1, s1 + Tn) * (Tn + s1)) * 1.0001f;
     S[slot] = p.sx * p.sx + p.sy * p.sy + p.sz * p.sz;
     list[slot] = p.i;
 }
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void icp_transform_pack_kernel(
     const int32_t *__restrict__ perm, int64_t N, float4 *__restrict__ B, float *__restrict__ eps, float *__restrict__ S,
     int32_t *__restrict__ list, float4 *__restrict__ blk_sph, int32_t *__restrict__ idx_out,
     double *__restrict__ d2_out, float Tn, float T2, float r1, double r2cut, double lox, double loy, double loz,
-    double hix, double hiy, double hiz) {
+    double hix, double hiy, double hiz, float mi_factor) {
     if (st->done) return;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256) void icp_transform_pack_kernel(
     blk = __builtin_amdgcn_readfirstlane(blk);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int base = blk * 128;
-    if (p0.cand) pack_store(p0, base + __builtin_popcountll(m0 & lt), B, eps, S, list, Tn, T2, r1);
-    if (p1.cand) pack_store(p1, base + c0 + __builtin_popcountll(m1 & lt), B, eps, S, list, Tn, T2, r1);
+    if (p0.cand) pack_store(p0, base + __builtin_popcountll(m0 & lt), B, eps, S, list, Tn, T2, r1, mi_factor);
+    if (p1.cand) pack_store(p1, base + c0 + __builtin_popcountll(m1 & lt), B, eps, S, list, Tn, T2, r1, mi_factor);
     for (int s = cnt + lane; s < 128; s += 64) {  // dummies: never inliers, never selected
         B[base + s] = make_float4(0.f, 0.f, 0.f, 1.f);
         eps[base + s] = 0.f;
@@ -684,6 +687,149 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_kernel(
     for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = n_tiles; }
     sweep_list<QT, G>(mine, n_s, tgtf, frag, b, b1, t1, b2);
     const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) {
+        const size_t o = ((size_t)seg * 4 + q) * (NN_SB * 16) + (size_t)(sb * 16 + j);
+        tr_b1[o] = b1[sb];
+        tr_t1[o] = t1[sb];
+        tr_b2[o] = b2[sb];
+    }
+}
+
+// ---- 3b. the dense sweep on the bf16 matrix pipe (units of QT = 4 tiles: pedp_nn, large radii, the exhaustive
+// configuration).  g(i, j) = |t'_j|^2 - 2 s'_i . t'_j is one K = 32 contraction of v_mfma_f32_16x16x32_bf16 over EXACT
+// three-way bf16 pieces (truncation splits: 3 x 8 bits carry an fp32 mantissa): slot k = 9 c + 3 i + j holds piece i of the
+// model's t'_c against piece j of the scene's -2 s'_c (27 slots), slots 27..29 the pieces of |t'|^2 against 1, slots 30,
+// 31 zero.  Every product is exact; what is left of the error is the pipe's fp32 accumulation of thirty terms, which
+// the slot's bound eps charges at a full ulp of the largest partial sum per addition (mi_factor 34 instead of the fp32
+// form's 5): g is still a FILTER, winners are re-scored in float64 exactly as before.  16 cycles per MFMA instead of the
+// f32-input form's 32, and vector instructions issue beside it (8 of the 16 cycles are free): the fold's three VALU
+// operations per MFMA fit.  Same lanes, same triples, same selection and fallback kernels as nn_sweep_kernel.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+union BfFrag { bf8v v; unsigned short h[8]; uint4 q; };
+__device__ __forceinline__ void split3_bf16(float x, unsigned short (&out)[3]) {  // x = hi + mid + lo exactly (truncation)
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    const float r1 = __fsub_rn(x, hi);
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    const float lo = __fsub_rn(r1, mid);   // eight significant bits at most: a bf16
+    out[0] = (unsigned short)(__float_as_uint(hi) >> 16);
+    out[1] = (unsigned short)(__float_as_uint(mid) >> 16);
+    out[2] = (unsigned short)(__float_as_uint(lo) >> 16);
+}
+// A operand: per 16-row tile 64 lanes x 16 B, lane l = (row l & 15, k group l >> 4) holds its eight slots
+__global__ void pack_target_bf16_kernel(const float4 *__restrict__ tgt4, int64_t n_rows, uint4 *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * 4) return;
+    const int64_t tile = t >> 6;
+    const int lane = (int)(t & 63), row = lane & 15, q = lane >> 4;
+    const float4 v = tgt4[tile * 16 + row];
+    unsigned short pc[4][3];
+    split3_bf16(v.x, pc[0]); split3_bf16(v.y, pc[1]); split3_bf16(v.z, pc[2]); split3_bf16(v.w, pc[3]);
+    BfFrag f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * q + e;
+        f.h[e] = k < 27 ? pc[k / 9][(k % 9) / 3] : (k < 30 ? pc[3][k - 27] : (unsigned short)0);
+    }
+    out[t] = f.q;
+}
+template <int QT, int G>
+__device__ __forceinline__ void sweep_list_bf16(const unsigned *__restrict__ mine, int n_s, const uint4 *__restrict__ tgtb, int lane,
+                                                const bf8v (&b)[NN_SB], float (&b1)[NN_SB], int (&t1)[NN_SB], float (&b2)[NN_SB]) {
+    if (n_s <= 0) return;
+    constexpr int U = G * QT;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float vq[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) vq[sb] = __uint_as_float(0x7F800000u);
+    BfFrag a[U];
+    unsigned units[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        units[g] = mine[g];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) a[g * QT + u].q = tgtb[((size_t)units[g] * QT + u) * 64 + lane];
+    }
+    f32x4 acc[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[sb], zero, 0, 0, 0);
+    for (int k = 0; k < n_s; k += G) {
+        BfFrag an[U];
+        unsigned units_n[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            units_n[g] = mine[k + G + g];  // pad units follow the last real one
+#pragma unroll
+            for (int u = 0; u < QT; ++u) an[g * QT + u].q = tgtb[((size_t)units_n[g] * QT + u) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int u = t % QT;
+            const unsigned unit = units[t / QT];
+            const bf8v a_next = (t + 1 < U) ? a[t + 1].v : an[0].v;
+#pragma unroll
+            for (int sb = 0; sb < NN_SB; ++sb) {
+                f32x4 nxt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_next, b[sb], zero, 0, 0, 0);
+                const f32x4 cur = acc[sb];
+                if (u == 0) vq[sb] = fminf(fminf(fminf(cur[0], cur[1]), cur[2]), cur[3]);
+                else vq[sb] = fminf(fminf(fminf(fminf(vq[sb], cur[0]), cur[1]), cur[2]), cur[3]);
+                if (u == QT - 1) {
+                    const float v = vq[sb];
+                    t1[sb] = v < b1[sb] ? (int)unit : t1[sb];
+                    b2[sb] = __builtin_amdgcn_fmed3f(b1[sb], b2[sb], v);
+                    b1[sb] = fminf(b1[sb], v);
+                }
+                acc[sb] = nxt;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                if (u == QT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // then its VALU ops
+                else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) a[t] = an[t];
+#pragma unroll
+        for (int g = 0; g < G; ++g) units[g] = units_n[g];
+    }
+}
+// One wave per segment, like nn_sweep_kernel.  (Measured and not kept: the four waves of a workgroup taking the same piece
+// of four consecutive blocks and sharing its A operands through LDS, double-buffered, one barrier per 64 MFMAs of every
+// wave -- a quarter of the L2 traffic, 9.2 -> 2.3 GB per sweep, but 1.06-1.22 ms against this kernel's 0.84: the barrier,
+// the exposed LDS read at the head of every group and the lost cross-group pipelining cost more than the L2 gave back.)
+template <int QT, int G>
+__global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_bf16_kernel(
+    const IcpState *__restrict__ st, const uint4 *__restrict__ tgtb /* (n_tiles + pad) x 64 lanes x 16 B */, int n_tiles,
+    int n_words, const unsigned long long *__restrict__ mask, const int32_t *__restrict__ seg_blk,
+    const int32_t *__restrict__ seg_rank0, const int32_t *__restrict__ seg_n, const float4 *__restrict__ src4 /* slots */,
+    float *__restrict__ tr_b1, int32_t *__restrict__ tr_t1, float *__restrict__ tr_b2) {
+    __shared__ unsigned surv[NN_WAVES][NN_LIST_TILES / QT + 2 * G];
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int seg = blockIdx.x * NN_WAVES + wv;
+    if (seg >= st->n_segs) return;  // wave-uniform
+    const int blk = seg_blk[seg], r0 = seg_rank0[seg], n_s = seg_n[seg];
+    const int64_t base = (int64_t)blk * (NN_SB * 16);
+    unsigned *mine = surv[wv];
+    expand_ranks<G>(mask + (size_t)blk * n_words, n_words, r0, n_s, (unsigned)n_tiles, mine, lane);
+    const int q = lane >> 4, j = lane & 15;
+    bf8v b[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) {   // the B operand: pieces of the slot's (-2 x', -2 y', -2 z'), ones for |t'|^2's slots
+        const float4 sv = src4[base + sb * 16 + j];
+        unsigned short ps[3][3];
+        split3_bf16(sv.x, ps[0]); split3_bf16(sv.y, ps[1]); split3_bf16(sv.z, ps[2]);
+        BfFrag f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * q + e;
+            f.h[e] = k < 27 ? ps[k / 9][k % 3] : (k < 30 ? (unsigned short)0x3F80 : (unsigned short)0);
+        }
+        b[sb] = f.v;
+    }
+    float b1[NN_SB], b2[NN_SB];
+    int t1[NN_SB];
+#pragma unroll
+    for (int sb = 0; sb < NN_SB; ++sb) { b1[sb] = __uint_as_float(0x7F800000u); b2[sb] = b1[sb]; t1[sb] = n_tiles; }
+    sweep_list_bf16<QT, G>(mine, n_s, tgtb, lane, b, b1, t1, b2);
 #pragma unroll
     for (int sb = 0; sb < NN_SB; ++sb) {
         const size_t o = ((size_t)seg * 4 + q) * (NN_SB * 16) + (size_t)(sb * 16 + j);
@@ -2797,6 +2943,10 @@ int carve_workspace(pedp_ctx_t c, int64_t Ns, int64_t Nt, int max_iter, int qt, 
 
 // Enqueue one correspondence pass (transform, sweep, fallback).  mode as in
 // icp_transform_pack_kernel.
+inline bool nn_bf16_sweep() {  // PEDP_NN_F32=1: the dense sweep on the f32-input MFMA (A/B, tests)
+    static const bool off = getenv("PEDP_NN_F32") && atoi(getenv("PEDP_NN_F32")) != 0;
+    return !off;
+}
 int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_cloud_t tgt, int mode,
                     const TargetPrep &tp, double r, hipEvent_t ev0, hipEvent_t ev1, bool exhaustive = false) {
     const int64_t Ns = src->N, Nt = tgt->N;
@@ -2809,11 +2959,13 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
     const double r2cut = r_cull * r_cull * (1.0 + 1e-12);
     const float r_search = (float)(r_cull * (1.0 + 1e-6)) + 1e-6f;
     const int n_tiles = (int)(w.Nt_pad / (16 * w.qt));  // target units
+    // the dense sweep (units of four tiles) runs on the bf16 matrix pipe (PEDP_NN_F32=1: the f32-input MFMA of rounds 1-3)
+    const bool bf16_sweep = w.qt == 4 && nn_bf16_sweep() && tgt->tgt_bf != nullptr;
     {
         int64_t grid = (Ns + 511) / 512;  // 128 points per wave, 4 waves per workgroup
         hipLaunchKernelGGL(icp_transform_pack_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, w.st, mode,
                            src->pts, w.P, w.src_perm, Ns, w.B, w.eps, w.S, w.list, w.blk_sph, w.idx, w.d2, tp.Tn, tp.T2,
-                           r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2]);
+                           r1, r2cut, tp.lo[0], tp.lo[1], tp.lo[2], tp.hi[0], tp.hi[1], tp.hi[2], bf16_sweep ? 34.0f : 5.0f);
     }
     const float r2f = (float)(r * r) * 1.00001f;
     const unsigned sel_grid = (unsigned)((4 * w.Ns_pad + 255) / 256);
@@ -2844,7 +2996,18 @@ int enqueue_nn_pass(pedp_ctx_t c, const IcpWorkspace &w, pedp_cloud_t src, pedp_
         hipLaunchKernelGGL(nn_fallback_kernel<QTV>, dim3(fb_grid), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,     \
                            w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);       \
     } while (0)
-    if (w.qt == 4) PEDP_NN_STAGE(4, 2);
+    if (bf16_sweep) {
+        if (ev0) PEDP_HIP_CHECK(hipEventRecord(ev0, c->stream));
+        hipLaunchKernelGGL((nn_sweep_bf16_kernel<4, 2>), dim3(sweep_grid), dim3(NN_WAVES * 64), 0, c->stream, w.st,
+                           (const uint4 *)tgt->tgt_bf, n_tiles, w.n_words, w.mask, w.seg_blk, w.seg_rank0, w.seg_n,
+                           (const float4 *)w.B, w.tr_b1, w.tr_t1, w.tr_b2);
+        if (ev1) { PEDP_HIP_CHECK(hipEventRecord(ev1, c->stream)); c->nn_timed = true; }
+        hipLaunchKernelGGL(nn_select_kernel<4>, dim3(sel_grid), dim3(256), 0, c->stream, w.st, w.blk_segstart,
+                           w.tr_b1, w.tr_t1, w.tr_b2, tgt->pts, w.tgt_perm, Nt, w.P, w.eps, w.S, w.list, r2f, w.idx,
+                           w.d2, w.fb);
+        hipLaunchKernelGGL(nn_fallback_kernel<4>, dim3(fb_grid), dim3(FB_WAVES * 64), 0, c->stream, w.st, w.fb, w.list,
+                           w.mask, w.n_words, w.tile_sph, r_search, tgt->pts, w.tgt_perm, Nt, w.P, w.idx, w.d2);
+    } else if (w.qt == 4) PEDP_NN_STAGE(4, 2);
     else PEDP_NN_STAGE(1, 4);
 #undef PEDP_NN_STAGE
     PEDP_HIP_CHECK(hipGetLastError());
@@ -2980,6 +3143,22 @@ int ensure_target_pack(pedp_ctx_t c, pedp_cloud_t tgt, TargetPrep &tp) {
     return PEDP_OK;
 }
 
+// The bf16 pieces of the sorted operand, for the dense sweep: built when a call first takes that path
+int ensure_target_bf16(pedp_ctx_t c, pedp_cloud_t tgt) {
+    if (tgt->tgt_bf || !tgt->tgt4 || !nn_bf16_sweep()) return PEDP_OK;
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(uint4) * 4 * (size_t)tgt->tgt4_pad) != hipSuccess) {
+        pedp_set_error("pedp_icp: target pack allocation failed (bf16 operand)");
+        return PEDP_ERR_ALLOC;
+    }
+    tgt->tgt_bf = p;
+    const int64_t n = tgt->tgt4_pad * 4;
+    hipLaunchKernelGGL(pack_target_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)tgt->tgt4,
+                       tgt->tgt4_pad, (uint4 *)tgt->tgt_bf);
+    PEDP_HIP_CHECK(hipGetLastError());
+    return PEDP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -3026,6 +3205,8 @@ int icp_unit_size(pedp_cloud_t target, double r) {
 // order of the scene.
 int icp_prepare(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, TargetPrep &tp) {
     int rc = ensure_target_pack(c, target, tp);
+    if (rc) return rc;
+    rc = ensure_target_bf16(c, target);   // (with the pack, on the owner's stream: sub-contexts start after it is complete)
     if (rc) return rc;
     return ensure_spatial_perm(c, source);
 }
@@ -3557,6 +3738,7 @@ int pedp_nn(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, const double
     if (rc) return rc;
     TargetPrep tp;
     rc = ensure_target_pack(c, target, tp);
+    if (!rc) rc = ensure_target_bf16(c, target);
     if (rc) return rc;
     w.tgt4 = (const float4 *)target->tgt4;
     w.tile_sph = (const float4 *)target->tile_sph4;

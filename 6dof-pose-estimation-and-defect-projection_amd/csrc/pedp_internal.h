@@ -196,6 +196,7 @@ struct pedp_cloud_s {
     void *tile_sph4 = nullptr;  // one sphere per 64 sorted rows
     void *tile_sphw = nullptr;  // one sphere per 1024 sorted rows (one cull-mask word of 16-row tiles)
     void *tgt_s = nullptr;      // sorted rows as float64 x 3 (exact re-scoring)
+    void *tgt_bf = nullptr;     // the sorted operand as bf16 pieces for the dense sweep's v_mfma_f32_16x16x32_bf16 (1 KB per 16-row tile; built on first use)
     int64_t tgt4_pad = 0;
 };
 

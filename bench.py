@@ -60,6 +60,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector == f32-MFMA dense peak
+FLOP_PER_PAIR_BF16 = 64    # executed by the dense NN sweep on the bf16 pipe: 16 x 16 x 32 x 2 flop per 256 pairs
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TEST = 46        # Moeller-Trumbore with stored (v0, e1, e2)
 FLOP_PER_TEST_MFMA = 192     # matrix-pipe filter (round 4): 3 x v_mfma_f32_16x16x32_bf16 (16 x 16 x 32 x 2 flop) per 256 tests
@@ -623,15 +624,27 @@ def run(args):
                 "note": "every ray x every triangle (sweep variant 1), then every scene point x every model point in every "
                         "ICP pass (culling off), one stage after the other; same results as the headline path",
             }
+            nn_bf16 = os.environ.get("PEDP_NN_F32") != "1"     # the dense sweep's form (csrc/pedp_icp.hip: nn_bf16_sweep)
+            nn_key = "nn_sweep_bf16_kernel" if nn_bf16 else "nn_sweep_kernel"
+            nn_exec = (FLOP_PER_PAIR_BF16 if nn_bf16 else FLOP_PER_PAIR) * pairs / (ex_sweep_ms * 1e-3) / 1e12
+            nn_peak = PEAK_BF16_TFLOPS if nn_bf16 else PEAK_FP32_TFLOPS
             out["roofline_exhaustive_nn"] = {
-                "kernel": "nn_sweep_kernel<4,2> (all pairs)", "region": "exhaustive", "bound": "mfma",
-                "achieved": nn_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_TFLOPS,
-                "traffic": traffic.get("nn_sweep_kernel", {}).get("hbm_bytes_per_launch"),
+                "kernel": ("nn_sweep_bf16_kernel<4,2> (all pairs: one v_mfma_f32_16x16x32_bf16 per 16 x 16 pairs over exact three-way bf16 pieces)"
+                           if nn_bf16 else "nn_sweep_kernel<4,2> (all pairs, f32-input MFMA)"), "region": "exhaustive", "bound": "mfma",
+                "achieved": nn_exec, "peak": nn_peak, "unit": "TFLOP/s", "frac": nn_exec / nn_peak,
+                "traffic": traffic.get(nn_key, {}).get("hbm_bytes_per_launch"),
                 "traffic_source": traffic_source,
-                "mfma_util_pmc_committed_profile": traffic.get("nn_sweep_kernel", {}).get("mfma_util"),
+                "mfma_util_pmc_committed_profile": traffic.get(nn_key, {}).get("mfma_util"),
                 "kernel_ms": ex_sweep_ms, "launches_per_step": ex_passes, "kernel_ms_x_launches": ex_sweep_ms * ex_passes,
                 "region_ms_per_step": ex_ms,
-                "note": f"{FLOP_PER_PAIR} flop x {int(n_scene * share)} scene x {n_model} model points per launch (SURVEY s8d)"}
+                "algorithmic_8flop_tflops": nn_tflops, "algorithmic_8flop_frac_of_fp32_mfma_peak": nn_tflops / PEAK_FP32_TFLOPS,
+                "note": (f"frac counts the {FLOP_PER_PAIR_BF16} bf16 flop per pair the kernel EXECUTES (K = 32: 27 products of the coordinates' "
+                         "pieces + 3 of |t'|^2's, exact; the fp32 accumulation inside the pipe is covered by the slot's error bound, "
+                         "winners are re-scored in float64) against the dense bf16 peak; SURVEY s8d's 8 flop per pair (one K = 4 dot) "
+                         f"x {int(n_scene * share)} scene x {n_model} model points per launch beside it: the f32-input form of rounds 1-3 "
+                         "(PEDP_NN_F32=1) ran 1.69 ms = 0.555 of the fp32-MFMA peak, this one 0.84 ms with the same bits in every result"
+                         if nn_bf16 else
+                         f"{FLOP_PER_PAIR} flop x {int(n_scene * share)} scene x {n_model} model points per launch (SURVEY s8d)")}
             out["roofline_ray_sweep"] = {
                 "kernel": "ray_sweep_mfma_kernel<8> (every ray x every triangle: bf16 MFMA filter, exact test on the pairs that pass)",
                 "region": "exhaustive", "bound": "mfma",

@@ -457,3 +457,41 @@ def test_begin_end_equals_the_blocking_call(ctx, oracle):
         assert one["iters"] == two["iters"] and np.array_equal(one["corr"], two["corr"]) and np.array_equal(one["trace"], two["trace"])
     with pytest.raises(_lib.PedpError):
         _lib.icp_end(ctx)
+
+
+_DENSE_PROBE = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+from pedp_hip import _lib, synth
+ctx = _lib.Context(0)
+f = synth.Frame("parity")
+mesh = _lib.Mesh(ctx, f.verts_posed, f.tris)
+scene = f.scene(mesh.cast_rays(f.rays6, want_uv=False)["t_hit"])
+src, tgt = _lib.Cloud(ctx, scene), _lib.Cloud(ctx, f.model_points, f.normals)
+idx, d2 = _lib.nn(ctx, src, tgt, f.icp_init())
+_lib.icp_configure(ctx, exhaustive=True, timed_pass=1)
+r = _lib.icp(ctx, src, tgt, 10.0, f.icp_init(), max_iteration=8, relative_fitness=-1, relative_rmse=-1, want_corr=True, want_trace=True)
+np.savez(sys.argv[2], idx=idx, d2=d2, T=r["T"], corr=r["corr"], trace=r["trace"], fb=np.int64(_lib.icp_last_stats(ctx)[2]))
+"""
+
+
+def test_dense_sweep_on_the_bf16_pipe_equals_the_f32_form(tmp_path):
+    """The all-pairs sweep (pedp_nn, the exhaustive configuration, large radii) runs as one v_mfma_f32_16x16x32_bf16 per
+    16 x 16 pairs over exact three-way bf16 pieces; PEDP_NN_F32=1 keeps the f32-input MFMA of rounds 1-3.  Both are
+    filters in front of the float64 selection: nearest neighbours, squared distances, correspondences and every pass of the
+    trace agree bit for bit (the bf16 form's wider error bound only sends more slots to the exact search)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"dense{flag}.npz")
+        env = dict(os.environ, PEDP_NN_F32=flag)
+        p = subprocess.run([sys.executable, "-c", _DENSE_PROBE, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, p.stdout.decode()
+        outs.append(np.load(out))
+    for k in ("idx", "d2", "T", "corr", "trace"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert int(outs[0]["fb"]) >= int(outs[1]["fb"])

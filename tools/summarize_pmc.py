@@ -32,6 +32,7 @@ def pick(d, key, counter):
 
 
 KERNELS = (  # (substring of the kernel name, key in the JSON, reads are vector streams)
+    ("nn_sweep_bf16_kernel<4", "nn_sweep_bf16_kernel", True),
     ("nn_sweep_kernel<4", "nn_sweep_kernel", True),
     ("nn_sweep_kernel<1", "nn_sweep_kernel_culled", True),
     ("icp_pass_kernel", "icp_pass_kernel", True),
