@@ -733,6 +733,11 @@ __global__ void pack_target_bf16_kernel(const float4 *__restrict__ tgt4, int64_t
     }
     out[t] = f.q;
 }
+#if PEDP_NN_EXPERIMENT == 2   /* timing experiment (wrong results): every wave reads the same unit -- the operand out of L1 */
+#define PEDP_BF_UNIT(u) ((u) & 1u)
+#else
+#define PEDP_BF_UNIT(u) (u)
+#endif
 template <int QT, int G>
 __device__ __forceinline__ void sweep_list_bf16(const unsigned *__restrict__ mine, int n_s, const uint4 *__restrict__ tgtb, int lane,
                                                 const bf8v (&b)[NN_SB], float (&b1)[NN_SB], int (&t1)[NN_SB], float (&b2)[NN_SB]) {
@@ -748,7 +753,7 @@ __device__ __forceinline__ void sweep_list_bf16(const unsigned *__restrict__ min
     for (int g = 0; g < G; ++g) {
         units[g] = mine[g];
 #pragma unroll
-        for (int u = 0; u < QT; ++u) a[g * QT + u].q = tgtb[((size_t)units[g] * QT + u) * 64 + lane];
+        for (int u = 0; u < QT; ++u) a[g * QT + u].q = tgtb[((size_t)PEDP_BF_UNIT(units[g]) * QT + u) * 64 + lane];
     }
     f32x4 acc[NN_SB];
 #pragma unroll
@@ -760,7 +765,7 @@ __device__ __forceinline__ void sweep_list_bf16(const unsigned *__restrict__ min
         for (int g = 0; g < G; ++g) {
             units_n[g] = mine[k + G + g];  // pad units follow the last real one
 #pragma unroll
-            for (int u = 0; u < QT; ++u) an[g * QT + u].q = tgtb[((size_t)units_n[g] * QT + u) * 64 + lane];
+            for (int u = 0; u < QT; ++u) an[g * QT + u].q = tgtb[((size_t)PEDP_BF_UNIT(units_n[g]) * QT + u) * 64 + lane];
         }
 #pragma unroll
         for (int t = 0; t < U; ++t) {
@@ -780,9 +785,11 @@ __device__ __forceinline__ void sweep_list_bf16(const unsigned *__restrict__ min
                     b1[sb] = fminf(b1[sb], v);
                 }
                 acc[sb] = nxt;
+#if PEDP_NN_EXPERIMENT != 3
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
                 if (u == QT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // then its VALU ops
                 else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+#endif
             }
         }
 #pragma unroll
