@@ -2428,14 +2428,18 @@ int pedp_preprocess_source_ex(pedp_ctx_t c, const double *pts, int64_t N, int pt
     double *d_avg = nullptr;
     rc = knn_core(c, C_pts, m3, prm->outlier_neighbors, lo, hi, &d_avg);
     if (rc) return rc;
-    std::vector<double> dist((size_t)m3);
-    { int dn_ = pedp_download(c, dist.data(), d_avg, sizeof(double) * (size_t)m3); if (dn_) return dn_; }
+    // (read where the copy lands, in the context's page-locked buffer: a std::vector of its own cost an allocation, its
+    // page faults and a staged copy -- 0.13 ms of host time in a frame's trace for 12 k doubles)
+    const double *dist = nullptr;
+    { const void *v_ = nullptr; int dn_ = pedp_download_view(c, d_avg, sizeof(double) * (size_t)m3, &v_); if (dn_) return dn_; dist = (const double *)v_; }
     int64_t valid = 0;
-    for (int64_t i = 0; i < m3; ++i) valid += dist[i] >= 0.0 ? 1 : 0;
+    double sum = 0.0;     // (index order, like the two separate loops before: the count is exact in any order)
+    for (int64_t i = 0; i < m3; ++i) {
+        valid += dist[i] >= 0.0 ? 1 : 0;
+        sum += dist[i] > 0.0 ? dist[i] : 0.0;
+    }
     int64_t m4 = 0;
     if (valid > 0) {
-        double sum = 0.0;
-        for (int64_t i = 0; i < m3; ++i) sum += dist[i] > 0.0 ? dist[i] : 0.0;
         const double mean = sum / (double)valid;
         double sq = 0.0;
         for (int64_t i = 0; i < m3; ++i) sq += dist[i] > 0.0 ? (dist[i] - mean) * (dist[i] - mean) : 0.0;

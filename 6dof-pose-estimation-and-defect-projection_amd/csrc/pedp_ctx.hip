@@ -116,6 +116,17 @@ int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
     return PEDP_OK;
 }
 
+int pedp_download_view(pedp_ctx_s *c, const void *src, size_t bytes, const void **view) {
+    int rc = stage_reserve(c, 1, bytes > STAGE_MIN ? bytes : STAGE_MIN);
+    if (rc) return rc;
+    if (bytes > c->stage_cap[1]) { pedp_set_error("pedp_download_view: %zu bytes exceed the staging buffer", bytes); return PEDP_ERR_BAD_ARG; }
+    if (bytes) PEDP_HIP_CHECK(hipMemcpyAsync(c->stage[1], src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PEDP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->stage_busy = false;
+    *view = c->stage[1];
+    return PEDP_OK;
+}
+
 int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PEDP_OK;
     if (bytes < STAGE_MIN) {

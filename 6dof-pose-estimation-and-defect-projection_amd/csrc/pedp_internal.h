@@ -20,6 +20,9 @@ int pedp_upload(pedp_ctx_s *c, void *dst, const void *src, size_t bytes);
 // The way back: device -> caller's (pageable) array through the same staging buffers.  Returns
 // after the data are in `dst` (the stream has been drained up to and including the copy).
 int pedp_download(pedp_ctx_s *c, void *dst, const void *src, size_t bytes);
+// `bytes` of device memory into the context's page-locked download buffer (valid until the next download through it);
+// returns when the copy is complete: host code that only READS a result needs neither an array of its own nor a staged copy
+int pedp_download_view(pedp_ctx_s *c, const void *src, size_t bytes, const void **view);
 int pedp_download_parts(pedp_ctx_s *c, const void *src, size_t span, int n, const size_t *off, void *const *dst, const size_t *bytes);
 struct pedp_ctx_s;
 int pedp_sort_keys64_begin(pedp_ctx_s *c, int64_t N, int bits, unsigned long long **d_keys);

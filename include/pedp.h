@@ -399,7 +399,7 @@ int pedp_icp(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target,
  * (enqueueing a frame's ray stage on ANOTHER context, bench.py's step) overlaps with the registration instead of waiting in
  * front of it.  Between the two calls this context must not be used for anything else (its workspace and its page-locked
  * state block belong to the pending registration): a second pedp_icp_begin, pedp_icp or pedp_icp_batched returns
- * PEDP_ERR_ARG; destroying the context or either cloud with a registration pending is an error of the caller.  want_trace:
+ * PEDP_ERR_BAD_ARG; destroying the context or either cloud with a registration pending is an error of the caller.  want_trace:
  * pedp_icp_end's `trace` may be non-null.  The reference has no counterpart (registration_icp is one blocking call,
  * src/pose_estimation.py:447-453). */
 int pedp_icp_begin(pedp_ctx_t ctx, pedp_cloud_t source, pedp_cloud_t target, const pedp_icp_params *params,
