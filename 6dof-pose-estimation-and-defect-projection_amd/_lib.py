@@ -115,6 +115,7 @@ PROTOTYPES = {
     "pedp_nn_last_sweep_ms": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "pedp_icp_last_stats": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "pedp_icp_last_planned_passes": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "pedp_debug_nn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "pedp_icp_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(IcpParams), C.c_void_p, C.c_int]),
     "pedp_icp_end": (C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_void_p, C.c_void_p]),
     "pedp_icp_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -649,6 +650,15 @@ def icp(ctx, source, target, max_correspondence_distance, init, estimator=POINT_
     if want_trace:
         out["trace"] = trace[: it.value + 1]
     return out
+
+
+def debug_nn_bf16(ctx, src4, tgt4):
+    """g of every (scene row, model row) pair as the dense sweep's bf16 MFMA produces it (pedp_debug_nn_bf16)."""
+    a = np.ascontiguousarray(src4, np.float32).reshape(-1, 4)
+    b = np.ascontiguousarray(tgt4, np.float32).reshape(-1, 4)
+    g = np.empty((len(a), len(b)), np.float32)
+    check(load().pedp_debug_nn_bf16(ctx._h, _ptr(a), len(a), _ptr(b), len(b), _ptr(g)), "pedp_debug_nn_bf16")
+    return g
 
 
 def icp_begin(ctx, source, target, max_correspondence_distance, init, estimator=POINT_TO_PLANE, max_iteration=30,

@@ -846,6 +846,31 @@ __global__ __launch_bounds__(NN_WAVES * 64) void nn_sweep_bf16_kernel(
     }
 }
 
+// Diagnostics (tests/test_icp_gpu.py measures the bf16 form's error against float64): g of every (scene row, model row)
+// pair as the sweep's MFMA produces it -- one wave per (16 scene rows, 16 model rows), the same operand packing
+__global__ __launch_bounds__(64) void nn_bf16_debug_kernel(const uint4 *__restrict__ tgtb, const float4 *__restrict__ src4, int n_src16,
+                                                           int n_tgt, float *__restrict__ g_out) {
+    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    const int sb = blockIdx.x % n_src16, tile = blockIdx.x / n_src16;
+    const float4 sv = src4[(size_t)sb * 16 + j];
+    unsigned short ps[3][3];
+    split3_bf16(sv.x, ps[0]); split3_bf16(sv.y, ps[1]); split3_bf16(sv.z, ps[2]);
+    BfFrag f, a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * q + e;
+        f.h[e] = k < 27 ? ps[k / 9][k % 3] : (k < 30 ? (unsigned short)0x3F80 : (unsigned short)0);
+    }
+    a.q = tgtb[(size_t)tile * 64 + lane];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, f.v, zero, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // D: column = scene slot j, row = model row 4 q + e of the tile
+        const int row = tile * 16 + 4 * q + e;
+        if (row < n_tgt) g_out[((size_t)sb * 16 + j) * n_tgt + row] = r[e];
+    }
+}
+
 // ---- 4. exact selection, four threads per slot (thread gl of a slot reads lane group gl of
 // every segment of its block): window = min b1 + 2 eps; every (segment, lane group) whose best
 // tile is inside the window has its 4 rows re-scored in float64 (the oracle's formula,
@@ -3817,6 +3842,32 @@ int pedp_icp_last_stats(pedp_ctx_t c, int64_t *passes, int64_t *pairs_swept, int
     if (passes) *passes = c->icp_last_passes;
     if (pairs_swept) *pairs_swept = c->icp_last_cand;
     if (fallback_points) *fallback_points = c->icp_last_fb;
+    return PEDP_OK;
+}
+
+int pedp_debug_nn_bf16(pedp_ctx_t c, const float *src4, int64_t n_src, const float *tgt4, int64_t n_tgt, float *g) {
+    PEDP_REQUIRE(c && src4 && tgt4 && g && n_src > 0 && n_tgt > 0 && n_src % 16 == 0 && n_tgt % 16 == 0 && n_src * n_tgt <= ((int64_t)1 << 26),
+                 "pedp_debug_nn_bf16: counts must be positive multiples of 16, at most 2^26 pairs");
+    PEDP_HIP_CHECK(hipSetDevice(c->device));
+    float4 *d_s = nullptr, *d_t = nullptr;
+    uint4 *d_b = nullptr;
+    float *d_g = nullptr;
+    hipError_t e = hipMalloc((void **)&d_s, sizeof(float4) * (size_t)n_src);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_t, sizeof(float4) * (size_t)n_tgt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, sizeof(uint4) * 4 * (size_t)n_tgt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_g, sizeof(float) * (size_t)(n_src * n_tgt));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_s, src4, sizeof(float4) * (size_t)n_src, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, tgt4, sizeof(float4) * (size_t)n_tgt, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack_target_bf16_kernel, dim3((unsigned)((n_tgt * 4 + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)d_t, n_tgt, d_b);
+        hipLaunchKernelGGL(nn_bf16_debug_kernel, dim3((unsigned)((n_src / 16) * (n_tgt / 16))), dim3(64), 0, c->stream, (const uint4 *)d_b,
+                           (const float4 *)d_s, (int)(n_src / 16), (int)n_tgt, d_g);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(g, d_g, sizeof(float) * (size_t)(n_src * n_tgt), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_s); (void)hipFree(d_t); (void)hipFree(d_b); (void)hipFree(d_g);
+    PEDP_HIP_CHECK(e);
     return PEDP_OK;
 }
 

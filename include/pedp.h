@@ -479,6 +479,11 @@ int pedp_icp_last_stats(pedp_ctx_t ctx, int64_t *passes, int64_t *pairs_swept, i
  * tests/test_icp_gpu.py compares).  No counterpart in the reference (src/pose_estimation.py:447-453 calls Open3D). */
 int pedp_icp_last_planned_passes(pedp_ctx_t ctx, int64_t *planned);
 
+/* Diagnostics of the dense sweep's bf16 form (tests measure its error against float64): for n_src scene rows (b.x, b.y, b.z, .)
+ * = (-2 s') and n_tgt model rows (t'.x, t'.y, t'.z, |t'|^2), float32 x 4 each on the host, counts multiples of 16,
+ * g[i * n_tgt + j] = |t'_j|^2 - 2 s'_i . t'_j exactly as the sweep's v_mfma_f32_16x16x32_bf16 produces it (same operand packing). */
+int pedp_debug_nn_bf16(pedp_ctx_t ctx, const float *src4, int64_t n_src, const float *tgt4, int64_t n_tgt, float *g);
+
 /* ---------------------------------------------------------------- multi-GPU collectives
  * One process per GPU.  The reference has no distributed path; these entry points
  * exist so that the two exchange steps of the sharded path run inside the library, on

@@ -495,3 +495,26 @@ def test_dense_sweep_on_the_bf16_pipe_equals_the_f32_form(tmp_path):
     for k in ("idx", "d2", "T", "corr", "trace"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert int(outs[0]["fb"]) >= int(outs[1]["fb"])
+
+
+def test_bf16_contraction_error_stays_inside_the_bound(ctx):
+    """The dense sweep's g = |t'|^2 - 2 s'.t' as ONE bf16 MFMA over exact three-way pieces: against float64 on the same
+    float32 inputs the error is the pipe's fp32 accumulation alone.  The slot's bound charges 34 M 2^-23 for it (M = 2 |s'|_1
+    max|t'|_1 + max|t'|^2); measured over 4 M pairs at the bench frame's scale it uses a small part of that."""
+    from pedp_hip import _lib
+
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for scale_s, scale_t in ((400.0, 120.0), (60.0, 60.0), (5.0, 150.0)):
+        s = (rng.uniform(-1, 1, (2048, 3)) * scale_s).astype(np.float32)
+        t = (rng.uniform(-1, 1, (2048, 3)) * scale_t).astype(np.float32)
+        t2 = (t.astype(np.float64) ** 2).sum(1).astype(np.float32)
+        src4 = np.column_stack([-2.0 * s, np.ones(len(s), np.float32)]).astype(np.float32)
+        tgt4 = np.column_stack([t, t2]).astype(np.float32)
+        g = _lib.debug_nn_bf16(ctx, src4, tgt4).astype(np.float64)
+        ref = t2.astype(np.float64)[None, :] + src4[:, :3].astype(np.float64) @ t.astype(np.float64).T
+        Tn, T2 = np.abs(t).sum(1).max(), t2.max()
+        M = 2.0 * np.abs(s).sum(1) * Tn + T2                          # per scene row, like pack_store's Mi
+        used = np.abs(g - ref) / (34.0 * M[:, None] * 2.0 ** -23)
+        worst = max(worst, float(used.max()))
+    assert worst < 0.25, worst
