@@ -3518,7 +3518,11 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
     key.seg = no_exit ? all : (all < 10 ? all : 10);
     key.poses = G;
     slot = 3 * slot + (key.seg == 1 ? 0 : (key.seg == 2 ? 1 : 2));  // a graph per group size and kind of stretch
-    if (!(c->icp_bgraph[slot] && graph_key_equal(c->icp_bgraph_key[slot], key))) {
+    // One or two passes per stretch (a z-search probe is a one-iteration registration) are launched as they are: a graph
+    // of two kernels saves nothing, and with a new scene handle every frame its capture and instantiation (35-50 us) came
+    // back for every frame's first batch
+    const bool direct = key.seg <= 2;
+    if (!direct && !(c->icp_bgraph[slot] && graph_key_equal(c->icp_bgraph_key[slot], key))) {
         if (c->icp_bgraph[slot]) { (void)hipGraphExecDestroy(c->icp_bgraph[slot]); c->icp_bgraph[slot] = nullptr; }
         hipGraph_t graph = nullptr;
         PEDP_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -3561,6 +3565,17 @@ int icp_batch_fused(pedp_ctx_t c, pedp_cloud_t source, pedp_cloud_t target, cons
                            w.pose_stride, (int)(sizeof(IcpState) / 8), (char *)w.ticket, (int)(zero_bytes / 8));
         bool finished = false;
         for (int guard = 0; guard < (1 << 20) && !finished; ++guard) {
+            if (direct) {
+                for (int p = 0; p < key.seg; ++p) {
+                    int rp = enqueue_fused_pass(c, w, source, target, prms[0].estimator, tp, nullptr, nullptr, true, nullptr, G);
+                    if (rp) return rp;
+                    if (unfused_finish())
+                        hipLaunchKernelGGL(icp_finish_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, c->stream, w.st, w.live, w.live_list,
+                                           w.n_lw, w.cpart, w.packet, 0, prms[0].estimator, (double *)nullptr, w.hist,
+                                           0.5 * (tp.lo[0] + tp.hi[0]), 0.5 * (tp.lo[1] + tp.hi[1]), 0.5 * (tp.lo[2] + tp.hi[2]),
+                                           G > 1 ? w.pose_stride : (size_t)0);
+                }
+            } else
             PEDP_HIP_CHECK(hipGraphLaunch(c->icp_bgraph[slot], c->stream));
             hipLaunchKernelGGL(batch_state_gather_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, (const char *)w.st, w.pose_stride,
                                (int)(sizeof(IcpState) / 8), (unsigned long long *)down);
