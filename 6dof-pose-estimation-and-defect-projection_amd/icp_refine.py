@@ -382,17 +382,17 @@ def improve_result(source_processed, original_target_processed, current_result, 
     while unfinished():
         # ---- draw the next `n` restarts as the one-by-one loop would if nothing changed in between
         n = min(ahead, 50 - rounds)
-        rng_before = np.random.get_state()
+        rng_before = np.random.get_state() if n > 1 else None          # (a copy of the 624-word state: only where it can be needed)
         radius = settings["refine_registration"]["distance_threshold"]
         radii, starts, rng_after = [], [], []
-        for _ in range(n):
+        for k_ahead in range(n):
             radius = radius * np.random.uniform(0.8, 1.2)
             wobble = np.eye(4)
             wobble[:3, :3] = reg.get_rotation_matrix_from_xyz([np.random.uniform(-0.01, 0.01) for _ in range(3)])
             wobble[:3, 3] = np.random.uniform(-spread, spread, 3)
             radii.append(radius)
             starts.append(wobble @ best_T)
-            rng_after.append(np.random.get_state())
+            rng_after.append(np.random.get_state() if k_ahead + 1 < n else None)   # (the state behind the last draw is the live one)
         try:
             results = reg.registration_icp_batch(d_src, d_tgt, radii, starts, plane)
         except Exception as exc:
